@@ -1,0 +1,336 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's sampling hot path.
+
+This file is the checker the HIP path is compared with; it is never imported by
+``rap_amd/`` (the product) and is never the thing measured, except as the
+``cpu_baseline`` leg of ``bench.py``.
+
+It restates, function by function, the arithmetic of
+
+* ``rectified_point_flow/sampler.py``            (flow_sampler, euler_step)
+* ``rectified_point_flow/flow_model/*.py``       (PointCloudDiT and its layers)
+* ``rectified_point_flow/procrustes.py``         (solve_procrustes, fit_transformations, rigidify)
+* ``rectified_point_flow/utils/point_clouds.py`` (split_parts, repeat_by_cu_seqlens)
+* the closure of ``rectified_point_flow/modeling.py:659-722`` (sample_rectified_flow)
+
+as plain functional torch-CPU code over a ``state_dict`` (fp32 or fp64), each
+function citing the reference lines it follows.  Two third-party pieces whose
+source is not in the mount are restated from their published behaviour:
+``flash_attn.flash_attn_varlen_qkvpacked_func`` (flash-attn 2.7.4.post1,
+install.sh:19) and diffusers 0.33.0 ``FeedForward("geglu")`` / ``Timesteps`` /
+``TimestepEmbedding`` (install.sh:9) -- those two are "parity unpinned" (the
+reference ships no test for them).
+
+Pinning: ``tests/test_oracle_vs_reference.py`` executes the reference's own
+unmodified modules (``oracle/ref_loader.py``) on the same inputs and requires
+agreement to fp32 round-off; ``tests/golden/*.npz`` were produced by the
+reference's modules (``oracle/make_golden.py``) and are checked against this
+file on every CPU test run (the mount does not exist on the GPU box).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------
+# utils/point_clouds.py
+# ----------------------------------------------------------------------------
+def repeat_by_cu_seqlens(x: torch.Tensor, cu_seqlens: torch.Tensor) -> torch.Tensor:
+    """point_clouds.py:161-184 -- row b of x repeated (cu[b+1]-cu[b]) times."""
+    lens = (cu_seqlens[1:] - cu_seqlens[:-1]).to(torch.int64)
+    idx = torch.repeat_interleave(torch.arange(x.shape[0]), lens)
+    return x.index_select(0, idx)
+
+
+def split_parts(pointclouds: torch.Tensor, points_per_part: torch.Tensor, cu_seqlens_batch: torch.Tensor):
+    """point_clouds.py:6-48 (packed branch): list over samples of list over non-empty parts."""
+    if cu_seqlens_batch is None:
+        raise ValueError("cu_seqlens_batch is required when pointclouds has shape (TP, 3)")
+    out = []
+    counts_per_batch = points_per_part.tolist()
+    for b, counts in enumerate(counts_per_batch):
+        seg = pointclouds[int(cu_seqlens_batch[b]):int(cu_seqlens_batch[b + 1])]
+        assert sum(counts) == seg.size(0), "Mismatch detected: sum(counts) != segment length"
+        out.append([s for s in torch.split(seg, counts, dim=0) if s.size(0) > 0])
+    return out
+
+
+# ----------------------------------------------------------------------------
+# flow_model/embedding.py
+# ----------------------------------------------------------------------------
+def posenc(x: torch.Tensor, num_freqs: int = 10) -> torch.Tensor:
+    """embedding.py:29-58: [x, sin(f0 x), cos(f0 x), ..., sin(f9 x), cos(f9 x)], f_k = 2^k."""
+    outs = [x]
+    freqs = 2.0 ** torch.linspace(0.0, num_freqs - 1, steps=num_freqs)
+    for f in freqs:
+        fx = x * f.to(x.dtype)
+        outs.append(torch.sin(fx))
+        outs.append(torch.cos(fx))
+    return torch.cat(outs, -1)
+
+
+def encoding_manager(sd, x, cond, feats, scales_pt):
+    """embedding.py:131-179: cat[PE63(cond), PE63(x), PE21(scale), feat] -> emb_proj."""
+    emb = torch.cat([posenc(cond), posenc(x), posenc(scales_pt.unsqueeze(-1)), feats], dim=-1)
+    return F.linear(emb, sd["encoding_manager.emb_proj.weight"], sd["encoding_manager.emb_proj.bias"])
+
+
+# ----------------------------------------------------------------------------
+# flow_model/norm.py (+ diffusers Timesteps / TimestepEmbedding)
+# ----------------------------------------------------------------------------
+def timestep_sinusoid(t: torch.Tensor, num_channels: int = 256) -> torch.Tensor:
+    """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0, scale=1)
+    as configured at norm.py:50-52: [cos(t w_i), sin(t w_i)], w_i = exp(-ln(1e4) i/128).
+    The frequencies are built in fp32 (as diffusers does) and the product/sin/cos in fp32."""
+    half = num_channels // 2
+    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / half
+    w = torch.exp(exponent)
+    arg = t[:, None].float() * w[None, :]
+    return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
+
+
+def adaln_scale_shift(sd, prefix: str, t: torch.Tensor):
+    """norm.py:71-73: emb = linear(SiLU(linear_2(SiLU(linear_1(TS(t)))))); scale, shift = chunk."""
+    dt = sd[prefix + "linear.weight"].dtype
+    ts = timestep_sinusoid(t).to(dt)
+    h = F.linear(ts, sd[prefix + "timestep_embedder.linear_1.weight"], sd[prefix + "timestep_embedder.linear_1.bias"])
+    h = F.linear(F.silu(h), sd[prefix + "timestep_embedder.linear_2.weight"], sd[prefix + "timestep_embedder.linear_2.bias"])
+    e = F.linear(F.silu(h), sd[prefix + "linear.weight"], sd[prefix + "linear.bias"])
+    return e.chunk(2, dim=-1)
+
+
+def adaptive_layer_norm(sd, prefix, x, t, cu_batch):
+    """norm.py:60-76: LN(no affine, eps 1e-5)(x) * (1 + scale_b) + shift_b."""
+    scale, shift = adaln_scale_shift(sd, prefix, t)
+    scale = repeat_by_cu_seqlens(scale, cu_batch)
+    shift = repeat_by_cu_seqlens(shift, cu_batch)
+    return F.layer_norm(x, (x.shape[-1],), eps=1e-5) * (1 + scale) + shift
+
+
+def multi_head_rms_norm(x, gamma):
+    """norm.py:28-33: F.normalize(x, dim=-1, eps=1e-12) * gamma * sqrt(Dh)."""
+    return F.normalize(x, dim=-1) * gamma * (x.shape[-1] ** 0.5)
+
+
+# ----------------------------------------------------------------------------
+# flow_model/layer.py (+ flash-attn varlen, diffusers FeedForward)
+# ----------------------------------------------------------------------------
+def varlen_attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor) -> torch.Tensor:
+    """flash_attn_varlen_qkvpacked_func(qkv (T,3,H,D), cu_seqlens, softmax_scale=D^-1/2,
+    causal=False, softcap=0, dropout=0) as called at layer.py:106-111,123-128."""
+    T, _, H, D = qkv.shape
+    out = torch.zeros((T, H, D), dtype=qkv.dtype)
+    cu = cu_seqlens.tolist()
+    for s in range(len(cu) - 1):
+        a, b = cu[s], cu[s + 1]
+        if b == a:
+            continue
+        q, k, v = (qkv[a:b, i].transpose(0, 1) for i in range(3))
+        out[a:b] = F.scaled_dot_product_attention(q, k, v).transpose(0, 1)
+    return out
+
+
+def attention_block(sd, prefix, which, x, cu_seqlens, H):
+    """layer.py:98-131: qkv_proj (no bias) -> view (T,3,H,Dh) -> qk-norm -> varlen attn -> out_proj."""
+    T, d = x.shape
+    qkv = F.linear(x, sd[prefix + f"{which}_qkv_proj.weight"]).reshape(T, 3, H, d // H)
+    q, k, v = qkv.unbind(dim=1)                                               # layer.py:91-96
+    q = multi_head_rms_norm(q, sd[prefix + f"{which}_q_norm.gamma"])
+    k = multi_head_rms_norm(k, sd[prefix + f"{which}_k_norm.gamma"])
+    out = varlen_attention(torch.stack([q, k, v], dim=1), cu_seqlens).reshape(T, d)
+    return F.linear(out, sd[prefix + f"{which}_out_proj.weight"], sd[prefix + f"{which}_out_proj.bias"])
+
+
+def feed_forward(sd, prefix, x):
+    """diffusers FeedForward(dim, activation_fn="geglu") (layer.py:89,164):
+    u = proj(x); h, g = chunk(u); y = h * gelu_erf(g); out = net.2(y)."""
+    u = F.linear(x, sd[prefix + "ff.net.0.proj.weight"], sd[prefix + "ff.net.0.proj.bias"])
+    h, g = u.chunk(2, dim=-1)
+    return F.linear(h * F.gelu(g), sd[prefix + "ff.net.2.weight"], sd[prefix + "ff.net.2.bias"])
+
+
+def dit_layer(sd, i, h, t, cu_batch, cu_part, H, taps=None):
+    """layer.py:134-166."""
+    p = f"transformer_layers.{i}."
+    x = adaptive_layer_norm(sd, p + "self_prenorm.", h, t, cu_batch)
+    if taps is not None and i == 0:
+        taps["l0_self_prenorm"] = x.clone()
+    a = attention_block(sd, p, "self", x, cu_part, H)
+    h = h + a
+    if taps is not None and i == 0:
+        taps["l0_after_part_attn"] = h.clone()
+    x = adaptive_layer_norm(sd, p + "global_prenorm.", h, t, cu_batch)
+    h = h + attention_block(sd, p, "global", x, cu_batch, H)
+    if taps is not None and i == 0:
+        taps["l0_after_global_attn"] = h.clone()
+    x = F.layer_norm(h, (h.shape[-1],), sd[p + "ff_norm.weight"], sd[p + "ff_norm.bias"], eps=1e-5)
+    h = h + feed_forward(sd, p, x)
+    if taps is not None and i == 0:
+        taps["l0_out"] = h.clone()
+    return h
+
+
+# ----------------------------------------------------------------------------
+# flow_model/point_cloud_dit.py
+# ----------------------------------------------------------------------------
+def dit_forward(sd, cfg, x, timesteps, cond, feats, scales, anchor, cu_batch, cu_part,
+                return_transformer_features: bool = False, taps: dict | None = None):
+    """PointCloudDiT.forward (point_cloud_dit.py:141-191)."""
+    scales_pt = repeat_by_cu_seqlens(scales, cu_batch)                        # :174
+    h = encoding_manager(sd, x, cond, feats, scales_pt)                       # :175
+    emb = sd["anchor_part_emb.weight"]
+    h = h + torch.where(anchor[:, None], emb[1][None, :], emb[0][None, :])    # :119-139
+    if taps is not None:
+        taps["embed"] = h.clone()
+    for i in range(cfg["num_layers"]):                                        # :179-180
+        h = dit_layer(sd, i, h, timesteps, cu_batch, cu_part, cfg["num_heads"], taps)
+    y = F.silu(F.linear(h, sd["final_mlp.0.weight"], sd["final_mlp.0.bias"]))  # :111-117,183-184
+    y = F.silu(F.linear(y, sd["final_mlp.2.weight"], sd["final_mlp.2.bias"]))
+    v = F.linear(y, sd["final_mlp.4.weight"])
+    if return_transformer_features:
+        return {"velocity": v, "transformer_features": h}
+    return v
+
+
+# ----------------------------------------------------------------------------
+# procrustes.py
+# ----------------------------------------------------------------------------
+def solve_procrustes(source: torch.Tensor, target: torch.Tensor):
+    """procrustes.py:6-37.  Convention target ~= source @ R^T + t."""
+    sm = source.mean(dim=0, keepdim=True)
+    tm = target.mean(dim=0, keepdim=True)
+    Hm = (source - sm).t() @ (target - tm)
+    U, _, Vt = torch.linalg.svd(Hm)
+    R = Vt.t() @ U.t()
+    if torch.det(R) < 0:
+        Vt = Vt.clone()
+        Vt[-1, :] *= -1
+        R = Vt.t() @ U.t()
+    t = tm - sm @ R.t()
+    return R, t.squeeze(0)
+
+
+def fit_transformations(source, target, points_per_part, cu_seqlens_batch):
+    """procrustes.py:40-84: zero rows for empty parts."""
+    B, P = points_per_part.shape
+    ps = split_parts(source, points_per_part, cu_seqlens_batch)
+    pt = split_parts(target, points_per_part, cu_seqlens_batch)
+    R = torch.zeros(B, P, 3, 3, dtype=source.dtype)
+    t = torch.zeros(B, P, 3, dtype=source.dtype)
+    for b in range(B):
+        for p in range(P):
+            if points_per_part[b, p] == 0:
+                continue
+            # NB (procrustes.py:79): the reference indexes the *compacted* per-sample list with p,
+            # i.e. it assumes empty parts only ever trail the non-empty ones (the collate guarantees it).
+            R[b, p], t[b, p] = solve_procrustes(ps[b][p], pt[b][p])
+    return R, t
+
+
+def rigidify_prediction_with_procrustes(prediction, condition, points_per_part, cu_seqlens_batch):
+    """procrustes.py:86-118: out[off:off+n] = cond_p R^T + t in (b, p) order."""
+    B, P = points_per_part.shape
+    ps = split_parts(condition, points_per_part, cu_seqlens_batch)
+    pt = split_parts(prediction, points_per_part, cu_seqlens_batch)
+    out = torch.zeros_like(prediction)
+    off = 0
+    for b in range(B):
+        for p in range(P):
+            n = int(points_per_part[b, p])
+            if n == 0:
+                continue
+            R, t = solve_procrustes(ps[b][p], pt[b][p])
+            out[off:off + n] = ps[b][p] @ R.t() + t
+            off += n
+    return out
+
+
+# ----------------------------------------------------------------------------
+# sampler.py
+# ----------------------------------------------------------------------------
+def euler_step(x_t, t: float, dt: float, flow_model_fn):
+    """sampler.py:79-92."""
+    v = flow_model_fn(x_t, t)
+    x0_hat = x_t - v * t
+    x_t = x_t - dt * v
+    return x_t, x0_hat
+
+
+def flow_sampler(flow_model_fn, x_1, num_steps, points_per_part, cu_seqlens_batch, condition,
+                 rigidity_forcing: bool):
+    """sampler.py:11-74 with return_trajectory=True (the only way modeling.py:719 calls it)."""
+    dt = 1.0 / num_steps
+    x_t = x_1.clone()
+    traj = torch.empty((num_steps, *x_1.shape), dtype=x_1.dtype)
+    traj_xt = torch.empty((num_steps, *x_1.shape), dtype=x_1.dtype)
+    for step in range(num_steps):
+        t = 1 - step * dt
+        x_t, x0_hat = euler_step(x_t, t, dt, flow_model_fn)
+        if rigidity_forcing:
+            x0_r = rigidify_prediction_with_procrustes(x0_hat, condition, points_per_part, cu_seqlens_batch)
+            x_t = x0_r * (1 - t + dt) + x_1 * (t - dt)
+        traj[step] = x0_hat
+        traj_xt[step] = x_t
+    return {"end_point_trajectory": traj, "trajectory": traj_xt}
+
+
+# ----------------------------------------------------------------------------
+# modeling.py:203-231, 632-741 (the closure around the sampler) + :389-391 (final poses)
+# ----------------------------------------------------------------------------
+def prepare_cu_seqlens(inputs):
+    ppp = inputs["points_per_part"]
+    cu_part = F.pad(torch.cumsum(ppp[ppp > 0], 0), (1, 0)).to(torch.int32)    # modeling.py:219-222
+    cu_batch = inputs["cu_seqlens"].to(torch.int32)                            # modeling.py:223
+    return cu_batch, cu_part
+
+
+@torch.inference_mode()
+def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.float32,
+           max_steps: int | None = None):
+    """sample_rectified_flow + fit_transformations on the last end-point (modeling.py:356-391).
+
+    ``max_steps`` (oracle-only convenience for the bounded CPU baseline): run only the first
+    ``max_steps`` of ``num_steps`` flow steps (same dt and time grid)."""
+    sd = {k: v.to(dtype) for k, v in sd.items()}
+    cond = inputs["pointclouds"].to(dtype)
+    feats = inputs["features"].to(dtype)
+    scales = inputs["scales"].to(dtype)
+    x_1 = inputs["x_1"].to(dtype)
+    anchor = inputs["anchor_indices"]
+    ppp = inputs["points_per_part"]
+    cu_batch, cu_part = prepare_cu_seqlens(inputs)
+    B = cu_batch.shape[0] - 1
+
+    def fn(x, t):
+        ts = torch.full((B,), t, dtype=dtype)                                  # modeling.py:674
+        return dit_forward(sd, cfg, x, ts, cond, feats, scales, anchor, cu_batch, cu_part)
+
+    if max_steps is None:
+        res = flow_sampler(fn, x_1, num_steps, ppp, cu_batch, cond, rigidity_forcing)
+    else:
+        dt = 1.0 / num_steps
+        x_t = x_1.clone()
+        traj = torch.empty((max_steps, *x_1.shape), dtype=dtype)
+        traj_xt = torch.empty((max_steps, *x_1.shape), dtype=dtype)
+        for step in range(max_steps):
+            t = 1 - step * dt
+            x_t, x0_hat = euler_step(x_t, t, dt, fn)
+            if rigidity_forcing:
+                x0_r = rigidify_prediction_with_procrustes(x0_hat, cond, ppp, cu_batch)
+                x_t = x0_r * (1 - t + dt) + x_1 * (t - dt)
+            traj[step] = x0_hat
+            traj_xt[step] = x_t
+        res = {"end_point_trajectory": traj, "trajectory": traj_xt}
+    R, t = fit_transformations(cond, res["end_point_trajectory"][-1], ppp, cu_batch)
+    return {"end_point_trajectory": res["end_point_trajectory"], "trajectory": res["trajectory"], "R": R, "t": t}
+
+
+# ----------------------------------------------------------------------------
+# eval/metrics.py:284-294 -- the SE(3) error formulae used to report pose deviation
+# ----------------------------------------------------------------------------
+def rotation_error_deg(R_a: torch.Tensor, R_b: torch.Tensor) -> torch.Tensor:
+    """acos((trace(R_a^T R_b) - 1) / 2) in degrees, clamped (metrics.py:289-291)."""
+    tr = torch.einsum("...ij,...ij->...", R_a, R_b)
+    return torch.rad2deg(torch.acos(((tr - 1) / 2).clamp(-1, 1)))

@@ -1,0 +1,227 @@
+"""TEST INFRASTRUCTURE ONLY -- import the *unmodified* reference modules on CPU.
+
+Only usable inside the build container where ``/root/reference`` is mounted
+(the GPU box has no such path; nothing in ``-m gpu`` tests, ``smoke()`` or
+``bench.py`` calls this).  It is used by ``oracle/make_golden.py`` to produce
+the fixtures under ``tests/golden/`` and by ``tests/test_oracle_vs_reference.py``
+to pin ``oracle/rap_oracle.py`` (the restatement that travels) against the
+reference's own source.
+
+Recipe: the reference package cannot be imported
+naively (``rectified_point_flow/__init__.py`` pulls lightning / hydra /
+pytorch3d).  We pre-register *bare* package objects for
+``rectified_point_flow`` and ``rectified_point_flow.utils`` whose ``__path__``
+points into the mount, so that the sub-modules we need
+(``sampler``, ``procrustes``, ``flow_model.*``, ``utils.point_clouds``) are
+executed from the reference's own files without running either ``__init__``.
+
+Two third-party wheels that are on the path but absent here are stubbed by
+restating their published semantics (pins from reference
+``scripts/install.sh:9,19``):
+
+* ``flash_attn`` 2.7.4.post1 -- ``flash_attn_varlen_qkvpacked_func``:
+  per-segment, non-causal softmax(q k^T / sqrt(D)) v.
+* ``diffusers`` 0.33.0 -- ``FeedForward(activation_fn="geglu")``,
+  ``Timesteps``, ``TimestepEmbedding``.
+
+Those two stubs are "parity unpinned": the reference ships no test that pins
+them; they follow the libraries' documented behaviour.
+"""
+from __future__ import annotations
+
+import importlib
+import math
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REFERENCE_ROOT = os.environ.get("RAP_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "rectified_point_flow", "flow_model"))
+
+
+# ----------------------------------------------------------------------------
+# stubs
+# ----------------------------------------------------------------------------
+def _flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
+                                      softmax_scale=None, causal=False,
+                                      window_size=(-1, -1), softcap=0.0,
+                                      alibi_slopes=None, deterministic=False,
+                                      return_attn_probs=False):
+    """qkv (T,3,H,D); cu_seqlens (S+1,) int32 -> (T,H,D).  Dense softmax attention
+    inside every segment, none across segments."""
+    assert dropout_p == 0.0 and not causal and softcap == 0.0
+    T, three, H, D = qkv.shape
+    assert three == 3
+    scale = softmax_scale if softmax_scale is not None else D ** -0.5
+    out = torch.empty((T, H, D), dtype=qkv.dtype, device=qkv.device)
+    cu = cu_seqlens.tolist()
+    for s in range(len(cu) - 1):
+        a, b = cu[s], cu[s + 1]
+        if b == a:
+            continue
+        q = qkv[a:b, 0].transpose(0, 1)  # (H,L,D)
+        k = qkv[a:b, 1].transpose(0, 1)
+        v = qkv[a:b, 2].transpose(0, 1)
+        att = torch.softmax((q @ k.transpose(1, 2)) * scale, dim=-1)
+        out[a:b] = (att @ v).transpose(0, 1)
+    return out
+
+
+class _GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out, bias=True):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2, bias=bias)
+
+    def forward(self, x):
+        h = self.proj(x)
+        h, gate = h.chunk(2, dim=-1)
+        return h * F.gelu(gate)  # exact erf GELU
+
+
+class _FeedForward(nn.Module):
+    """diffusers.models.attention.FeedForward (mult=4), keys net.0.proj.*, net.2.*"""
+
+    def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="geglu",
+                 final_dropout=False, inner_dim=None, bias=True):
+        super().__init__()
+        assert activation_fn == "geglu"
+        inner_dim = int(dim * mult) if inner_dim is None else inner_dim
+        dim_out = dim if dim_out is None else dim_out
+        self.net = nn.ModuleList([_GEGLU(dim, inner_dim, bias=bias), nn.Dropout(dropout),
+                                  nn.Linear(inner_dim, dim_out, bias=bias)])
+
+    def forward(self, x, *a, **k):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+class _Timesteps(nn.Module):
+    def __init__(self, num_channels, flip_sin_to_cos, downscale_freq_shift, scale=1):
+        super().__init__()
+        self.num_channels = num_channels
+        self.flip_sin_to_cos = flip_sin_to_cos
+        self.downscale_freq_shift = downscale_freq_shift
+        self.scale = scale
+
+    def forward(self, timesteps):
+        half = self.num_channels // 2
+        exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=timesteps.device)
+        exponent = exponent / (half - self.downscale_freq_shift)
+        emb = torch.exp(exponent)
+        emb = timesteps[:, None].float() * emb[None, :]
+        emb = self.scale * emb
+        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+        if self.flip_sin_to_cos:
+            emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+        return emb
+
+
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, sample, condition=None):
+        # diffusers keeps the sinusoid in fp32 and lets the Linear's dtype decide;
+        # cast so that an fp64 oracle run stays fp64 end to end.
+        sample = sample.to(self.linear_1.weight.dtype)
+        return self.linear_2(self.act(self.linear_1(sample)))
+
+
+def _install_stubs():
+    if "flash_attn" not in sys.modules:
+        m = types.ModuleType("flash_attn")
+        m.flash_attn_varlen_qkvpacked_func = _flash_attn_varlen_qkvpacked_func
+        sys.modules["flash_attn"] = m
+    if "diffusers" not in sys.modules:
+        d = types.ModuleType("diffusers"); d.__path__ = []
+        dm = types.ModuleType("diffusers.models"); dm.__path__ = []
+        da = types.ModuleType("diffusers.models.attention"); da.FeedForward = _FeedForward
+        de = types.ModuleType("diffusers.models.embeddings")
+        de.Timesteps = _Timesteps; de.TimestepEmbedding = _TimestepEmbedding
+        sys.modules.update({"diffusers": d, "diffusers.models": dm,
+                            "diffusers.models.attention": da, "diffusers.models.embeddings": de})
+
+
+_LOADED = None
+
+
+def load_reference():
+    """Returns a namespace with the reference's own (unmodified) objects."""
+    global _LOADED
+    if _LOADED is not None:
+        return _LOADED
+    if not reference_available():
+        raise RuntimeError(f"reference not mounted at {REFERENCE_ROOT}")
+    _install_stubs()
+    pkg_dir = os.path.join(REFERENCE_ROOT, "rectified_point_flow")
+    pkg = types.ModuleType("rectified_point_flow"); pkg.__path__ = [pkg_dir]
+    utils = types.ModuleType("rectified_point_flow.utils"); utils.__path__ = [os.path.join(pkg_dir, "utils")]
+    sys.modules.setdefault("rectified_point_flow", pkg)
+    sys.modules.setdefault("rectified_point_flow.utils", utils)
+    ns = types.SimpleNamespace()
+    ns.point_clouds = importlib.import_module("rectified_point_flow.utils.point_clouds")
+    ns.procrustes = importlib.import_module("rectified_point_flow.procrustes")
+    ns.sampler = importlib.import_module("rectified_point_flow.sampler")
+    ns.flow_model = importlib.import_module("rectified_point_flow.flow_model")
+    ns.PointCloudDiT = ns.flow_model.PointCloudDiT
+    ns.get_sampler = ns.sampler.get_sampler
+    ns.fit_transformations = ns.procrustes.fit_transformations
+    ns.rigidify_prediction_with_procrustes = ns.procrustes.rigidify_prediction_with_procrustes
+    _LOADED = ns
+    return ns
+
+
+def build_reference_dit(cfg, state_dict, dtype=torch.float32):
+    """Instantiate the reference's PointCloudDiT and load ``state_dict`` into it."""
+    ns = load_reference()
+    m = ns.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
+                         num_heads=cfg["num_heads"], attn_dtype="float32",
+                         local_feat_dim=cfg["local_feat_dim"], scale_emb_on=True, local_feat_concat_on=True)
+    # fp32 only: the reference forces its head to fp32 (point_cloud_dit.py:183-184 `embed.float()`), so an
+    # fp64 ground truth cannot be produced by the unmodified modules; oracle/rap_oracle.py (pinned to this
+    # loader in fp32) provides the fp64 ground truth instead.
+    assert dtype == torch.float32
+    missing, unexpected = m.load_state_dict({k: v.to(dtype) for k, v in state_dict.items()}, strict=True)
+    return m.eval()
+
+
+def reference_sample(cfg, state_dict, inputs, num_steps, rigidity_forcing, dtype=torch.float32):
+    """Restates only the 30-line closure of modeling.py:659-722 around the reference's own
+    get_sampler / PointCloudDiT / procrustes (modeling.py itself needs lightning)."""
+    ns = load_reference()
+    model = build_reference_dit(cfg, state_dict, dtype)
+    cond = inputs["pointclouds"].to(dtype)
+    feats = inputs["features"].to(dtype)
+    scales = inputs["scales"].to(dtype)
+    anchor = inputs["anchor_indices"]
+    ppp = inputs["points_per_part"]
+    x_1 = inputs["x_1"].to(dtype)
+    valid = ppp > 0
+    cu_part = F.pad(torch.cumsum(ppp[valid], 0), (1, 0)).to(torch.int32)   # modeling.py:219-222
+    cu_batch = inputs["cu_seqlens"].to(torch.int32)                          # modeling.py:223
+    B = cu_batch.shape[0] - 1
+
+    @torch.inference_mode()
+    def run():
+        def fn(x, t):                                                        # modeling.py:672-708
+            ts = torch.full((B,), t, dtype=dtype)
+            return model(x=x, timesteps=ts, cond_coord=cond, local_features=feats, latent_features=None,
+                         scales=scales, anchor_indices=anchor, cu_seqlens_batch=cu_batch, cu_seqlens_part=cu_part)
+        res = ns.get_sampler("euler")(flow_model_fn=fn, x_1=x_1, x_0=cond, condition=cond, points_per_part=ppp,
+                                      cu_seqlens_batch=cu_batch, anchor_indices=anchor, num_steps=num_steps,
+                                      return_trajectory=True, rigidity_forcing=rigidity_forcing)
+        R, t = ns.fit_transformations(cond, res["end_point_trajectory"][-1], ppp, cu_batch)  # modeling.py:389-391
+        return res, R, t
+    res, R, t = run()
+    return {"end_point_trajectory": res["end_point_trajectory"], "trajectory": res["trajectory"], "R": R, "t": t}
