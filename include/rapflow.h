@@ -1,0 +1,131 @@
+/* librapflow -- C ABI of the MI355X-native rectified-flow registration sampler.
+ *
+ * Drop-in boundary for ONE hot path of PRBonn/RAP: rectified_point_flow/{sampler.py, flow_model/,
+ * procrustes.py} behind RectifiedPointFlow.sample_rectified_flow (reference modeling.py:632-741).
+ * The reference has no native code; its "FFI" for this path is the set of Python call sites listed
+ * next to each entry point below.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer (HIP, gfx950) unless named h_*;
+ *   - fp32 tensors are dense row-major; packed varlen layout (TP,C) with segment tables, exactly the
+ *     reference's collate schema (data/datamodule.py:169-198);
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, the call never synchronises and never
+ *     allocates (except rap_model_create / rap_model_destroy);
+ *   - returns 0 (RAP_OK) or a negative code: -1 invalid argument, -2 workspace too small,
+ *     -3 HIP runtime error (see rap_last_hip_error), -4 allocation failure;
+ *   - the caller owns every buffer, including the workspace (size from rap_workspace_bytes).
+ */
+#ifndef RAPFLOW_H
+#define RAPFLOW_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rap_model rap_model;
+
+/* PointCloudDiT hyper-parameters (reference config/model/flow_model/point_cloud_dit_12.yaml,
+ * flow_model/point_cloud_dit.py:20-36).  head_dim is fixed at 64 (embed_dim == 64 * num_heads),
+ * embed_dim a multiple of 256, local_feat_dim a multiple of 4 and <= 40, in_dim == 0,
+ * scale_emb_on == local_feat_concat_on == true, qk_norm == true (config/RAP_inference.yaml:65). */
+typedef struct rap_model_desc {
+  int32_t embed_dim;      /* 512 */
+  int32_t num_layers;     /* 10 / 12 / 16 */
+  int32_t num_heads;      /* 8 */
+  int32_t local_feat_dim; /* 32 */
+} rap_model_desc;
+
+int rap_version(void);
+int rap_last_hip_error(void);
+
+/* Number of fp32 values in the raw weight blob: the tensors of PointCloudDiT.state_dict() concatenated
+ * in the reference's registration order (flow_model/point_cloud_dit.py:83-117, layer.py:71-89,
+ * norm.py:47-58; table in DESIGN.md "Weight contract").  Returns < 0 for an unsupported desc. */
+int64_t rap_weight_count(const rap_model_desc* desc);
+
+/* Replaces  PointCloudDiT(...).load_state_dict(ckpt)  (reference sample.py:58, utils/checkpoint.py:13-61).
+ * Copies the blob into model-owned device memory and builds the kernel-side packings (split embedding
+ * projection, stacked adaLN weights, value/gate-interleaved GEGLU projection).  Allocates. */
+int rap_model_create(const rap_model_desc* desc, const float* d_weights, int64_t n_floats, void* stream,
+                     rap_model** out);
+void rap_model_destroy(rap_model* m);
+
+/* Bytes of caller-provided workspace for one call on a batch of TP points, B samples, `nseg_part`
+ * part segments (B*P for rap_sample, VP for rap_dit_forward) and `rows` adaLN rows
+ * (num_steps for rap_sample, B for rap_dit_forward). */
+size_t rap_workspace_bytes(const rap_model* m, int64_t TP, int32_t B, int32_t nseg_part, int32_t rows);
+
+/* Replaces PointCloudDiT.forward (reference flow_model/point_cloud_dit.py:141-191), called from
+ * modeling.py:684-706.  x_t (TP,3), timesteps (B,) raw t in (0,1], cond (TP,3), feat (TP,F), scales (B,),
+ * anchor (TP,) uint8/bool, cu_batch (B+1,) int32, cu_part (VP+1,) int32 (zero-length segments allowed).
+ * v_out (TP,3); feats_out (TP,embed_dim) or NULL ('transformer_features', :186-190). */
+int rap_dit_forward(const rap_model* m, const float* x_t, const float* timesteps, const float* cond, const float* feat,
+                    const float* scales, const uint8_t* anchor, const int32_t* cu_batch, const int32_t* cu_part,
+                    int32_t B, int32_t VP, int64_t TP, float* v_out, float* feats_out, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* Replaces euler_step's tensor update (reference sampler.py:88-90): x0_hat = x_t - v*t ; x_next = x_t - dt*v.
+ * n = number of floats (3*TP).  x_next may alias x_t.  traj_xt_slot may be NULL. */
+int rap_euler_step(const float* x_t, const float* v, float t, float dt, float* x0_hat, float* x_next,
+                   float* traj_xt_slot, int64_t n, void* stream);
+
+/* Replaces fit_transformations (reference procrustes.py:40-84).  points_per_part (B,P) int64 as in the
+ * reference; src/tgt (TP,3) packed in (b,p) order.  R_out (B,P,3,3), t_out (B,P,3); empty parts -> zero rows.
+ * Convention: tgt ~= src @ R^T + t.  ws >= rap_procrustes_workspace_bytes(B*P). */
+size_t rap_procrustes_workspace_bytes(int32_t nparts);
+int rap_fit_transformations(const float* src, const float* tgt, const int64_t* points_per_part, int32_t B, int32_t P,
+                            float* R_out, float* t_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Replaces rigidify_prediction_with_procrustes (reference procrustes.py:86-118): out = cond_p R_p^T + t_p. */
+int rap_rigidify(const float* prediction, const float* condition, const int64_t* points_per_part, int32_t B, int32_t P,
+                 float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* The sampler's rigidity-forcing update (reference sampler.py:59-60):
+ *   x_t = rigidify(x0_hat, cond) * w0 + x_1 * w1   with w0 = 1 - t + dt, w1 = t - dt (computed in double by the caller). */
+int rap_rigidify_blend(const float* x0_hat, const float* condition, const int64_t* points_per_part, int32_t B, int32_t P,
+                       const float* x_1, float w0, float w1, float* x_t_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Replaces the whole of sample_rectified_flow + the final fit_transformations
+ * (reference modeling.py:632-741 -> sampler.py:11-74 [euler] -> modeling.py:389-391):
+ *   dt = 1/num_steps; x_t = x_1; for s: t = 1 - s*dt; v = DiT(x_t, t); x0 = x_t - v t; x_t -= dt v;
+ *   if rigidity: x_t = rigid(x0, cond) (1-t+dt) + x_1 (t-dt);  traj_x0[s] = x0 (raw);  traj_xt[s] = x_t;
+ *   R,t = fit_transformations(cond, traj_x0[S-1]).
+ * traj_x0, traj_xt (num_steps,TP,3); R_out (B,P,3,3); t_out (B,P,3); feats_out (TP,embed_dim) or NULL
+ * (transformer features of the last step, modeling.py:678-695). */
+int rap_sample(const rap_model* m, const float* cond, const float* feat, const float* scales, const uint8_t* anchor,
+               const int64_t* points_per_part, const int32_t* cu_batch, const float* x_1, int32_t B, int32_t P,
+               int64_t TP, int32_t num_steps, int32_t rigidity_forcing, float* traj_x0, float* traj_xt, float* R_out,
+               float* t_out, float* feats_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- kernel-level entry points (used by the parity tests; same kernels the calls above launch) ---- */
+/* C(M,N) = A(M,K) W(N,K)^T (+bias) (+resid) ; epilogue: 0 bias, 1 bias+resid, 2 bias+SiLU,
+ * 3 GEGLU (W/bias must be value/gate interleaved by rap_geglu_interleave; C is (M,N/2)),
+ * 4 head-major qkv scatter ([3][H][M][64]), 5 bias + anchor embedding select. */
+int rap_gemm_f32(int32_t epilogue, const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc,
+                 int32_t M, int32_t N, int32_t K, const float* bias, const float* resid, int32_t ldr,
+                 const uint8_t* anchor, const float* anchor_emb, int32_t heads, void* stream);
+int rap_geglu_interleave(const float* W, const float* b, float* Wp, float* bp, int32_t inner, int32_t K, void* stream);
+/* flash_attn_varlen_qkvpacked_func equivalent (reference layer.py:106-111,123-128) on head-major qkv
+ * [3][H][TP][64]; out (TP, H*64).  ws >= rap_attention_workspace_bytes(TP, nseg). */
+size_t rap_attention_workspace_bytes(int64_t TP, int32_t nseg);
+int rap_attention_f32(const float* qkv_headmajor, const int32_t* cu_seqlens, int32_t nseg, float* out, int64_t TP,
+                      int32_t heads, void* ws, size_t ws_bytes, void* stream);
+int rap_layernorm_mod(const float* x, float* out, int64_t TP, int32_t d, const float* mod, int64_t mod_stride,
+                      const int32_t* token_row, void* stream);
+int rap_layernorm_affine(const float* x, float* out, int64_t TP, int32_t d, const float* gain, const float* shift,
+                         void* stream);
+int rap_qknorm(float* qkv_headmajor, int64_t TP, int32_t heads, const float* gamma_q, const float* gamma_k, void* stream);
+int rap_posenc_x(const float* x, float* ax, int64_t TP, void* stream);
+int rap_posenc_static(const float* cond, const float* scales, const int32_t* token_sample, const float* feat,
+                      int32_t feat_dim, float* astatic, int64_t TP, void* stream);
+int rap_token_sample(const int32_t* cu_batch, int32_t B, int32_t* token_sample, void* stream);
+/* adaLN (scale|shift) table for model `m`: t (rows,), out (rows, 2*num_layers, 2*embed_dim);
+ * scratch >= rows*(256 + 4*num_layers*embed_dim) floats. */
+int rap_adaln_table(const rap_model* m, const float* t, int32_t rows, float* scratch, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAPFLOW_H */

@@ -1,0 +1,70 @@
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.npz by running the reference's OWN modules.
+
+Run inside the build container (needs /root/reference):   python -m oracle.make_golden
+The fixtures hold the inputs, the seeds/config that regenerate the weights (rap_amd.synthetic.make_weights)
+and the outputs of the unmodified reference code (sampler.py, flow_model/*, procrustes.py imported by
+oracle/ref_loader.py; fp32, CPU).  They travel to the GPU box, where /root/reference does not exist.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_loader                      # noqa: E402
+from oracle import rap_oracle as O                 # noqa: E402
+from rap_amd import synthetic as S                 # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = [
+    # name, num_layers, parts, input seed, weight seed, steps, rigidity
+    ("l2_ragged_rigid", 2, [[37, 64, 100], [50, 129]], 7, 0, 4, True),
+    ("l2_ragged_free", 2, [[37, 64, 100], [50, 129]], 7, 0, 4, False),
+    ("l2_emptypart_rigid", 2, [[70, 45, 0], [33, 90, 61]], 11, 1, 3, True),
+    ("l12_small_rigid", 12, [[64, 96], [128, 40, 33]], 21, 0, 3, True),
+    ("l12_pair512_free", 12, [[512, 512]], 31, 0, 2, False),
+]
+
+
+def weights_checksum(sd) -> float:
+    return float(sum(v.double().sum().item() for v in sd.values()))
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, L, parts, iseed, wseed, steps, rigid in CASES:
+        cfg = dict(S.RAP_12); cfg["num_layers"] = L
+        sd = S.make_weights(cfg, wseed)
+        inp = S.make_inputs(parts, seed=iseed)
+        ref = ref_loader.reference_sample(cfg, sd, inp, steps, rigid)
+        # one stand-alone forward of the reference PointCloudDiT with a different t per sample
+        model = ref_loader.build_reference_dit(cfg, sd)
+        cu_b, cu_p = O.prepare_cu_seqlens(inp)
+        B = len(parts)
+        ts = torch.linspace(0.15, 0.9, B)
+        with torch.inference_mode():
+            fw = model(x=inp["x_1"], timesteps=ts, cond_coord=inp["pointclouds"], local_features=inp["features"],
+                       latent_features=None, scales=inp["scales"], anchor_indices=inp["anchor_indices"],
+                       cu_seqlens_batch=cu_b, cu_seqlens_part=cu_p, return_transformer_features=True)
+        out = {
+            "num_layers": np.int64(L), "weight_seed": np.int64(wseed), "num_steps": np.int64(steps),
+            "rigidity": np.int64(int(rigid)), "weights_checksum": np.float64(weights_checksum(sd)),
+            "fwd_timesteps": ts.numpy(), "fwd_velocity": fw["velocity"].numpy(),
+            "fwd_features": fw["transformer_features"].numpy(),
+            "end_point_trajectory": ref["end_point_trajectory"].numpy(), "trajectory": ref["trajectory"].numpy(),
+            "R": ref["R"].numpy(), "t": ref["t"].numpy(),
+        }
+        for k, v in inp.items():
+            out["in_" + k] = v.numpy()
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,13 @@
+"""rap_amd -- MI355X-native (gfx950) rectified-flow registration sampler.
+
+One hot path of PRBonn/RAP, rebuilt as hand-written HIP kernels behind the reference's own Python API:
+``rectified_point_flow/{sampler.py, flow_model/, procrustes.py}`` behind
+``RectifiedPointFlow.sample_rectified_flow``.  See DESIGN.md / INTEGRATION.md.
+"""
+from .flow_model import PointCloudDiT
+from .modeling import RectifiedPointFlow
+from .procrustes import fit_transformations, rigidify_prediction_with_procrustes, solve_procrustes
+from .sampler import euler_step, flow_sampler, get_sampler
+
+__all__ = ["PointCloudDiT", "RectifiedPointFlow", "fit_transformations", "rigidify_prediction_with_procrustes",
+           "solve_procrustes", "euler_step", "flow_sampler", "get_sampler"]

@@ -1,0 +1,499 @@
+// C ABI of librapflow (see include/rapflow.h): model packing, workspace carving and the launch
+// sequences of one velocity-network forward and of the whole Euler sampling loop.  Host code only;
+// every kernel lives in the sibling .hip files.
+#include "../../include/rapflow.h"
+#include "kernels.h"
+
+#include <new>
+#include <vector>
+
+static thread_local int g_last_hip_error = 0;
+void rap_set_last_hip_error(int e) { g_last_hip_error = e; }
+
+// ---------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------
+struct LayerW {
+  const float* Wqkv[2];   // (3d,d)  [0]=self (per part), [1]=global (per sample)
+  const float* Wout[2];   // (d,d)
+  const float* bout[2];   // (d)
+  const float* gq[2];     // (H,64)
+  const float* gk[2];
+  const float* ffn_g;     // (d)
+  const float* ffn_b;
+  const float* Wff1p;     // (8d,d) value/gate interleaved
+  const float* bff1p;     // (8d)
+  const float* Wff2;      // (d,4d)
+  const float* bff2;      // (d)
+};
+
+struct rap_model {
+  rap_model_desc desc;
+  int d, L, H, F, E;
+  float* raw = nullptr;       // copy of the caller's blob
+  float* derived = nullptr;   // packed arrays
+  const float* anchor_emb;    // (2,d)
+  const float* emb_bias;      // (d)
+  const float* Wstatic;       // (d,128): [cond PE63 | scale PE21 | feat F | 0]
+  const float* Wx;            // (d,64):  [x_t PE63 | 0]
+  const float *adaW1, *adab1, *adaW2, *adab2, *adaW3, *adab3;  // stacked over j = 2*layer + {0 self, 1 global}
+  std::vector<LayerW> layers;
+  const float *hW0, *hb0, *hW2, *hb2, *hW4;
+};
+
+static bool desc_ok(const rap_model_desc* d) {
+  if (!d) return false;
+  if (d->embed_dim <= 0 || d->embed_dim % 256 != 0 || d->embed_dim > 1024) return false;
+  if (d->num_heads * 64 != d->embed_dim) return false;
+  if (d->num_layers <= 0 || d->num_layers > 64) return false;
+  if (d->local_feat_dim < 0 || d->local_feat_dim % 4 != 0 || d->local_feat_dim > 40) return false;
+  return true;
+}
+
+extern "C" int rap_version(void) { return 1; }
+extern "C" int rap_last_hip_error(void) { return g_last_hip_error; }
+
+extern "C" int64_t rap_weight_count(const rap_model_desc* desc) {
+  if (!desc_ok(desc)) return -1;
+  const int64_t d = desc->embed_dim, L = desc->num_layers, H = desc->num_heads, E = 147 + desc->local_feat_dim;
+  int64_t n = 2 * d + d * E + d;
+  const int64_t attn = (d * 256 + d) + (d * d + d) + (2 * d * d + 2 * d) + 3 * d * d + (d * d + d) + 2 * H * 64;
+  const int64_t layer = 2 * attn + 2 * d + (8 * d * d + 8 * d) + (4 * d * d + d);
+  n += L * layer;
+  n += (d * d + d) + (d / 2 * d + d / 2) + 3 * (d / 2);
+  return n;
+}
+
+extern "C" int rap_model_create(const rap_model_desc* desc, const float* d_weights, int64_t n_floats, void* stream_,
+                                rap_model** out) {
+  if (!out) return RAP_ERR_INVALID;
+  *out = nullptr;
+  if (!desc_ok(desc) || !d_weights) return RAP_ERR_INVALID;
+  if (n_floats != rap_weight_count(desc)) return RAP_ERR_INVALID;
+  hipStream_t stream = (hipStream_t)stream_;
+  rap_model* m = new (std::nothrow) rap_model();
+  if (!m) return RAP_ERR_ALLOC;
+  m->desc = *desc;
+  const int d = m->d = desc->embed_dim, L = m->L = desc->num_layers, H = m->H = desc->num_heads;
+  m->F = desc->local_feat_dim;
+  const int E = m->E = 147 + m->F;
+  if (hipMalloc((void**)&m->raw, (size_t)n_floats * sizeof(float)) != hipSuccess) { delete m; return RAP_ERR_ALLOC; }
+  const size_t n_ada = (size_t)2 * L * ((size_t)d * 256 + d + (size_t)d * d + d + (size_t)2 * d * d + 2 * d);
+  const size_t n_ff1 = (size_t)L * ((size_t)8 * d * d + 8 * d);
+  const size_t n_derived = (size_t)d * 128 + (size_t)d * 64 + n_ada + n_ff1;
+  if (hipMalloc((void**)&m->derived, n_derived * sizeof(float)) != hipSuccess) {
+    (void)hipFree(m->raw); delete m; return RAP_ERR_ALLOC;
+  }
+  int rc = RAP_OK;
+  auto fail = [&](int code) { rap_model_destroy(m); return code; };
+  if (hipMemcpyAsync(m->raw, d_weights, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+    return fail(RAP_ERR_HIP);
+
+  // ---- walk the raw blob in state_dict order
+  const float* p = m->raw;
+  auto take = [&](size_t n) { const float* r = p; p += n; return r; };
+  m->anchor_emb = take((size_t)2 * d);
+  const float* embW = take((size_t)d * E);
+  m->emb_bias = take(d);
+
+  float* q = m->derived;
+  auto carve = [&](size_t n) { float* r = q; q += n; return r; };
+  float* Wstatic = carve((size_t)d * 128);
+  float* Wx = carve((size_t)d * 64);
+  float* aW1 = carve((size_t)2 * L * d * 256); float* ab1 = carve((size_t)2 * L * d);
+  float* aW2 = carve((size_t)2 * L * d * d);   float* ab2 = carve((size_t)2 * L * d);
+  float* aW3 = carve((size_t)2 * L * 2 * d * d); float* ab3 = carve((size_t)2 * L * 2 * d);
+  m->Wstatic = Wstatic; m->Wx = Wx;
+  m->adaW1 = aW1; m->adab1 = ab1; m->adaW2 = aW2; m->adab2 = ab2; m->adaW3 = aW3; m->adab3 = ab3;
+
+  // embedding projection columns (embedding.py:161-177): [0,63) cond | [63,126) x_t | [126,147) scale | [147,E) feat
+  if ((rc = launch_fill_zero(stream, Wstatic, (size_t)d * 128))) return fail(rc);
+  if ((rc = launch_fill_zero(stream, Wx, (size_t)d * 64))) return fail(rc);
+  if ((rc = launch_copy_cols(stream, embW, E, 0, Wstatic, 128, 0, d, 63))) return fail(rc);
+  if ((rc = launch_copy_cols(stream, embW, E, 126, Wstatic, 128, 63, d, 21))) return fail(rc);
+  if ((rc = launch_copy_cols(stream, embW, E, 147, Wstatic, 128, 84, d, m->F))) return fail(rc);
+  if ((rc = launch_copy_cols(stream, embW, E, 63, Wx, 64, 0, d, 63))) return fail(rc);
+
+  m->layers.resize(L);
+  for (int i = 0; i < L; ++i) {
+    LayerW& lw = m->layers[i];
+    for (int a = 0; a < 2; ++a) {
+      const int j = 2 * i + a;
+      const float* W1 = take((size_t)d * 256); const float* b1 = take(d);
+      const float* W2 = take((size_t)d * d);   const float* b2 = take(d);
+      const float* W3 = take((size_t)2 * d * d); const float* b3 = take((size_t)2 * d);
+      if ((rc = launch_copy_cols(stream, W1, 256, 0, aW1 + (size_t)j * d * 256, 256, 0, d, 256))) return fail(rc);
+      if ((rc = launch_copy_cols(stream, b1, d, 0, ab1 + (size_t)j * d, d, 0, 1, d))) return fail(rc);
+      if ((rc = launch_copy_cols(stream, W2, d, 0, aW2 + (size_t)j * d * d, d, 0, d, d))) return fail(rc);
+      if ((rc = launch_copy_cols(stream, b2, d, 0, ab2 + (size_t)j * d, d, 0, 1, d))) return fail(rc);
+      if ((rc = launch_copy_cols(stream, W3, d, 0, aW3 + (size_t)j * 2 * d * d, d, 0, 2 * d, d))) return fail(rc);
+      if ((rc = launch_copy_cols(stream, b3, 2 * d, 0, ab3 + (size_t)j * 2 * d, 2 * d, 0, 1, 2 * d))) return fail(rc);
+      lw.Wqkv[a] = take((size_t)3 * d * d);
+      lw.Wout[a] = take((size_t)d * d);
+      lw.bout[a] = take(d);
+      lw.gq[a] = take((size_t)H * 64);
+      lw.gk[a] = take((size_t)H * 64);
+    }
+    lw.ffn_g = take(d);
+    lw.ffn_b = take(d);
+    const float* Wff1 = take((size_t)8 * d * d);
+    const float* bff1 = take((size_t)8 * d);
+    float* Wp = carve((size_t)8 * d * d);
+    float* bp = carve((size_t)8 * d);
+    if ((rc = launch_geglu_interleave(stream, Wff1, bff1, Wp, bp, 4 * d, d))) return fail(rc);
+    lw.Wff1p = Wp; lw.bff1p = bp;
+    lw.Wff2 = take((size_t)d * 4 * d);
+    lw.bff2 = take(d);
+  }
+  m->hW0 = take((size_t)d * d); m->hb0 = take(d);
+  m->hW2 = take((size_t)(d / 2) * d); m->hb2 = take(d / 2);
+  m->hW4 = take((size_t)3 * (d / 2));
+  if ((int64_t)(p - m->raw) != n_floats || (size_t)(q - m->derived) != n_derived) return fail(RAP_ERR_INVALID);
+  *out = m;
+  return RAP_OK;
+}
+
+extern "C" void rap_model_destroy(rap_model* m) {
+  if (!m) return;
+  if (m->raw) (void)hipFree(m->raw);
+  if (m->derived) (void)hipFree(m->derived);
+  delete m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------
+struct Workspace {
+  float *base, *h, *xn, *qkv, *att, *ffmid, *ax, *v, *mod, *ada_scratch, *xt, *Rc, *tc, *tgrid;
+  double* proc_partials;
+  int32_t *token_sample, *part_offsets;
+  AttnWorkItem *items_batch, *items_part;
+  int max_items_batch, max_items_part;
+  size_t total;
+};
+
+static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg_part, int rows, char* basep) {
+  Workspace w;
+  const size_t d = m->d, L = m->L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* r = basep ? basep + off : nullptr; off += align_up(bytes, 256); return r; };
+  const size_t T = (size_t)TP;
+  w.base = (float*)take(T * d * 4);
+  w.h = (float*)take(T * d * 4);
+  w.xn = (float*)take(T * d * 4);            // also head hidden 1 (TP,d)
+  w.qkv = (float*)take(T * 3 * d * 4);
+  w.att = (float*)take(T * d * 4);           // also head hidden 2 (TP,d/2)
+  w.ffmid = (float*)take(T * 4 * d * 4);     // also the static feature matrix (TP,128) during prepare
+  w.ax = (float*)take(T * 64 * 4);
+  w.v = (float*)take(T * 3 * 4);
+  w.xt = (float*)take(T * 3 * 4);
+  w.mod = (float*)take((size_t)rows * 2 * L * 2 * d * 4);
+  w.ada_scratch = (float*)take((size_t)rows * (256 + 4 * L * d) * 4);
+  w.tgrid = (float*)take((size_t)rows * 4);
+  w.token_sample = (int32_t*)take(T * 4);
+  w.part_offsets = (int32_t*)take(((size_t)nseg_part + 1) * 4);
+  w.max_items_batch = (int)(TP / RAP_ATTN_BQ) + B + 1;
+  w.max_items_part = (int)(TP / RAP_ATTN_BQ) + nseg_part + 1;
+  w.items_batch = (AttnWorkItem*)take((size_t)w.max_items_batch * sizeof(AttnWorkItem));
+  w.items_part = (AttnWorkItem*)take((size_t)w.max_items_part * sizeof(AttnWorkItem));
+  w.proc_partials = (double*)take((size_t)nseg_part * RAP_PROC_CHUNKS * 16 * 8);
+  w.Rc = (float*)take((size_t)nseg_part * 9 * 4);
+  w.tc = (float*)take((size_t)nseg_part * 3 * 4);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t rap_workspace_bytes(const rap_model* m, int64_t TP, int32_t B, int32_t nseg_part, int32_t rows) {
+  if (!m || TP < 0 || B < 0 || nseg_part < 0 || rows < 0) return 0;
+  return carve_workspace(m, TP, B, nseg_part, rows, nullptr).total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// prepare (step-invariant work) and one forward
+// ---------------------------------------------------------------------------------------------
+static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t stream, const float* cond, const float* feat,
+                          const float* scales, const uint8_t* anchor, const int32_t* cu_batch, const int32_t* cu_part,
+                          int B, int nseg_part, int TP) {
+  int rc;
+  if ((rc = launch_token_sample(stream, cu_batch, B, w.token_sample))) return rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch))) return rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part))) return rc;
+  // base = [PE63(cond) | PE21(scale) | feat | 0] Wstatic^T + emb bias + anchor embedding   (embedding.py:155-179,
+  // point_cloud_dit.py:119-139) -- everything in the embedding that does not depend on x_t.
+  float* astatic = w.ffmid;
+  if ((rc = launch_posenc_static(stream, cond, scales, w.token_sample, feat, m->F, astatic, TP))) return rc;
+  GemmParams g{};
+  g.A = astatic; g.lda = 128; g.W = m->Wstatic; g.ldw = 128; g.C = w.base; g.ldc = m->d;
+  g.M = TP; g.N = m->d; g.K = 128; g.bias = m->emb_bias; g.anchor = anchor; g.anchor_emb = m->anchor_emb;
+  return launch_gemm_f32(stream, EPI_BIAS_ANCHOR, g);
+}
+
+// mod: (scale|shift) rows for this forward: row r at mod + r*mod_stride, LN j at + j*2d.
+static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stream, const float* x_t, const float* mod,
+                        long mod_stride, const int32_t* token_row, int TP, float* v_out, float* feats_out) {
+  const int d = m->d, H = m->H;
+  int rc;
+  // embed = PE63(x_t) Wx^T + base
+  if ((rc = launch_posenc_x(stream, x_t, w.ax, TP))) return rc;
+  {
+    GemmParams g{};
+    g.A = w.ax; g.lda = 64; g.W = m->Wx; g.ldw = 64; g.C = w.h; g.ldc = d; g.M = TP; g.N = d; g.K = 64;
+    g.resid = w.base; g.ldr = d;
+    if ((rc = launch_gemm_f32(stream, EPI_BIAS_RESID, g))) return rc;
+  }
+  for (int i = 0; i < m->L; ++i) {
+    const LayerW& lw = m->layers[i];
+    for (int a = 0; a < 2; ++a) {   // a = 0: per-part attention, a = 1: per-sample attention (layer.py:152-160)
+      const int j = 2 * i + a;
+      if ((rc = launch_layernorm_mod(stream, w.h, w.xn, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
+      GemmParams g{};
+      g.A = w.xn; g.lda = d; g.W = lw.Wqkv[a]; g.ldw = d; g.C = w.qkv; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
+      if ((rc = launch_gemm_f32(stream, EPI_QKV_HEADMAJOR, g))) return rc;
+      if ((rc = launch_qknorm(stream, w.qkv, TP, H, lw.gq[a], lw.gk[a]))) return rc;
+      if (a == 0) rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_part, w.max_items_part);
+      else rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_batch, w.max_items_batch);
+      if (rc) return rc;
+      GemmParams o{};
+      o.A = w.att; o.lda = d; o.W = lw.Wout[a]; o.ldw = d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = d;
+      o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d;
+      if ((rc = launch_gemm_f32(stream, EPI_BIAS_RESID, o))) return rc;
+    }
+    if ((rc = launch_layernorm_affine(stream, w.h, w.xn, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
+    GemmParams f1{};
+    f1.A = w.xn; f1.lda = d; f1.W = lw.Wff1p; f1.ldw = d; f1.C = w.ffmid; f1.ldc = 4 * d; f1.M = TP; f1.N = 8 * d; f1.K = d;
+    f1.bias = lw.bff1p;
+    if ((rc = launch_gemm_f32(stream, EPI_GEGLU, f1))) return rc;
+    GemmParams f2{};
+    f2.A = w.ffmid; f2.lda = 4 * d; f2.W = lw.Wff2; f2.ldw = 4 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 4 * d;
+    f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d;
+    if ((rc = launch_gemm_f32(stream, EPI_BIAS_RESID, f2))) return rc;
+  }
+  if (feats_out) {
+    if (hipMemcpyAsync(feats_out, w.h, (size_t)TP * d * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+      rap_set_last_hip_error((int)hipGetLastError());
+      return RAP_ERR_HIP;
+    }
+  }
+  // final_mlp (point_cloud_dit.py:111-117): Lin+SiLU, Lin+SiLU, Lin(no bias)
+  GemmParams h0{};
+  h0.A = w.h; h0.lda = d; h0.W = m->hW0; h0.ldw = d; h0.C = w.xn; h0.ldc = d; h0.M = TP; h0.N = d; h0.K = d; h0.bias = m->hb0;
+  if ((rc = launch_gemm_f32(stream, EPI_BIAS_SILU, h0))) return rc;
+  GemmParams h2{};
+  h2.A = w.xn; h2.lda = d; h2.W = m->hW2; h2.ldw = d; h2.C = w.att; h2.ldc = d / 2; h2.M = TP; h2.N = d / 2; h2.K = d;
+  h2.bias = m->hb2;
+  if ((rc = launch_gemm_f32(stream, EPI_BIAS_SILU, h2))) return rc;
+  return launch_head_out3(stream, w.att, d / 2, m->hW4, v_out, TP, d / 2);
+}
+
+extern "C" int rap_dit_forward(const rap_model* m, const float* x_t, const float* timesteps, const float* cond,
+                               const float* feat, const float* scales, const uint8_t* anchor, const int32_t* cu_batch,
+                               const int32_t* cu_part, int32_t B, int32_t VP, int64_t TP, float* v_out, float* feats_out,
+                               void* ws, size_t ws_bytes, void* stream_) {
+  if (!m || !x_t || !timesteps || !cond || !scales || !anchor || !cu_batch || !cu_part || !v_out) return RAP_ERR_INVALID;
+  if (m->F > 0 && !feat) return RAP_ERR_INVALID;
+  if (B <= 0 || VP < 0 || TP < 0 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
+  if (TP == 0) return RAP_OK;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  Workspace w = carve_workspace(m, TP, B, VP, B, (char*)ws);
+  if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  if ((rc = prepare_static(m, w, stream, cond, feat, scales, anchor, cu_batch, cu_part, B, VP, (int)TP))) return rc;
+  if ((rc = launch_adaln_table(stream, timesteps, B, 2 * m->L, m->d, m->adaW1, m->adab1, m->adaW2, m->adab2, m->adaW3,
+                               m->adab3, w.ada_scratch, w.mod)))
+    return rc;
+  return forward_step(m, w, stream, x_t, w.mod, (long)2 * m->L * 2 * m->d, w.token_sample, (int)TP, v_out, feats_out);
+}
+
+extern "C" int rap_euler_step(const float* x_t, const float* v, float t, float dt, float* x0_hat, float* x_next,
+                              float* traj_xt_slot, int64_t n, void* stream) {
+  if (!x_t || !v || !x0_hat || !x_next || n < 0) return RAP_ERR_INVALID;
+  return launch_euler_step((hipStream_t)stream, x_t, v, t, dt, x0_hat, x_next, traj_xt_slot, (long)n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// procrustes entry points
+// ---------------------------------------------------------------------------------------------
+struct ProcWs { int32_t* off; double* partials; float* Rc; float* tc; size_t total; };
+static ProcWs carve_proc(int nparts, char* basep) {
+  ProcWs p; size_t off = 0;
+  auto take = [&](size_t bytes) { char* r = basep ? basep + off : nullptr; off += align_up(bytes, 256); return r; };
+  p.off = (int32_t*)take(((size_t)nparts + 1) * 4);
+  p.partials = (double*)take((size_t)nparts * RAP_PROC_CHUNKS * 16 * 8);
+  p.Rc = (float*)take((size_t)nparts * 9 * 4);
+  p.tc = (float*)take((size_t)nparts * 3 * 4);
+  p.total = off;
+  return p;
+}
+extern "C" size_t rap_procrustes_workspace_bytes(int32_t nparts) { return nparts < 0 ? 0 : carve_proc(nparts, nullptr).total; }
+
+extern "C" int rap_fit_transformations(const float* src, const float* tgt, const int64_t* points_per_part, int32_t B,
+                                       int32_t P, float* R_out, float* t_out, void* ws, size_t ws_bytes, void* stream_) {
+  if (!src || !tgt || !points_per_part || !R_out || !t_out || B <= 0 || P <= 0) return RAP_ERR_INVALID;
+  if ((int64_t)B * P > 65535) return RAP_ERR_INVALID;
+  const int np = B * P;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  ProcWs p = carve_proc(np, (char*)ws);
+  if (p.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  if ((rc = launch_part_offsets(stream, points_per_part, np, p.off))) return rc;
+  return launch_procrustes_fit(stream, src, tgt, p.off, np, R_out, t_out, p.partials);
+}
+
+extern "C" int rap_rigidify(const float* prediction, const float* condition, const int64_t* points_per_part, int32_t B,
+                            int32_t P, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  if (!prediction || !condition || !points_per_part || !out || B <= 0 || P <= 0) return RAP_ERR_INVALID;
+  if ((int64_t)B * P > 65535) return RAP_ERR_INVALID;
+  const int np = B * P;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  ProcWs p = carve_proc(np, (char*)ws);
+  if (p.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  if ((rc = launch_part_offsets(stream, points_per_part, np, p.off))) return rc;
+  if ((rc = launch_procrustes_fit(stream, condition, prediction, p.off, np, p.Rc, p.tc, p.partials))) return rc;
+  return launch_rigid_apply(stream, condition, p.Rc, p.tc, p.off, np, out, nullptr, 0.f, 0.f, nullptr, 0);
+}
+
+extern "C" int rap_rigidify_blend(const float* x0_hat, const float* condition, const int64_t* points_per_part, int32_t B,
+                                  int32_t P, const float* x_1, float w0, float w1, float* x_t_out, void* ws, size_t ws_bytes,
+                                  void* stream_) {
+  if (!x0_hat || !condition || !points_per_part || !x_1 || !x_t_out || B <= 0 || P <= 0) return RAP_ERR_INVALID;
+  if ((int64_t)B * P > 65535) return RAP_ERR_INVALID;
+  const int np = B * P;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  ProcWs p = carve_proc(np, (char*)ws);
+  if (p.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  if ((rc = launch_part_offsets(stream, points_per_part, np, p.off))) return rc;
+  if ((rc = launch_procrustes_fit(stream, condition, x0_hat, p.off, np, p.Rc, p.tc, p.partials))) return rc;
+  return launch_rigid_apply(stream, condition, p.Rc, p.tc, p.off, np, x_t_out, x_1, w0, w1, nullptr, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the whole sampling loop
+// ---------------------------------------------------------------------------------------------
+__global__ void tgrid_kernel(float* t, int steps, double dt) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s < steps) t[s] = (float)(1.0 - (double)s * dt);   // t = 1 - step*dt in double (sampler.py:42,55), cast at torch.full
+}
+
+extern "C" int rap_sample(const rap_model* m, const float* cond, const float* feat, const float* scales,
+                          const uint8_t* anchor, const int64_t* points_per_part, const int32_t* cu_batch, const float* x_1,
+                          int32_t B, int32_t P, int64_t TP, int32_t num_steps, int32_t rigidity_forcing, float* traj_x0,
+                          float* traj_xt, float* R_out, float* t_out, float* feats_out, void* ws, size_t ws_bytes,
+                          void* stream_) {
+  if (!m || !cond || !scales || !anchor || !points_per_part || !cu_batch || !x_1 || !traj_x0 || !traj_xt || !R_out || !t_out)
+    return RAP_ERR_INVALID;
+  if (m->F > 0 && !feat) return RAP_ERR_INVALID;
+  if (B <= 0 || P <= 0 || TP <= 0 || num_steps <= 0 || TP > 0x7fffffffLL / 8 || (int64_t)B * P > 65535) return RAP_ERR_INVALID;
+  const int np = B * P;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  Workspace w = carve_workspace(m, TP, B, np, num_steps, (char*)ws);
+  if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int T = (int)TP;
+  const long n3 = (long)TP * 3;
+  int rc;
+  if ((rc = launch_part_offsets(stream, points_per_part, np, w.part_offsets))) return rc;
+  if ((rc = prepare_static(m, w, stream, cond, feat, scales, anchor, cu_batch, w.part_offsets, B, np, T))) return rc;
+  // t is uniform over the batch inside the sampler (modeling.py:674), so the adaLN table is computed once for
+  // ALL flow steps (row s = step s) instead of per sample per step.
+  const double dt = 1.0 / (double)num_steps;
+  hipLaunchKernelGGL(tgrid_kernel, dim3((num_steps + 63) / 64), dim3(64), 0, stream, w.tgrid, num_steps, dt);
+  RAP_LAUNCH_CHECK();
+  if ((rc = launch_adaln_table(stream, w.tgrid, num_steps, 2 * m->L, m->d, m->adaW1, m->adab1, m->adaW2, m->adab2,
+                               m->adaW3, m->adab3, w.ada_scratch, w.mod)))
+    return rc;
+  RAP_HIP_CHECK(hipMemcpyAsync(w.xt, x_1, (size_t)n3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  const size_t mod_step = (size_t)2 * m->L * 2 * m->d;
+  for (int s = 0; s < num_steps; ++s) {
+    const double t = 1.0 - (double)s * dt;
+    float* x0_slot = traj_x0 + (size_t)s * n3;
+    float* xt_slot = traj_xt + (size_t)s * n3;
+    float* feats = (feats_out && s == num_steps - 1) ? feats_out : nullptr;
+    if ((rc = forward_step(m, w, stream, w.xt, w.mod + (size_t)s * mod_step, 0, nullptr, T, w.v, feats))) return rc;
+    if ((rc = launch_euler_step(stream, w.xt, w.v, (float)t, (float)dt, x0_slot, w.xt, rigidity_forcing ? nullptr : xt_slot, n3)))
+      return rc;
+    if (rigidity_forcing) {
+      if ((rc = launch_procrustes_fit(stream, cond, x0_slot, w.part_offsets, np, w.Rc, w.tc, w.proc_partials))) return rc;
+      const float w0 = (float)(1.0 - t + dt), w1 = (float)(t - dt);
+      if ((rc = launch_rigid_apply(stream, cond, w.Rc, w.tc, w.part_offsets, np, w.xt, x_1, w0, w1, xt_slot, 1))) return rc;
+    }
+  }
+  // final poses (modeling.py:389-391): fit_transformations(cond, trajs[-1])
+  return launch_procrustes_fit(stream, cond, traj_x0 + (size_t)(num_steps - 1) * n3, w.part_offsets, np, R_out, t_out,
+                               w.proc_partials);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel-level entry points
+// ---------------------------------------------------------------------------------------------
+extern "C" int rap_gemm_f32(int32_t epilogue, const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc,
+                            int32_t M, int32_t N, int32_t K, const float* bias, const float* resid, int32_t ldr,
+                            const uint8_t* anchor, const float* anchor_emb, int32_t heads, void* stream) {
+  if (!A || !W || !C) return RAP_ERR_INVALID;
+  if (epilogue == EPI_BIAS_RESID && !resid) return RAP_ERR_INVALID;
+  if (epilogue == EPI_BIAS_ANCHOR && (!anchor || !anchor_emb)) return RAP_ERR_INVALID;
+  GemmParams g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias;
+  g.resid = resid; g.ldr = ldr; g.anchor = anchor; g.anchor_emb = anchor_emb; g.heads = heads;
+  return launch_gemm_f32((hipStream_t)stream, epilogue, g);
+}
+
+extern "C" int rap_geglu_interleave(const float* W, const float* b, float* Wp, float* bp, int32_t inner, int32_t K,
+                                    void* stream) {
+  if (!W || !b || !Wp || !bp) return RAP_ERR_INVALID;
+  return launch_geglu_interleave((hipStream_t)stream, W, b, Wp, bp, inner, K);
+}
+
+extern "C" size_t rap_attention_workspace_bytes(int64_t TP, int32_t nseg) {
+  return ((size_t)(TP / RAP_ATTN_BQ) + (size_t)nseg + 1) * sizeof(AttnWorkItem);
+}
+
+extern "C" int rap_attention_f32(const float* qkv_headmajor, const int32_t* cu_seqlens, int32_t nseg, float* out,
+                                 int64_t TP, int32_t heads, void* ws, size_t ws_bytes, void* stream_) {
+  if (!qkv_headmajor || !cu_seqlens || !out || nseg < 0 || TP < 0 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
+  if (!ws || ws_bytes < rap_attention_workspace_bytes(TP, nseg)) return RAP_ERR_WORKSPACE;
+  const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items))) return rc;
+  return launch_attention_f32(stream, qkv_headmajor, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items);
+}
+
+extern "C" int rap_layernorm_mod(const float* x, float* out, int64_t TP, int32_t d, const float* mod, int64_t mod_stride,
+                                 const int32_t* token_row, void* stream) {
+  if (!x || !out || !mod) return RAP_ERR_INVALID;
+  return launch_layernorm_mod((hipStream_t)stream, x, out, (int)TP, d, mod, (long)mod_stride, token_row);
+}
+extern "C" int rap_layernorm_affine(const float* x, float* out, int64_t TP, int32_t d, const float* gain, const float* shift,
+                                    void* stream) {
+  if (!x || !out || !gain || !shift) return RAP_ERR_INVALID;
+  return launch_layernorm_affine((hipStream_t)stream, x, out, (int)TP, d, gain, shift);
+}
+extern "C" int rap_qknorm(float* qkv_headmajor, int64_t TP, int32_t heads, const float* gamma_q, const float* gamma_k,
+                          void* stream) {
+  if (!qkv_headmajor || !gamma_q || !gamma_k) return RAP_ERR_INVALID;
+  return launch_qknorm((hipStream_t)stream, qkv_headmajor, (int)TP, heads, gamma_q, gamma_k);
+}
+extern "C" int rap_posenc_x(const float* x, float* ax, int64_t TP, void* stream) {
+  if (!x || !ax) return RAP_ERR_INVALID;
+  return launch_posenc_x((hipStream_t)stream, x, ax, (int)TP);
+}
+extern "C" int rap_posenc_static(const float* cond, const float* scales, const int32_t* token_sample, const float* feat,
+                                 int32_t feat_dim, float* astatic, int64_t TP, void* stream) {
+  if (!cond || !scales || !token_sample || !astatic) return RAP_ERR_INVALID;
+  return launch_posenc_static((hipStream_t)stream, cond, scales, token_sample, feat, feat_dim, astatic, (int)TP);
+}
+extern "C" int rap_token_sample(const int32_t* cu_batch, int32_t B, int32_t* token_sample, void* stream) {
+  if (!cu_batch || !token_sample) return RAP_ERR_INVALID;
+  return launch_token_sample((hipStream_t)stream, cu_batch, B, token_sample);
+}
+extern "C" int rap_adaln_table(const rap_model* m, const float* t, int32_t rows, float* scratch, float* out, void* stream) {
+  if (!m || !t || !scratch || !out) return RAP_ERR_INVALID;
+  return launch_adaln_table((hipStream_t)stream, t, rows, 2 * m->L, m->d, m->adaW1, m->adab1, m->adaW2, m->adab2, m->adaW3,
+                            m->adab3, scratch, out);
+}

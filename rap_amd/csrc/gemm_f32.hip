@@ -1,0 +1,202 @@
+// fp32 GEMM on the CDNA4 matrix cores:  C (M,N) = A (M,K) * W (N,K)^T  + fused epilogue.
+//
+// Replaces the nn.Linear calls on the reference's velocity-network path
+// (flow_model/layer.py:73-74,81-82,89 ; embedding.py:179 ; point_cloud_dit.py:111-117).
+//
+// Design (gfx950 only):
+//  * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 cyc/SIMD, one VGPR per operand.
+//  * 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator regs).
+//  * BK = 32: every A/W row contributes one full 128-byte line per k-tile.
+//  * LDS image [row][36 floats] (144-B row stride = 9 sixteen-byte slots: the 16 rows of each
+//    ds_read_b128 lane group land on 16 distinct slots -> conflict free).
+//  * The contraction order inside a k-tile is permuted so that one ds_read_b128 feeds four MFMAs:
+//    for k-group g (8 columns) lanes 0-31 read columns 8g..8g+3 and lanes 32-63 columns 8g+4..8g+7;
+//    MFMA step s then contracts the column pair {8g+s, 8g+4+s}.  A sum is order independent up to
+//    fp32 rounding, and the same permutation is applied to A and W.
+//  * global -> register -> LDS staging, double-buffered LDS, one barrier per k-tile; the loads of
+//    tile t+1 are issued before the 64 MFMAs of tile t.
+//  * 1-D grid, XCD-aware remap, n-tile fastest: all n-tiles of one 128-row A panel run back to
+//    back on one XCD (A panel stays in that XCD's L2; W streams from L2 / Infinity Cache).
+#include "kernels.h"
+
+#define GBM 128
+#define GBN 128
+#define GBK 32
+#define GLD 36  // LDS row stride in floats
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * GBM * GLD];
+  float* As = smem;                      // [2][128][36]
+  float* Bs = smem + 2 * GBM * GLD;      // [2][128][36]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nt = p.N / GBN;
+  const int mt = (p.M + GBM - 1) / GBM;
+  const int logical = xcd_remap(blockIdx.x, mt * nt);
+  const int m0 = (logical / nt) * GBM;
+  const int n0 = (logical % nt) * GBN;
+
+  // per-thread staging coordinates: 4 float4 of A and 4 of W per k-tile
+  const int srow = tid >> 3;         // 0..31 (+32*i)
+  const int sc4 = (tid & 7) * 4;     // float column inside the k-tile
+  const float* a_ptr[4];
+  const float* w_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = m0 + srow + 32 * i;
+    r = r < p.M ? r : p.M - 1;
+    a_ptr[i] = p.A + (size_t)r * p.lda + sc4;
+    w_ptr[i] = p.W + (size_t)(n0 + srow + 32 * i) * p.ldw + sc4;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[4], rw[4];
+  const int nk = p.K / GBK;
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *reinterpret_cast<const float4*>(a_ptr[i]);
+    rw[i] = *reinterpret_cast<const float4*>(w_ptr[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<float4*>(&As[(srow + 32 * i) * GLD + sc4]) = ra[i];
+    *reinterpret_cast<float4*>(&Bs[(srow + 32 * i) * GLD + sc4]) = rw[i];
+  }
+  __syncthreads();
+
+  const int a_off = (wm * 64 + l31) * GLD + 4 * hi;
+  const int b_off = (wn * 64 + l31) * GLD + 4 * hi;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1) < nk;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (size_t)(kt + 1) * GBK);
+        rw[i] = *reinterpret_cast<const float4*>(w_ptr[i] + (size_t)(kt + 1) * GBK);
+      }
+    }
+    const float* Ac = As + cur * (GBM * GLD);
+    const float* Bc = Bs + cur * (GBN * GLD);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 a0 = *reinterpret_cast<const float4*>(&Ac[a_off + 8 * g]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&Ac[a_off + 32 * GLD + 8 * g]);
+      const float4 b0 = *reinterpret_cast<const float4*>(&Bc[b_off + 8 * g]);
+      const float4 b1 = *reinterpret_cast<const float4*>(&Bc[b_off + 32 * GLD + 8 * g]);
+      const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
+      const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
+      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
+      const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
+      }
+    }
+    if (more) {
+      float* An = As + (cur ^ 1) * (GBM * GLD);
+      float* Bn = Bs + (cur ^ 1) * (GBN * GLD);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<float4*>(&An[(srow + 32 * i) * GLD + sc4]) = ra[i];
+        *reinterpret_cast<float4*>(&Bn[(srow + 32 * i) * GLD + sc4]) = rw[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  const int mw = m0 + wm * 64;
+  const int nw = n0 + wn * 64;
+  if (EPI == EPI_GEGLU) {
+    // acc[mi][0] = value columns, acc[mi][1] = gate columns of the same 32 outputs
+    const int nout = (nw >> 1) + l31;
+    const float bh = p.bias ? p.bias[nw + l31] : 0.f;
+    const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + mi * 32 + mfma32_crow(r, hi);
+        if (m < p.M) {
+          const float h = acc[mi][0][r] + bh;
+          const float g = acc[mi][1][r] + bg;
+          const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+          p.C[(size_t)m * p.ldc + nout] = h * ge;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = nw + ni * 32 + l31;
+      const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + mi * 32 + mfma32_crow(r, hi);
+        if (m >= p.M) continue;
+        float v = acc[mi][ni][r] + bn;
+        if (EPI == EPI_BIAS) {
+          p.C[(size_t)m * p.ldc + n] = v;
+        } else if (EPI == EPI_BIAS_RESID) {
+          p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
+        } else if (EPI == EPI_BIAS_SILU) {
+          p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
+        } else if (EPI == EPI_BIAS_ANCHOR) {
+          const int sel = p.anchor[m] ? 1 : 0;
+          p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
+        } else if (EPI == EPI_QKV_HEADMAJOR) {
+          const int dmodel = p.heads * 64;
+          const int c = n / dmodel;
+          const int rem = n - c * dmodel;
+          const int h = rem >> 6, j = rem & 63;
+          p.C[(((size_t)c * p.heads + h) * p.M + m) * 64 + j] = v;
+        }
+      }
+    }
+  }
+}
+
+int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p) {
+  if (p.M <= 0) return RAP_OK;
+  if (p.N % GBN != 0 || p.K % GBK != 0 || p.K <= 0) return RAP_ERR_INVALID;
+  if ((p.lda & 3) || (p.ldw & 3)) return RAP_ERR_INVALID;
+  const int mt = (p.M + GBM - 1) / GBM, nt = p.N / GBN;
+  dim3 grid(mt * nt), block(256);
+  switch (epilogue) {
+    case EPI_BIAS: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS>, grid, block, 0, stream, p); break;
+    case EPI_BIAS_RESID: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS_RESID>, grid, block, 0, stream, p); break;
+    case EPI_BIAS_SILU: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS_SILU>, grid, block, 0, stream, p); break;
+    case EPI_GEGLU: hipLaunchKernelGGL(gemm_f32_kernel<EPI_GEGLU>, grid, block, 0, stream, p); break;
+    case EPI_QKV_HEADMAJOR:
+      if (p.N != 3 * p.heads * 64) return RAP_ERR_INVALID;
+      hipLaunchKernelGGL(gemm_f32_kernel<EPI_QKV_HEADMAJOR>, grid, block, 0, stream, p);
+      break;
+    case EPI_BIAS_ANCHOR: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS_ANCHOR>, grid, block, 0, stream, p); break;
+    default: return RAP_ERR_INVALID;
+  }
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}

@@ -1,0 +1,179 @@
+"""Host-side mirror of the reference's velocity network class.
+
+``PointCloudDiT`` keeps the reference constructor and ``forward`` signature
+(reference ``rectified_point_flow/flow_model/point_cloud_dit.py:20-36,141-191``) and the reference
+``state_dict`` key/shape contract, but owns no PyTorch math: ``forward``
+hands device pointers to ``rap_dit_forward`` in librapflow (hand-written gfx950 kernels).
+PyTorch is used for device memory and the current stream only.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from .synthetic import weight_spec
+
+_WORKSPACES: dict = {}
+
+
+def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Grow-only per-device scratch buffer handed to the C ABI as the caller-owned workspace."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _WORKSPACES.pop(key, None)
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = buf
+    return buf
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise _lib.RapError(f"{name} must live on the GPU: rap_amd has no CPU path (got device {t.device})")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.float32).contiguous()
+
+
+class PointCloudDiT:
+    """Drop-in for ``rectified_point_flow.flow_model.PointCloudDiT`` (inference only)."""
+
+    def __init__(self, in_dim: int, out_dim: int, embed_dim: int, num_layers: int, num_heads: int,
+                 dropout_rate: float = 0.0, softcap: float = 0.0, qk_norm: bool = True, attn_dtype: str = "float16",
+                 final_mlp_act=None, max_points_per_part: int = 500, max_points_per_batch: int = 40000,
+                 scale_emb_on: bool = True, local_feat_concat_on: bool = True, local_feat_dim: int = 0):
+        if in_dim != 0:
+            raise NotImplementedError("in_dim != 0 (PTv3 encoder latent) is off in every shipped config (rap_12.yaml:17)")
+        if out_dim != 3:
+            raise NotImplementedError("out_dim must be 3")
+        if dropout_rate != 0.0 or softcap != 0.0:
+            raise NotImplementedError("dropout / softcap are 0 in inference (layer.py:28-29)")
+        if not (qk_norm and scale_emb_on and local_feat_concat_on):
+            raise NotImplementedError("qk_norm, scale_emb_on, local_feat_concat_on must be True (RAP_inference.yaml:65, "
+                                      "point_cloud_dit_12.yaml:8-9)")
+        if attn_dtype not in ("float16", "fp16", "bfloat16", "bf16", "float32", "fp32"):
+            raise ValueError(f"Unsupported attn_dtype: {attn_dtype}")   # point_cloud_dit.py:80-81
+        if embed_dim != 64 * num_heads:
+            raise NotImplementedError("head_dim must be 64")
+        self.in_dim, self.out_dim, self.embed_dim = in_dim, out_dim, embed_dim
+        self.num_layers, self.num_heads, self.local_feat_dim = num_layers, num_heads, local_feat_dim
+        self.max_points_per_part, self.max_points_per_batch = max_points_per_part, max_points_per_batch
+        # The kernels compute attention (and everything else) in fp32, i.e. at or above any attn_dtype the
+        # reference accepts; the string is kept for interface parity.
+        self.attn_dtype = attn_dtype
+        self.cfg = dict(embed_dim=embed_dim, num_layers=num_layers, num_heads=num_heads, local_feat_dim=local_feat_dim)
+        self._spec = weight_spec(self.cfg)
+        self._sd: dict[str, torch.Tensor] | None = None
+        self._handle = ctypes.c_void_p(0)
+        self._device: torch.device | None = None
+        self._desc = _lib.ModelDesc(embed_dim, num_layers, num_heads, local_feat_dim)
+        lib = _lib.load()
+        n = lib.rap_weight_count(ctypes.byref(self._desc))
+        if n < 0:
+            raise NotImplementedError(f"unsupported PointCloudDiT configuration {self.cfg}")
+        self._n_floats = int(n)
+
+    # ---- weights -------------------------------------------------------------------------------
+    def state_dict(self) -> dict[str, torch.Tensor]:
+        if self._sd is None:
+            raise _lib.RapError("no weights loaded")
+        return dict(self._sd)
+
+    def load_state_dict(self, state_dict: dict, strict: bool = True):
+        """Same key/shape contract as the reference module; ``strict`` as in nn.Module."""
+        names = [n for n, _ in self._spec]
+        missing = [n for n in names if n not in state_dict]
+        unexpected = [k for k in state_dict if k not in set(names)]
+        if missing or (strict and unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for PointCloudDiT: missing {missing[:4]}..., "
+                               f"unexpected {unexpected[:4]}...")
+        sd = {}
+        for n, shape in self._spec:
+            t = state_dict[n]
+            if tuple(t.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {n}: {tuple(t.shape)} vs {shape}")
+            sd[n] = t.detach().to(torch.float32)
+        self._sd = sd
+        self._release()
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.RapError("rap_amd.PointCloudDiT runs on the GPU only (no CPU fallback)")
+        self._ensure_model(device)
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+
+    def eval(self):
+        return self
+
+    def _release(self):
+        if self._handle:
+            _lib.load().rap_model_destroy(self._handle)
+            self._handle = ctypes.c_void_p(0)
+            self._device = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _ensure_model(self, device: torch.device):
+        if self._handle and self._device == device:
+            return
+        if self._sd is None:
+            raise _lib.RapError("load_state_dict() must be called before the model is used")
+        self._release()
+        lib = _lib.load()
+        with torch.cuda.device(device):
+            blob = torch.cat([self._sd[n].reshape(-1) for n, _ in self._spec]).to(device=device, dtype=torch.float32)
+            assert blob.numel() == self._n_floats
+            handle = ctypes.c_void_p(0)
+            rc = lib.rap_model_create(ctypes.byref(self._desc), _lib.ptr(blob), blob.numel(),
+                                      _lib.current_stream(device), ctypes.byref(handle))
+            _lib.check(rc, "rap_model_create")
+            torch.cuda.current_stream(device).synchronize()   # blob may be freed after this
+        self._handle, self._device = handle, device
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward(self, x, timesteps, cond_coord, local_features, latent_features, scales, anchor_indices,
+                cu_seqlens_batch, cu_seqlens_part, return_transformer_features: bool = False):
+        """(TP,3) velocity, or {'velocity','transformer_features'}  (point_cloud_dit.py:141-191)."""
+        if latent_features is not None:
+            raise NotImplementedError("latent_features must be None (in_dim == 0)")
+        _require_cuda(x, "x")
+        device = x.device
+        self._ensure_model(device)
+        lib = _lib.load()
+        TP = x.shape[0]
+        B = cu_seqlens_batch.shape[0] - 1
+        VP = cu_seqlens_part.shape[0] - 1
+        x = _f32c(x); cond = _f32c(cond_coord.reshape(TP, 3)); feats = _f32c(local_features.reshape(TP, -1))
+        ts = _f32c(timesteps.to(device)); sc = _f32c(scales.to(device))
+        anchor = anchor_indices.to(device=device, dtype=torch.uint8).contiguous()
+        cu_b = cu_seqlens_batch.to(device=device, dtype=torch.int32).contiguous()
+        cu_p = cu_seqlens_part.to(device=device, dtype=torch.int32).contiguous()
+        if feats.shape[1] != self.local_feat_dim or ts.shape[0] != B or sc.shape[0] != B:
+            raise ValueError("shape mismatch in PointCloudDiT.forward inputs")
+        v = torch.empty((TP, 3), dtype=torch.float32, device=device)
+        feat_out = torch.empty((TP, self.embed_dim), dtype=torch.float32, device=device) if return_transformer_features else None
+        nbytes = lib.rap_workspace_bytes(self._handle, TP, B, VP, B)
+        ws = workspace(device, nbytes)
+        with torch.cuda.device(device):
+            rc = lib.rap_dit_forward(self._handle, _lib.ptr(x), _lib.ptr(ts), _lib.ptr(cond), _lib.ptr(feats), _lib.ptr(sc),
+                                     _lib.ptr(anchor), _lib.ptr(cu_b), _lib.ptr(cu_p), B, VP, TP, _lib.ptr(v),
+                                     _lib.ptr(feat_out), _lib.ptr(ws), ws.numel(), _lib.current_stream(device))
+        _lib.check(rc, "rap_dit_forward")
+        if return_transformer_features:
+            return {"velocity": v, "transformer_features": feat_out}
+        return v
+
+    __call__ = forward

@@ -1,0 +1,102 @@
+"""Host-side mirror of the sampling boundary of ``rectified_point_flow/modeling.py``.
+
+``RectifiedPointFlow`` here is a plain class (no Lightning): it keeps the reference's
+``sample_rectified_flow`` signature and return structure (modeling.py:632-741) plus the
+``fit_transformations`` call that ``test_step`` makes right after it (modeling.py:389-391).  The whole
+Euler loop -- velocity network, Euler update, optional per-step Procrustes rigidity projection,
+trajectory capture, final pose recovery -- is ONE call into librapflow (``rap_sample``); nothing on
+the path syncs with the host.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .flow_model import PointCloudDiT, _f32c, _require_cuda, workspace
+
+
+class RectifiedPointFlow:
+    """Inference-side drop-in for the reference LightningModule's sampling API."""
+
+    def __init__(self, flow_model: PointCloudDiT = None, inference_sampling_steps: int = 20,
+                 inference_sampler: str = "euler", n_generations: int = 1, rigidity_forcing: bool = False,
+                 return_end_point_trajectory: bool = True, encoder_on: bool = False, **_ignored):
+        if flow_model is None:
+            raise ValueError("flow_model is required")            # modeling.py:80-81
+        if encoder_on:
+            raise NotImplementedError("encoder_on=True (PTv3 latent) is disabled in every shipped config")
+        if inference_sampler != "euler":
+            raise ValueError(f"Unknown sampler: {inference_sampler}. Available: ['euler']")   # sampler.py:168-169
+        self.flow_model = flow_model
+        self.inference_sampling_steps = inference_sampling_steps
+        self.inference_sampler = inference_sampler
+        self.n_generations = n_generations
+        self.rigidity_forcing = rigidity_forcing
+        self.return_end_point_trajectory = return_end_point_trajectory
+        self.last_poses = None
+
+    # modeling.py:203-231 without the boolean-mask compaction (which syncs): empty parts stay in the table as
+    # zero-length segments, which every kernel treats as a no-op and which yields the same zero R,t rows.
+    @staticmethod
+    def _prepare_data(data_dict: dict):
+        cond = data_dict["pointclouds"]
+        _require_cuda(cond, 'data_dict["pointclouds"]')
+        device = cond.device
+        return dict(
+            cond=_f32c(cond), feats=_f32c(data_dict["features"].to(device)), scales=_f32c(data_dict["scales"].to(device)),
+            anchor=data_dict["anchor_indices"].to(device=device, dtype=torch.uint8).contiguous(),
+            ppp=data_dict["points_per_part"].to(device=device, dtype=torch.int64).contiguous(),
+            cu_batch=data_dict["cu_seqlens"].to(device=device, dtype=torch.int32).contiguous())
+
+    @torch.inference_mode()
+    def sample_and_register(self, data_dict: dict, x_1: torch.Tensor | None = None,
+                            return_transformer_features: bool = False) -> dict:
+        """One generation: {'end_point_trajectory','trajectory' (S,TP,3), 'R' (B,P,3,3), 't' (B,P,3)[, features]}."""
+        d = self._prepare_data(data_dict)
+        cond = d["cond"]
+        device = cond.device
+        TP = cond.shape[0]
+        B, P = d["ppp"].shape
+        S = int(self.inference_sampling_steps)
+        x_1 = torch.randn_like(cond) if x_1 is None else _f32c(x_1.to(device))    # modeling.py:664
+        model = self.flow_model
+        model._ensure_model(device)
+        lib = _lib.load()
+        traj_x0 = torch.empty((S, TP, 3), dtype=torch.float32, device=device)     # sampler.py:47-49
+        traj_xt = torch.empty((S, TP, 3), dtype=torch.float32, device=device)
+        R = torch.empty((B, P, 3, 3), dtype=torch.float32, device=device)
+        t = torch.empty((B, P, 3), dtype=torch.float32, device=device)
+        feats_out = torch.empty((TP, model.embed_dim), dtype=torch.float32, device=device) if return_transformer_features else None
+        ws = workspace(device, lib.rap_workspace_bytes(model._handle, TP, B, B * P, S))
+        with torch.cuda.device(device):
+            rc = lib.rap_sample(model._handle, _lib.ptr(cond), _lib.ptr(d["feats"]), _lib.ptr(d["scales"]), _lib.ptr(d["anchor"]),
+                                _lib.ptr(d["ppp"]), _lib.ptr(d["cu_batch"]), _lib.ptr(x_1), B, P, TP, S,
+                                1 if self.rigidity_forcing else 0, _lib.ptr(traj_x0), _lib.ptr(traj_xt), _lib.ptr(R),
+                                _lib.ptr(t), _lib.ptr(feats_out), _lib.ptr(ws), ws.numel(), _lib.current_stream(device))
+        _lib.check(rc, "rap_sample")
+        out = {"end_point_trajectory": traj_x0, "trajectory": traj_xt, "R": R, "t": t}
+        if return_transformer_features:
+            out["transformer_features"] = feats_out
+        return out
+
+    @torch.inference_mode()
+    def sample_rectified_flow(self, data_dict: dict, latent_features: torch.Tensor | None, x_1: torch.Tensor | None = None,
+                              return_tarjectory: bool = False, return_transformer_features: bool = False):
+        """Reference signature and return structure (modeling.py:633-741; the misspelt keyword is the reference's).
+
+        The per-part poses of the final end point -- what ``test_step`` computes next with
+        ``fit_transformations(cond, trajs[-1], ...)`` (modeling.py:389-391) -- come out of the same call and are
+        kept in ``self.last_poses`` as ``(R (B,P,3,3), t (B,P,3))``."""
+        if latent_features is not None:
+            raise NotImplementedError("latent_features must be None (encoder_on=False)")
+        out = self.sample_and_register(data_dict, x_1, return_transformer_features)
+        self.last_poses = (out["R"], out["t"])
+        result = {"end_point_trajectory": out["end_point_trajectory"], "trajectory": out["trajectory"]}
+        if return_transformer_features:
+            if return_tarjectory:
+                return {"trajectory": result, "transformer_features": out["transformer_features"]}
+            # modeling.py:733 indexes the dict with [-1] (a latent bug: KeyError); we return the final end point
+            return {"points": result["end_point_trajectory"][-1], "transformer_features": out["transformer_features"]}
+        return result
+
+    sample = sample_rectified_flow   # the name BASELINE.json's north_star uses

