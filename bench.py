@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- registered points/sec of the MI355X-native flow-matching registration sampler.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one batch: RectifiedPointFlow.sample_rectified_flow
+(20 Euler flow steps of the rap_12 velocity network + per-step Procrustes rigidity projection + final
+per-view SE(3) recovery) on BASELINE.json configs[1]: 32 scan pairs x 2 views x 4096 points, fp32,
+inputs already resident in HBM.  Multi-GPU: independent pairs shard across ranks (32 pairs per rank, weak
+scaling), one RCCL all-gather of the registered clouds and poses at the end of every step.
+
+Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline      -- the dominant kernel (attention_f32_kernel): algorithmic FLOPs / HIP-event time, vs the
+                   157.3 TFLOP/s fp32 matrix peak of gfx950;
+  cpu_baseline  -- the CPU oracle (restatement of the reference, pinned to it) timed on this box's host cores
+                   on a bounded sample (1 pair, 1 of 20 flow steps), extrapolated linearly.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="scan pairs per GPU")
+    ap.add_argument("--views", type=int, default=2)
+    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--flow-steps", type=int, default=20)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--rigidity", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def attention_flops_per_forward(batch, views, points, layers, heads=8, dh=64):
+    """Algorithmic FLOPs of the two attention launches of one layer, summed over the batch:
+    4 * H * Dh * L_seg per query token (QK^T and PV, 2 FLOP per MAC)."""
+    tp = batch * views * points
+    per_part = tp * 4 * heads * dh * points
+    per_sample = tp * 4 * heads * dh * views * points
+    return per_part, per_sample
+
+
+def cpu_baseline(cfg, sd, args, gpu_first_step):
+    """Oracle on the host cores: 1 pair, the first of `flow_steps` flow steps; linear extrapolation."""
+    from oracle import rap_oracle as O
+    from rap_amd import synthetic as S
+    torch.set_num_threads(os.cpu_count() or 1)
+    inp = S.make_uniform_inputs(1, args.views, args.points, seed=1234)   # == pair 0 of rank 0's batch
+    t0 = time.perf_counter()
+    ref = O.sample(sd, cfg, inp, args.flow_steps, bool(args.rigidity), max_steps=1)
+    dt = time.perf_counter() - t0
+    pts = args.views * args.points
+    out = {"value": pts / (dt * args.flow_steps), "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"1 pair ({args.views}x{args.points} pts), 1 of {args.flow_steps} flow steps incl. rigidity projection "
+                     f"and pose fit: {dt:.1f} s; linearly extrapolated to {args.flow_steps} steps",
+           "seconds_measured": dt}
+    # SE(3) / end-point deviation of the GPU path vs the CPU oracle on that same pair and step
+    x0_gpu, R_gpu, t_gpu = gpu_first_step
+    err = {"x0_max_abs": float((x0_gpu - ref["end_point_trajectory"][0]).abs().max()),
+           "rot_err_deg_max": float(O.rotation_error_deg(R_gpu, ref["R"][0]).max()),
+           "R_frob_max": float(torch.linalg.matrix_norm(R_gpu - ref["R"][0]).max()),
+           "trans_abs_max": float((t_gpu - ref["t"][0]).abs().max())}
+    return out, err
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (rap_amd has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    import rap_amd
+    from rap_amd import _lib, synthetic as S
+    from rap_amd.parallel import gather_registrations
+
+    cfg = dict(S.RAP_12); cfg["num_layers"] = args.layers
+    sd = S.make_weights(cfg, 0)
+    model = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
+                                  num_heads=cfg["num_heads"], local_feat_dim=cfg["local_feat_dim"], attn_dtype="float32")
+    model.load_state_dict(sd)
+    model.to(dev)
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=args.flow_steps,
+                                      rigidity_forcing=bool(args.rigidity))
+    # rank r owns pairs [r*batch, (r+1)*batch) of the global job; synthetic, seeded per pair
+    inp = S.make_inputs([[args.points] * args.views for _ in range(args.batch)], seed=1234 + rank * args.batch)
+    data = {k: v.to(dev) for k, v in inp.items()}
+    x_1 = data["x_1"]
+    pts_per_rank = args.batch * args.views * args.points
+    lib = _lib.load()
+
+    def one_step():
+        out = flow.sample_and_register(data, x_1=x_1)
+        final = out["end_point_trajectory"][-1]
+        if distributed:
+            return gather_registrations(final, out["R"], out["t"]), out
+        return (final, out["R"], out["t"]), out
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    profile = not args.no_profile
+    if profile:
+        lib.rap_profile_reset(); lib.rap_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered, last = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof_ms = (ctypes.c_float * 3)(); prof_n = (ctypes.c_int64 * 3)()
+    if profile:
+        lib.rap_profile_enable(0)
+        _lib.check(lib.rap_profile_collect(prof_ms, prof_n), "rap_profile_collect")
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        total_pts = pts_per_rank * world * args.steps
+        value = total_pts / elapsed
+        result = {
+            "metric": "registered points/sec @20 flow steps, 2-view N=4096", "value": value, "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: batch={args.batch} pairs/GPU x {args.views} views x {args.points} pts, "
+                                   f"{args.flow_steps} Euler flow steps, rap_{args.layers} (d=512, H=8), fp32, "
+                                   f"rigidity_forcing={'on' if args.rigidity else 'off'}, final per-view SE(3) fit",
+                       "pairs_per_gpu": args.batch, "views": args.views, "points_per_view": args.points,
+                       "flow_steps": args.flow_steps, "num_layers": args.layers, "rigidity_forcing": bool(args.rigidity),
+                       "sharding": f"independent pairs, {world} rank(s), one RCCL all-gather of clouds+poses per step"},
+        }
+        if profile and prof_n[0] > 0 and prof_n[1] > 0:
+            f_part, f_samp = attention_flops_per_forward(args.batch, args.views, args.points, args.layers)
+            n_launch = int(prof_n[0] + prof_n[1])
+            flops = f_part * int(prof_n[0]) + f_samp * int(prof_n[1])
+            secs = (prof_ms[0] + prof_ms[1]) * 1e-3
+            achieved = flops / secs / 1e12
+            result["roofline"] = {
+                "kernel": "attention_f32_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                "launches": n_launch, "avg_launch_ms": 1e3 * secs / n_launch,
+                "flops_per_launch_avg": flops / n_launch,
+                "per_part": {"launches": int(prof_n[0]), "avg_ms": prof_ms[0] / max(1, prof_n[0]),
+                             "tflops": f_part * int(prof_n[0]) / (prof_ms[0] * 1e-3) / 1e12},
+                "per_sample": {"launches": int(prof_n[1]), "avg_ms": prof_ms[1] / max(1, prof_n[1]),
+                               "tflops": f_samp * int(prof_n[1]) / (prof_ms[1] * 1e-3) / 1e12},
+                "gemm": {"launches": int(prof_n[2]), "total_ms": float(prof_ms[2]),
+                         "tflops": (args.batch * args.views * args.points * 10.486e6 * (int(prof_n[2]) / 6))
+                                   / (prof_ms[2] * 1e-3) / 1e12 if prof_n[2] else None},
+                "fraction_of_step_time": {"attention": secs / elapsed, "gemm": prof_ms[2] * 1e-3 / elapsed},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            n0 = args.views * args.points
+            x0_first = last["end_point_trajectory"][0][:n0]
+            ppp0 = data["points_per_part"][:1]
+            R0, t0_ = rap_amd.fit_transformations(data["pointclouds"][:n0], x0_first, ppp0, data["cu_seqlens"][:2])
+            base, err = cpu_baseline(cfg, sd, args, (x0_first.cpu(), R0.cpu()[0], t0_.cpu()[0]))
+            result["cpu_baseline"] = base
+            result["se3_vs_cpu_oracle"] = err
+            result["speedup_vs_cpu_baseline"] = value / base["value"]
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

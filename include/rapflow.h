@@ -125,6 +125,16 @@ int rap_token_sample(const int32_t* cu_batch, int32_t B, int32_t* token_sample, 
  * scratch >= rows*(256 + 4*num_layers*embed_dim) floats. */
 int rap_adaln_table(const rap_model* m, const float* t, int32_t rows, float* scratch, float* out, void* stream);
 
+
+/* ---- measurement hooks (bench.py roofline leg) ----
+ * When enabled, every attention and layer-GEMM launch inside rap_dit_forward / rap_sample is bracketed by two
+ * hipEvents recorded on the launch stream.  rap_profile_collect synchronises on them and returns, per class
+ * (0 attention per part, 1 attention per sample, 2 layer GEMMs), the summed milliseconds and the launch count
+ * into HOST arrays of 3 entries.  Not thread-safe; off by default. */
+int rap_profile_enable(int on);
+int rap_profile_reset(void);
+int rap_profile_collect(float* h_ms_out, int64_t* h_count_out);
+
 #ifdef __cplusplus
 }
 #endif

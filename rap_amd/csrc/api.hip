@@ -11,6 +11,53 @@ static thread_local int g_last_hip_error = 0;
 void rap_set_last_hip_error(int e) { g_last_hip_error = e; }
 
 // ---------------------------------------------------------------------------------------------
+// optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
+// Off by default; when on, every attention / GEMM launch of forward_step is bracketed by two events.
+// ---------------------------------------------------------------------------------------------
+#define RAP_PROF_CLASSES 3   // 0 = attention per part, 1 = attention per sample, 2 = GEMM
+struct ProfRec { hipEvent_t a, b; int cls; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static size_t g_prof_pool_used = 0;
+static const size_t RAP_PROF_MAX_EVENTS = 32768;
+
+static hipEvent_t prof_event() {
+  if (g_prof_pool_used < g_prof_pool.size()) return g_prof_pool[g_prof_pool_used++];
+  if (g_prof_pool.size() >= RAP_PROF_MAX_EVENTS) return nullptr;
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  g_prof_pool.push_back(e);
+  g_prof_pool_used++;
+  return e;
+}
+struct ProfScope {
+  hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int cls;
+  ProfScope(hipStream_t s_, int cls_) : s(s_), cls(cls_) {
+    if (!g_prof_on) return;
+    a = prof_event(); b = prof_event();
+    if (a && b) (void)hipEventRecord(a, s); else a = b = nullptr;
+  }
+  ~ProfScope() {
+    if (a && b) { (void)hipEventRecord(b, s); g_prof_recs.push_back({a, b, cls}); }
+  }
+};
+extern "C" int rap_profile_enable(int on) { g_prof_on = on != 0; return RAP_OK; }
+extern "C" int rap_profile_reset(void) { g_prof_recs.clear(); g_prof_pool_used = 0; return RAP_OK; }
+// Synchronises on the recorded events.  ms_out / count_out have RAP_PROF_CLASSES (3) entries.
+extern "C" int rap_profile_collect(float* h_ms_out, int64_t* h_count_out) {
+  if (!h_ms_out || !h_count_out) return RAP_ERR_INVALID;
+  for (int c = 0; c < RAP_PROF_CLASSES; ++c) { h_ms_out[c] = 0.f; h_count_out[c] = 0; }
+  for (const ProfRec& r : g_prof_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return RAP_ERR_HIP;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return RAP_ERR_HIP;
+    h_ms_out[r.cls] += ms; h_count_out[r.cls] += 1;
+  }
+  return RAP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------------------------
 struct LayerW {
@@ -248,25 +295,32 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       if ((rc = launch_layernorm_mod(stream, w.h, w.xn, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
       GemmParams g{};
       g.A = w.xn; g.lda = d; g.W = lw.Wqkv[a]; g.ldw = d; g.C = w.qkv; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
-      if ((rc = launch_gemm_f32(stream, EPI_QKV_HEADMAJOR, g))) return rc;
+      { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_QKV_HEADMAJOR, g); }
+      if (rc) return rc;
       if ((rc = launch_qknorm(stream, w.qkv, TP, H, lw.gq[a], lw.gk[a]))) return rc;
-      if (a == 0) rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_part, w.max_items_part);
-      else rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_batch, w.max_items_batch);
+      {
+        ProfScope ps(stream, a);
+        if (a == 0) rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_part, w.max_items_part);
+        else rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_batch, w.max_items_batch);
+      }
       if (rc) return rc;
       GemmParams o{};
       o.A = w.att; o.lda = d; o.W = lw.Wout[a]; o.ldw = d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = d;
       o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d;
-      if ((rc = launch_gemm_f32(stream, EPI_BIAS_RESID, o))) return rc;
+      { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_BIAS_RESID, o); }
+      if (rc) return rc;
     }
     if ((rc = launch_layernorm_affine(stream, w.h, w.xn, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
     GemmParams f1{};
     f1.A = w.xn; f1.lda = d; f1.W = lw.Wff1p; f1.ldw = d; f1.C = w.ffmid; f1.ldc = 4 * d; f1.M = TP; f1.N = 8 * d; f1.K = d;
     f1.bias = lw.bff1p;
-    if ((rc = launch_gemm_f32(stream, EPI_GEGLU, f1))) return rc;
+    { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_GEGLU, f1); }
+    if (rc) return rc;
     GemmParams f2{};
     f2.A = w.ffmid; f2.lda = 4 * d; f2.W = lw.Wff2; f2.ldw = 4 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 4 * d;
     f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d;
-    if ((rc = launch_gemm_f32(stream, EPI_BIAS_RESID, f2))) return rc;
+    { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_BIAS_RESID, f2); }
+    if (rc) return rc;
   }
   if (feats_out) {
     if (hipMemcpyAsync(feats_out, w.h, (size_t)TP * d * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) {

@@ -1,0 +1,151 @@
+"""GPU parity tests of the velocity network and the whole sampling call against (a) the golden
+vectors produced by the reference's own modules and (b) the CPU oracle, through the reference-shaped
+Python API (which calls the C ABI).
+
+Stated fp32 tolerances (calibrated against the fp64 oracle: the CPU fp32 oracle
+itself sits ~5e-7 from fp64 on these cases):
+  velocity per forward   max|dv|  <= 1e-4 * max|v|
+  end points / x_t       max|d|   <= 5e-4      (normalised units)
+  poses                  |R - R_ref|_F <= 1e-3, |t - t_ref| <= 1e-3
+The tests assert the much tighter bounds actually expected of an exact-fp32 path (1e-5 class).
+"""
+import pytest
+import torch
+
+import rap_amd
+from conftest import GOLDEN_CASES, load_golden
+from oracle import rap_oracle as O
+from rap_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+_MODELS = {}
+
+
+def get_model(num_layers, seed, dev):
+    key = (num_layers, seed)
+    if key not in _MODELS:
+        cfg = dict(S.RAP_12); cfg["num_layers"] = num_layers
+        sd = S.make_weights(cfg, seed)
+        m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=num_layers, num_heads=8,
+                                  local_feat_dim=32, attn_dtype="float32")
+        m.load_state_dict(sd)
+        _MODELS[key] = (cfg, sd, m.to(dev))
+    return _MODELS[key]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def to_dev(inp, dev):
+    return {k: v.to(dev) for k, v in inp.items()}
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_forward_matches_reference_golden(name, dev):
+    g, inp = load_golden(name)
+    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev)
+    cu_b, cu_p = O.prepare_cu_seqlens(inp)
+    d = to_dev(inp, dev)
+    out = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
+                local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev), return_transformer_features=True)
+    v_ref = torch.from_numpy(g["fwd_velocity"]); f_ref = torch.from_numpy(g["fwd_features"])
+    ev = (out["velocity"].cpu() - v_ref).abs().max().item()
+    ef = (out["transformer_features"].cpu() - f_ref).abs().max().item()
+    assert ev <= 1e-4 * v_ref.abs().max().item(), ev          # the stated tolerance
+    assert ev < 2e-5 and ef < 2e-4, (ev, ef)                    # what an exact-fp32 path actually achieves
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_sample_matches_reference_golden(name, dev):
+    g, inp = load_golden(name)
+    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev)
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=int(g["num_steps"]),
+                                      rigidity_forcing=bool(g["rigidity"]))
+    d = to_dev(inp, dev)
+    res = flow.sample_rectified_flow(d, None, x_1=d["x_1"])
+    R, t = flow.last_poses
+    e0 = (res["end_point_trajectory"].cpu() - torch.from_numpy(g["end_point_trajectory"])).abs().max().item()
+    e1 = (res["trajectory"].cpu() - torch.from_numpy(g["trajectory"])).abs().max().item()
+    eR = torch.linalg.matrix_norm(R.cpu() - torch.from_numpy(g["R"])).max().item()
+    et = (t.cpu() - torch.from_numpy(g["t"])).abs().max().item()
+    assert e0 <= 5e-4 and e1 <= 5e-4 and eR <= 1e-3 and et <= 1e-3, (e0, e1, eR, et)     # stated tolerance
+    if bool(g["rigidity"]):
+        assert e0 < 5e-5 and e1 < 5e-5 and eR < 5e-5 and et < 5e-5, (e0, e1, eR, et)
+    else:
+        # without rigidity forcing the final Procrustes is ill-conditioned on random weights
+        assert e0 < 5e-5 and e1 < 5e-5, (e0, e1)
+    # rotation error in degrees via the reference's formula (eval/metrics.py:289-291), reported for the record
+    valid = torch.from_numpy(g["in_points_per_part"]) > 0
+    deg = O.rotation_error_deg(R.cpu()[valid], torch.from_numpy(g["R"])[valid]).max().item()
+    print(f"{name}: x0 {e0:.2e} xt {e1:.2e} |dR|_F {eR:.2e} dt {et:.2e} rot {deg:.4f} deg")
+
+
+def test_sample_matches_oracle_on_fresh_ragged_batch(dev):
+    """Not a stored fixture: oracle and HIP path run on the same seeded inputs (varlen, 3 samples, 2-4 parts)."""
+    cfg, sd, model = get_model(2, 5, dev)
+    inp = S.make_inputs([[257, 300], [64, 1, 33, 90], [1000, 24, 511]], seed=77)
+    steps = 5
+    ref = O.sample(sd, cfg, inp, steps, True)
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=steps, rigidity_forcing=True)
+    out = flow.sample_and_register(to_dev(inp, dev), x_1=inp["x_1"].to(dev), return_transformer_features=True)
+    for k in ("end_point_trajectory", "trajectory", "R", "t"):
+        err = (out[k].cpu() - ref[k]).abs().max().item()
+        assert err < 5e-5, (k, err)
+    assert out["transformer_features"].shape == (inp["x_1"].shape[0], 512)
+
+
+def test_generic_sampler_equals_fused_loop(dev):
+    """get_sampler('euler') driving PointCloudDiT.forward step by step (per-sample t table) must reproduce the
+    fused rap_sample loop (per-step table, t uniform) -- same kernels, same numbers."""
+    cfg, sd, model = get_model(2, 0, dev)
+    inp = S.make_inputs([[37, 64, 100], [50, 129]], seed=7)
+    d = to_dev(inp, dev)
+    cu_b, cu_p = O.prepare_cu_seqlens(inp)
+    B = 2
+
+    def fn(x, t):
+        return model(x=x, timesteps=torch.full((B,), t, device=dev), cond_coord=d["pointclouds"], local_features=d["features"],
+                     latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                     cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev))
+    for rigid in (False, True):
+        res = rap_amd.get_sampler("euler")(flow_model_fn=fn, x_1=d["x_1"], x_0=d["pointclouds"], condition=d["pointclouds"],
+                                          points_per_part=d["points_per_part"], cu_seqlens_batch=cu_b.to(dev),
+                                          anchor_indices=d["anchor_indices"], num_steps=4, return_trajectory=True,
+                                          rigidity_forcing=rigid)
+        flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=4, rigidity_forcing=rigid)
+        fused = flow.sample_rectified_flow(d, None, x_1=d["x_1"])
+        for k in ("end_point_trajectory", "trajectory"):
+            assert (res[k] - fused[k]).abs().max().item() < 1e-6, (rigid, k)
+
+
+def test_full_size_pair_properties(dev):
+    """BASELINE geometry (2 views x 4096 points), rap_12, 2 of 20 flow steps (dt = 1/20 grid is what rap_sample uses
+    for num_steps = 2 -> dt = 0.5; the properties below are step-count independent):
+      * samples in a batch are independent: sample 0 of a 2-pair batch == the same pair alone;
+      * with rigidity forcing the last x_t is a rigid image of cond (weight on x_1 is t - dt = 0);
+      * recovered rotations are proper (R R^T = I, det = +1)."""
+    cfg, sd, model = get_model(12, 0, dev)
+    inp2 = S.make_uniform_inputs(2, 2, 4096, seed=1234)
+    inp1 = S.make_uniform_inputs(1, 2, 4096, seed=1234)
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=2, rigidity_forcing=True)
+    o2 = flow.sample_and_register(to_dev(inp2, dev), x_1=inp2["x_1"].to(dev))
+    o1 = flow.sample_and_register(to_dev(inp1, dev), x_1=inp1["x_1"].to(dev))
+    n = 8192
+    assert (o2["end_point_trajectory"][:, :n] - o1["end_point_trajectory"]).abs().max().item() < 1e-5
+    assert (o2["R"][0] - o1["R"][0]).abs().max().item() < 1e-5
+    R, t = o1["R"][0], o1["t"][0]                       # (P,3,3), (P,3)
+    eye = torch.eye(3, device=dev)
+    assert (R @ R.transpose(1, 2) - eye).abs().max().item() < 1e-5
+    assert (torch.linalg.det(R) - 1).abs().max().item() < 1e-5
+    cond = inp1["pointclouds"].to(dev)
+    rig = rap_amd.rigidify_prediction_with_procrustes(o1["end_point_trajectory"][-1], cond, inp1["points_per_part"],
+                                                      inp1["cu_seqlens"])
+    assert (o1["trajectory"][-1] - rig).abs().max().item() < 1e-5
+    for p in range(2):
+        seg = slice(p * 4096, (p + 1) * 4096)
+        assert (rig[seg] - (cond[seg] @ R[p].T + t[p])).abs().max().item() < 1e-5
