@@ -64,65 +64,68 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[4], rw[4];
+  float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;   // named registers: arrays under a branch end up in scratch
   const int nk = p.K / GBK;
+  const int st_off = srow * GLD + sc4;
 
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra[i] = *reinterpret_cast<const float4*>(a_ptr[i]);
-    rw[i] = *reinterpret_cast<const float4*>(w_ptr[i]);
+#define GEMM_LOAD_TILE(KT)                                                            \
+  ra0 = *reinterpret_cast<const float4*>(a_ptr[0] + (size_t)(KT) * GBK);              \
+  ra1 = *reinterpret_cast<const float4*>(a_ptr[1] + (size_t)(KT) * GBK);              \
+  ra2 = *reinterpret_cast<const float4*>(a_ptr[2] + (size_t)(KT) * GBK);              \
+  ra3 = *reinterpret_cast<const float4*>(a_ptr[3] + (size_t)(KT) * GBK);              \
+  rw0 = *reinterpret_cast<const float4*>(w_ptr[0] + (size_t)(KT) * GBK);              \
+  rw1 = *reinterpret_cast<const float4*>(w_ptr[1] + (size_t)(KT) * GBK);              \
+  rw2 = *reinterpret_cast<const float4*>(w_ptr[2] + (size_t)(KT) * GBK);              \
+  rw3 = *reinterpret_cast<const float4*>(w_ptr[3] + (size_t)(KT) * GBK);
+#define GEMM_STORE_TILE(BUF)                                                          \
+  *reinterpret_cast<float4*>(&As[(BUF) * (GBM * GLD) + st_off + 0 * 32 * GLD]) = ra0; \
+  *reinterpret_cast<float4*>(&As[(BUF) * (GBM * GLD) + st_off + 1 * 32 * GLD]) = ra1; \
+  *reinterpret_cast<float4*>(&As[(BUF) * (GBM * GLD) + st_off + 2 * 32 * GLD]) = ra2; \
+  *reinterpret_cast<float4*>(&As[(BUF) * (GBM * GLD) + st_off + 3 * 32 * GLD]) = ra3; \
+  *reinterpret_cast<float4*>(&Bs[(BUF) * (GBN * GLD) + st_off + 0 * 32 * GLD]) = rw0; \
+  *reinterpret_cast<float4*>(&Bs[(BUF) * (GBN * GLD) + st_off + 1 * 32 * GLD]) = rw1; \
+  *reinterpret_cast<float4*>(&Bs[(BUF) * (GBN * GLD) + st_off + 2 * 32 * GLD]) = rw2; \
+  *reinterpret_cast<float4*>(&Bs[(BUF) * (GBN * GLD) + st_off + 3 * 32 * GLD]) = rw3;
+#define GEMM_COMPUTE_TILE(BUF)                                                                        \
+  {                                                                                                   \
+    const float* Ac = As + (BUF) * (GBM * GLD);                                                       \
+    const float* Bc = Bs + (BUF) * (GBN * GLD);                                                       \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
+      const float4 a0 = *reinterpret_cast<const float4*>(&Ac[a_off + 8 * g]);                         \
+      const float4 a1 = *reinterpret_cast<const float4*>(&Ac[a_off + 32 * GLD + 8 * g]);              \
+      const float4 b0 = *reinterpret_cast<const float4*>(&Bc[b_off + 8 * g]);                         \
+      const float4 b1 = *reinterpret_cast<const float4*>(&Bc[b_off + 32 * GLD + 8 * g]);              \
+      GEMM_MFMA4(a0.x, a1.x, b0.x, b1.x)                                                              \
+      GEMM_MFMA4(a0.y, a1.y, b0.y, b1.y)                                                              \
+      GEMM_MFMA4(a0.z, a1.z, b0.z, b1.z)                                                              \
+      GEMM_MFMA4(a0.w, a1.w, b0.w, b1.w)                                                              \
+    }                                                                                                 \
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<float4*>(&As[(srow + 32 * i) * GLD + sc4]) = ra[i];
-    *reinterpret_cast<float4*>(&Bs[(srow + 32 * i) * GLD + sc4]) = rw[i];
-  }
-  __syncthreads();
+#define GEMM_MFMA4(A0, A1, B0, B1)                                                   \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc[0][0], 0, 0, 0);      \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B1, acc[0][1], 0, 0, 0);      \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B0, acc[1][0], 0, 0, 0);      \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, acc[1][1], 0, 0, 0);
 
   const int a_off = (wm * 64 + l31) * GLD + 4 * hi;
   const int b_off = (wn * 64 + l31) * GLD + 4 * hi;
 
-  for (int kt = 0; kt < nk; ++kt) {
+  GEMM_LOAD_TILE(0)
+  GEMM_STORE_TILE(0)
+  __syncthreads();
+
+  // main loop: prefetch tile kt+1 into registers, 64 MFMAs on tile kt, park the prefetch in the other buffer
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {
     const int cur = kt & 1;
-    const bool more = (kt + 1) < nk;
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (size_t)(kt + 1) * GBK);
-        rw[i] = *reinterpret_cast<const float4*>(w_ptr[i] + (size_t)(kt + 1) * GBK);
-      }
-    }
-    const float* Ac = As + cur * (GBM * GLD);
-    const float* Bc = Bs + cur * (GBN * GLD);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 a0 = *reinterpret_cast<const float4*>(&Ac[a_off + 8 * g]);
-      const float4 a1 = *reinterpret_cast<const float4*>(&Ac[a_off + 32 * GLD + 8 * g]);
-      const float4 b0 = *reinterpret_cast<const float4*>(&Bc[b_off + 8 * g]);
-      const float4 b1 = *reinterpret_cast<const float4*>(&Bc[b_off + 32 * GLD + 8 * g]);
-      const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
-      const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
-      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
-      const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
-      }
-    }
-    if (more) {
-      float* An = As + (cur ^ 1) * (GBM * GLD);
-      float* Bn = Bs + (cur ^ 1) * (GBN * GLD);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<float4*>(&An[(srow + 32 * i) * GLD + sc4]) = ra[i];
-        *reinterpret_cast<float4*>(&Bn[(srow + 32 * i) * GLD + sc4]) = rw[i];
-      }
-    }
+    GEMM_LOAD_TILE(kt + 1)
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc otherwise sinks it to its use)
+    GEMM_COMPUTE_TILE(cur)
+    __builtin_amdgcn_sched_barrier(0);
+    GEMM_STORE_TILE(cur ^ 1)
     __syncthreads();
   }
+  GEMM_COMPUTE_TILE(kt & 1)
 
   // ---------------- epilogue ----------------
   const int mw = m0 + wm * 64;

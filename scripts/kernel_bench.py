@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark at the BASELINE configs[1] shapes (TP = 32 pairs x 2 x 4096 = 262144 tokens).
+
+Times every kernel class of the hot path through the C ABI with HIP events on the launch stream and prints
+achieved TFLOP/s (MFMA-bound kernels, vs the 157.3 TF fp32 matrix peak) or GB/s (HBM-bound kernels, vs 8 TB/s
+spec / 6.3 TB/s achievable) from the ALGORITHMIC bytes/flops stated in DESIGN.md.  Writes JSON lines.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rap_amd import _lib  # noqa: E402
+from rap_amd.flow_model import workspace  # noqa: E402
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--views", type=int, default=2)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    st = lambda: _lib.current_stream(dev)
+    TP = args.batch * args.views * args.points
+    d, H = 512, 8
+    g = torch.Generator(device=dev).manual_seed(0)
+    rows = []
+
+    def gemm_case(name, epi, N, K, ldc=None, heads=0):
+        A = torch.randn(TP, K, device=dev, generator=g)
+        W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+        bias = torch.randn(N, device=dev, generator=g)
+        Cw = (N // 2) if epi == 3 else N
+        C = torch.zeros(TP * Cw, device=dev)
+        resid = C.view(TP, Cw) if epi == 1 else None
+        def fn():
+            rc = lib.rap_gemm_f32(epi, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(C), ldc or Cw, TP, N, K, _lib.ptr(bias),
+                                  _lib.ptr(resid), Cw if epi == 1 else 0, _lib.ptr(None), _lib.ptr(None), heads, st())
+            assert rc == 0, rc
+        t = timeit(fn)
+        fl = 2.0 * TP * N * K
+        rows.append({"kernel": f"gemm_f32[{name}]", "M": TP, "N": N, "K": K, "ms": t * 1e3, "tflops": fl / t / 1e12,
+                     "frac_of_157.3TF": fl / t / 1e12 / 157.3})
+
+    gemm_case("qkv headmajor", 4, 3 * d, d, heads=H)
+    gemm_case("out_proj +bias +resid", 1, d, d)
+    gemm_case("ff1 GEGLU", 3, 8 * d, d)
+    gemm_case("ff2 +bias +resid", 1, d, 4 * d)
+    gemm_case("embed K=64 +resid", 1, d, 64)
+    gemm_case("head silu 512->256", 2, d // 2, d)
+
+    # attention
+    qkv = torch.randn(3, H, TP, 64, device=dev, generator=g)
+    qkv[:2] = torch.nn.functional.normalize(qkv[:2], dim=-1) * 8
+    out = torch.empty(TP, d, device=dev)
+    for name, L in (("per part", args.points), ("per sample", args.points * args.views)):
+        cu = torch.arange(0, TP + 1, L, dtype=torch.int32, device=dev)
+        nseg = cu.numel() - 1
+        ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, nseg))
+        def fn():
+            rc = lib.rap_attention_f32(_lib.ptr(qkv), _lib.ptr(cu), nseg, _lib.ptr(out), TP, H, _lib.ptr(ws), ws.numel(), st())
+            assert rc == 0, rc
+        t = timeit(fn, iters=3, warm=1)
+        fl = 4.0 * H * 64 * L * TP
+        rows.append({"kernel": f"attention_f32[{name} L={L}]", "ms": t * 1e3, "tflops": fl / t / 1e12,
+                     "frac_of_157.3TF": fl / t / 1e12 / 157.3})
+
+    # HBM-bound ring
+    def mem_case(name, fn, nbytes):
+        t = timeit(fn, iters=10, warm=2)
+        rows.append({"kernel": name, "ms": t * 1e3, "algorithmic_GB": nbytes / 1e9, "GBps": nbytes / t / 1e9,
+                     "frac_of_8TBps": nbytes / t / 8e12})
+
+    x = torch.randn(TP, d, device=dev, generator=g); y = torch.empty_like(x)
+    mod = torch.randn(2 * d, device=dev, generator=g)
+    mem_case("layernorm_mod (adaLN)", lambda: lib.rap_layernorm_mod(_lib.ptr(x), _lib.ptr(y), TP, d, _lib.ptr(mod), 0, _lib.ptr(None), st()),
+             TP * d * 4 * 2)
+    gq = torch.ones(H, 64, device=dev)
+    mem_case("qknorm (q,k in place)", lambda: lib.rap_qknorm(_lib.ptr(qkv), TP, H, _lib.ptr(gq), _lib.ptr(gq), st()), 2 * TP * d * 4 * 2)
+    x3 = torch.randn(TP, 3, device=dev, generator=g); ax = torch.empty(TP, 64, device=dev)
+    mem_case("posenc_x", lambda: lib.rap_posenc_x(_lib.ptr(x3), _lib.ptr(ax), TP, st()), TP * (12 + 256))
+    v3 = torch.randn(TP, 3, device=dev, generator=g); x0 = torch.empty_like(x3); xn = torch.empty_like(x3); tr = torch.empty_like(x3)
+    mem_case("euler_step", lambda: lib.rap_euler_step(_lib.ptr(x3), _lib.ptr(v3), 0.5, 0.05, _lib.ptr(x0), _lib.ptr(xn), _lib.ptr(tr), TP * 3, st()),
+             TP * 60)
+    ppp = torch.full((args.batch, args.views), args.points, dtype=torch.int64, device=dev)
+    R = torch.empty(args.batch, args.views, 3, 3, device=dev); tt = torch.empty(args.batch, args.views, 3, device=dev)
+    wsp = workspace(dev, lib.rap_procrustes_workspace_bytes(args.batch * args.views))
+    mem_case("procrustes fit (moments+solve)", lambda: lib.rap_fit_transformations(_lib.ptr(x3), _lib.ptr(v3), _lib.ptr(ppp), args.batch, args.views,
+                                                                                 _lib.ptr(R), _lib.ptr(tt), _lib.ptr(wsp), wsp.numel(), st()), TP * 24)
+    mem_case("rigidify+blend (fit + apply)", lambda: lib.rap_rigidify_blend(_lib.ptr(v3), _lib.ptr(x3), _lib.ptr(ppp), args.batch, args.views, _lib.ptr(x0),
+                                                                            0.6, 0.4, _lib.ptr(xn), _lib.ptr(wsp), wsp.numel(), st()), TP * (24 + 36))
+    y2 = torch.randn(TP, 256, device=dev, generator=g); W4 = torch.randn(3, 256, device=dev, generator=g); vo = torch.empty(TP, 3, device=dev)
+    for r in rows:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()

