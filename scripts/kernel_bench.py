@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--views", type=int, default=2)
+    ap.add_argument("--only", default="", help="'attention' or 'gemm': restrict to one kernel family (PMC passes)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -61,12 +62,17 @@ def main():
         rows.append({"kernel": f"gemm_f32[{name}]", "M": TP, "N": N, "K": K, "ms": t * 1e3, "tflops": fl / t / 1e12,
                      "frac_of_157.3TF": fl / t / 1e12 / 157.3})
 
-    gemm_case("qkv headmajor", 4, 3 * d, d, heads=H)
-    gemm_case("out_proj +bias +resid", 1, d, d)
-    gemm_case("ff1 GEGLU", 3, 8 * d, d)
-    gemm_case("ff2 +bias +resid", 1, d, 4 * d)
-    gemm_case("embed K=64 +resid", 1, d, 64)
-    gemm_case("head silu 512->256", 2, d // 2, d)
+    if args.only in ("", "gemm"):
+        gemm_case("qkv headmajor", 4, 3 * d, d, heads=H)
+        gemm_case("out_proj +bias +resid", 1, d, d)
+        gemm_case("ff1 GEGLU", 3, 8 * d, d)
+        gemm_case("ff2 +bias +resid", 1, d, 4 * d)
+        gemm_case("embed K=64 +resid", 1, d, 64)
+        gemm_case("head silu 512->256", 2, d // 2, d)
+    if args.only == "gemm":
+        for r in rows:
+            print(json.dumps(r))
+        return
 
     # attention
     qkv = torch.randn(3, H, TP, 64, device=dev, generator=g)
@@ -79,10 +85,15 @@ def main():
         def fn():
             rc = lib.rap_attention_f32(_lib.ptr(qkv), _lib.ptr(cu), nseg, _lib.ptr(out), TP, H, _lib.ptr(ws), ws.numel(), st())
             assert rc == 0, rc
-        t = timeit(fn, iters=3, warm=1)
+        t = timeit(fn, iters=3 if not args.only else 1, warm=1 if not args.only else 0)
         fl = 4.0 * H * 64 * L * TP
         rows.append({"kernel": f"attention_f32[{name} L={L}]", "ms": t * 1e3, "tflops": fl / t / 1e12,
                      "frac_of_157.3TF": fl / t / 1e12 / 157.3})
+
+    if args.only == "attention":
+        for r in rows:
+            print(json.dumps(r))
+        return
 
     # HBM-bound ring
     def mem_case(name, fn, nbytes):
