@@ -32,6 +32,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+CPU_BASELINE_THREADS = 16
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside this
+    process; the passes are separate runs of scripts/kernel_bench.py, summarised in profiles/)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            j = json.load(f)
+        return j["hbm_bytes_per_launch"], j["source"]
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def parse_args():
@@ -63,7 +76,9 @@ def cpu_baseline(cfg, sd, args, gpu_first_step):
     """Oracle on the host cores: 1 pair, the first of `flow_steps` flow steps; linear extrapolation."""
     from oracle import rap_oracle as O
     from rap_amd import synthetic as S
-    torch.set_num_threads(os.cpu_count() or 1)
+    # one process, 16 threads: the fastest setting on the 256-core GPU box (scripts/cpu_thread_sweep.py: 8/16/32/64/128/256
+    # threads -> 3.5/2.7/3.0/3.4/5.1/35 s); more threads only add synchronisation overhead at these matrix sizes.
+    torch.set_num_threads(min(CPU_BASELINE_THREADS, os.cpu_count() or 1))
     inp = S.make_uniform_inputs(1, args.views, args.points, seed=1234)   # == pair 0 of rank 0's batch
     t0 = time.perf_counter()
     ref = O.sample(sd, cfg, inp, args.flow_steps, bool(args.rigidity), max_steps=1)
@@ -172,7 +187,9 @@ def main():
             achieved = flops / secs / 1e12
             result["roofline"] = {
                 "kernel": "attention_f32_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": pmc_traffic()[0],
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": pmc_traffic()[1],
+                "algorithmic_bytes_per_launch": 4 * 4 * args.batch * args.views * args.points * 512,
                 "launches": n_launch, "avg_launch_ms": 1e3 * secs / n_launch,
                 "flops_per_launch_avg": flops / n_launch,
                 "per_part": {"launches": int(prof_n[0]), "avg_ms": prof_ms[0] / max(1, prof_n[0]),

@@ -53,5 +53,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + idx;
 }
 
+// Round a product to fp32 and keep it from being contracted into an FMA with a following add/sub
+// (hipcc's default -ffp-contract=fast fuses across statements, and HIP's __fmul_rn is a plain `*`).
+__device__ __forceinline__ float mul_rn_nofuse(float a, float b) {
+  float m = a * b;
+  asm volatile("" : "+v"(m));
+  return m;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -89,14 +89,16 @@ __global__ __launch_bounds__(256) void rigid_apply_kernel(const float* __restric
     const size_t p = (size_t)(a + i) * 3;
     const float s0 = src[p], s1 = src[p + 1], s2 = src[p + 2];
     // x R^T + t : matmul (fma chain over k) then the translation add, as `parts_source @ rot.t() + trans`
-    float y0 = __fadd_rn(fmaf(s2, r02, fmaf(s1, r01, __fmul_rn(s0, r00))), t0);
-    float y1 = __fadd_rn(fmaf(s2, r12, fmaf(s1, r11, __fmul_rn(s0, r10))), t1);
-    float y2 = __fadd_rn(fmaf(s2, r22, fmaf(s1, r21, __fmul_rn(s0, r20))), t2);
+    float y0 = fmaf(s2, r02, fmaf(s1, r01, s0 * r00));
+    float y1 = fmaf(s2, r12, fmaf(s1, r11, s0 * r10));
+    float y2 = fmaf(s2, r22, fmaf(s1, r21, s0 * r20));
+    asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2));   // the matmul result is rounded before the translation add
+    y0 += t0; y1 += t1; y2 += t2;
     if (blend) {
       // x_t = x0_rigid * (1 - t + dt) + x_1 * (t - dt)   (sampler.py:60), separate roundings
-      y0 = __fadd_rn(__fmul_rn(y0, w0), __fmul_rn(x1[p], w1));
-      y1 = __fadd_rn(__fmul_rn(y1, w0), __fmul_rn(x1[p + 1], w1));
-      y2 = __fadd_rn(__fmul_rn(y2, w0), __fmul_rn(x1[p + 2], w1));
+      y0 = mul_rn_nofuse(y0, w0) + mul_rn_nofuse(x1[p], w1);
+      y1 = mul_rn_nofuse(y1, w0) + mul_rn_nofuse(x1[p + 1], w1);
+      y2 = mul_rn_nofuse(y2, w0) + mul_rn_nofuse(x1[p + 2], w1);
     }
     out[p] = y0; out[p + 1] = y1; out[p + 2] = y2;
     if (traj) { traj[p] = y0; traj[p + 1] = y1; traj[p + 2] = y2; }

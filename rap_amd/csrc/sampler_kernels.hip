@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void euler_step_kernel(const float* __restrict
   const long stride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const float x = x_t[i], vv = v[i];
-    const float x0 = __fsub_rn(x, __fmul_rn(vv, t));
-    const float xn = __fsub_rn(x, __fmul_rn(dt, vv));
+    const float x0 = x - mul_rn_nofuse(vv, t);
+    const float xn = x - mul_rn_nofuse(dt, vv);
     x0hat[i] = x0;
     x_next[i] = xn;
     if (traj_xt) traj_xt[i] = xn;
