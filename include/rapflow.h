@@ -132,6 +132,10 @@ int rap_adaln_table(const rap_model* m, const float* t, int32_t rows, float* scr
  * (0 attention per part, 1 attention per sample, 2 layer GEMMs), the summed milliseconds and the launch count
  * into HOST arrays of 3 entries.  Not thread-safe; off by default. */
 int rap_profile_enable(int on);
+/* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py): key 0 = GEMM {0: 128x128 v1, 2: pipelined
+ * 128x128, 4: pipelined 128x256 (default)}, key 1 = attention {1: v1 two query tiles per wave, 3: pipelined (default)}.
+ * All variants compute the same function. */
+int rap_set_tuning(int32_t key, int32_t value);
 int rap_profile_reset(void);
 int rap_profile_collect(float* h_ms_out, int64_t* h_count_out);
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "rap_posenc_static": (c_int32, [_P, _P, _P, _P, c_int32, _P, c_int64, _P]),
     "rap_token_sample": (c_int32, [_P, c_int32, _P, _P]),
     "rap_adaln_table": (c_int32, [_P, _P, c_int32, _P, _P, _P]),
+    "rap_set_tuning": (c_int32, [c_int32, c_int32]),
     "rap_profile_enable": (c_int32, [c_int32]),
     "rap_profile_reset": (c_int32, []),
     "rap_profile_collect": (c_int32, [_P, _P]),

@@ -182,22 +182,229 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined variant (the default).  Same tiling idea, but
+//  * the MFMA operands of k-group g+1 are read from LDS into a second register set while the 16*WNT/2
+//    MFMAs of group g issue (fragment double-buffering), and the first group of tile t+1 is read right
+//    after the barrier while the LAST group of tile t still runs -> no exposed ds_read latency after a barrier;
+//  * the prefetched tile t+1 is parked in the spare LDS buffer in the middle of tile t's MFMAs
+//    (it has had 32*WNT/2 MFMAs = 2-4k cycles to arrive), not in a serial block before the barrier;
+//  * WNT = 4: 128x256 block tile, each wave 64x128 (8 accumulator tiles = 128 registers), one block per CU
+//    (110 KB LDS): 1.33x fewer L2->LDS bytes per flop than 128x128 and 128 MFMAs between barriers.
+//    WNT = 2 keeps the 128x128 tile at two blocks per CU.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int WNT>
+__global__ __launch_bounds__(256, (WNT == 2 ? 2 : 1)) void gemm_f32_pipe_kernel(GemmParams p) {
+  constexpr int BN = 64 * WNT;        // block tile along N (two waves)
+  constexpr int NW4 = BN / 32;        // float4 of W staged per thread per k-tile
+  __shared__ __attribute__((aligned(16))) float smem[2 * (GBM + BN) * GLD];
+  float* As = smem;                      // [2][128][36]
+  float* Bs = smem + 2 * GBM * GLD;      // [2][BN][36]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nt = p.N / BN;
+  const int mt = (p.M + GBM - 1) / GBM;
+  const int logical = xcd_remap(blockIdx.x, mt * nt);
+  const int m0 = (logical / nt) * GBM;
+  const int n0 = (logical % nt) * BN;
+
+  const int srow = tid >> 3;
+  const int sc4 = (tid & 7) * 4;
+  const float* a_ptr[4];
+  const float* w_ptr[NW4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = m0 + srow + 32 * i;
+    r = r < p.M ? r : p.M - 1;
+    a_ptr[i] = p.A + (size_t)r * p.lda + sc4;
+  }
+#pragma unroll
+  for (int i = 0; i < NW4; ++i) w_ptr[i] = p.W + (size_t)(n0 + srow + 32 * i) * p.ldw + sc4;
+
+  f32x16 acc[2][WNT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Staging and fragment registers are named struct members (never arrays: hipcc promotes private arrays
+  // that survive until late unrolling to LDS or scratch).
+  float4 sg_a0, sg_a1, sg_a2, sg_a3, sg_w0, sg_w1, sg_w2, sg_w3, sg_w4, sg_w5, sg_w6, sg_w7;
+  struct Frag { float4 a0, a1, b0, b1, b2, b3; } f0, f1;
+  const int nk = p.K / GBK;
+  const int st_off = srow * GLD + sc4;
+  const int a_off = (wm * 64 + l31) * GLD + 4 * hi;
+  const int b_off = (wn * (32 * WNT) + l31) * GLD + 4 * hi;
+
+#define PG_LD(PTR, KT) (*reinterpret_cast<const float4*>((PTR) + (size_t)(KT) * GBK))
+#define PG_LOAD(KT)                                                                    \
+  sg_a0 = PG_LD(a_ptr[0], KT); sg_a1 = PG_LD(a_ptr[1], KT);                            \
+  sg_a2 = PG_LD(a_ptr[2], KT); sg_a3 = PG_LD(a_ptr[3], KT);                            \
+  sg_w0 = PG_LD(w_ptr[0], KT); sg_w1 = PG_LD(w_ptr[1], KT);                            \
+  sg_w2 = PG_LD(w_ptr[2], KT); sg_w3 = PG_LD(w_ptr[3], KT);                            \
+  if constexpr (WNT == 4) {                                                            \
+    sg_w4 = PG_LD(w_ptr[4], KT); sg_w5 = PG_LD(w_ptr[5], KT);                          \
+    sg_w6 = PG_LD(w_ptr[6], KT); sg_w7 = PG_LD(w_ptr[7], KT);                          \
+  }
+#define PG_ST(BASE, I, V) *reinterpret_cast<float4*>(&(BASE)[st_off + (I) * 32 * GLD]) = (V)
+#define PG_STORE(BUF)                                                                  \
+  {                                                                                    \
+    float* A_ = As + (BUF) * (GBM * GLD);                                              \
+    float* B_ = Bs + (BUF) * (BN * GLD);                                               \
+    PG_ST(A_, 0, sg_a0); PG_ST(A_, 1, sg_a1); PG_ST(A_, 2, sg_a2); PG_ST(A_, 3, sg_a3); \
+    PG_ST(B_, 0, sg_w0); PG_ST(B_, 1, sg_w1); PG_ST(B_, 2, sg_w2); PG_ST(B_, 3, sg_w3); \
+    if constexpr (WNT == 4) {                                                          \
+      PG_ST(B_, 4, sg_w4); PG_ST(B_, 5, sg_w5); PG_ST(B_, 6, sg_w6); PG_ST(B_, 7, sg_w7); \
+    }                                                                                  \
+  }
+#define PG_RD(BASE, OFF, I, G) (*reinterpret_cast<const float4*>(&(BASE)[(OFF) + (I) * 32 * GLD + 8 * (G)]))
+#define PG_READ(BUF, G, F)                                                             \
+  {                                                                                    \
+    const float* A_ = As + (BUF) * (GBM * GLD);                                        \
+    const float* B_ = Bs + (BUF) * (BN * GLD);                                         \
+    F.a0 = PG_RD(A_, a_off, 0, G); F.a1 = PG_RD(A_, a_off, 1, G);                      \
+    F.b0 = PG_RD(B_, b_off, 0, G); F.b1 = PG_RD(B_, b_off, 1, G);                      \
+    if constexpr (WNT == 4) { F.b2 = PG_RD(B_, b_off, 2, G); F.b3 = PG_RD(B_, b_off, 3, G); } \
+  }
+#define PG_MM(I, J, AV, BV) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV, acc[I][J], 0, 0, 0);
+#define PG_MFMA_STEP(F, C)                                                             \
+  PG_MM(0, 0, F.a0.C, F.b0.C) PG_MM(0, 1, F.a0.C, F.b1.C)                              \
+  if constexpr (WNT == 4) { PG_MM(0, 2, F.a0.C, F.b2.C) PG_MM(0, 3, F.a0.C, F.b3.C) }  \
+  PG_MM(1, 0, F.a1.C, F.b0.C) PG_MM(1, 1, F.a1.C, F.b1.C)                              \
+  if constexpr (WNT == 4) { PG_MM(1, 2, F.a1.C, F.b2.C) PG_MM(1, 3, F.a1.C, F.b3.C) }
+#define PG_MFMA(F) PG_MFMA_STEP(F, x) PG_MFMA_STEP(F, y) PG_MFMA_STEP(F, z) PG_MFMA_STEP(F, w)
+
+  PG_LOAD(0)
+  PG_STORE(0)
+  __syncthreads();
+  PG_READ(0, 0, f0)
+
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {
+    const int cur = kt & 1;
+    PG_LOAD(kt + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    PG_READ(cur, 1, f1)
+    PG_MFMA(f0)                             // group 0
+    __builtin_amdgcn_sched_barrier(0);
+    PG_READ(cur, 2, f0)
+    PG_MFMA(f1)                             // group 1
+    __builtin_amdgcn_sched_barrier(0);
+    PG_STORE(cur ^ 1)                       // tile kt+1 -> spare buffer (last read two barriers ago)
+    PG_READ(cur, 3, f1)
+    PG_MFMA(f0)                             // group 2
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                        // tile kt+1 visible; every wave has issued all its reads of tile kt
+    PG_READ(cur ^ 1, 0, f0)
+    PG_MFMA(f1)                             // group 3 of tile kt covers the first reads of tile kt+1
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    const int cur = kt & 1;
+    PG_READ(cur, 1, f1)
+    PG_MFMA(f0)
+    PG_READ(cur, 2, f0)
+    PG_MFMA(f1)
+    PG_READ(cur, 3, f1)
+    PG_MFMA(f0)
+    PG_MFMA(f1)
+  }
+
+  // ---------------- epilogue ----------------
+  const int mw = m0 + wm * 64;
+  const int nw = n0 + wn * (32 * WNT);
+  if (EPI == EPI_GEGLU) {
+#pragma unroll
+    for (int jp = 0; jp < WNT / 2; ++jp) {
+      const int nout = ((nw + 64 * jp) >> 1) + l31;
+      const float bh = p.bias ? p.bias[nw + 64 * jp + l31] : 0.f;
+      const float bg = p.bias ? p.bias[nw + 64 * jp + 32 + l31] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + mi * 32 + mfma32_crow(r, hi);
+          if (m < p.M) {
+            const float h = acc[mi][2 * jp][r] + bh;
+            const float g = acc[mi][2 * jp + 1][r] + bg;
+            const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+            p.C[(size_t)m * p.ldc + nout] = h * ge;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < WNT; ++ni) {
+      const int n = nw + ni * 32 + l31;
+      const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + mi * 32 + mfma32_crow(r, hi);
+        if (m >= p.M) continue;
+        float v = acc[mi][ni][r] + bn;
+        if (EPI == EPI_BIAS) {
+          p.C[(size_t)m * p.ldc + n] = v;
+        } else if (EPI == EPI_BIAS_RESID) {
+          p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
+        } else if (EPI == EPI_BIAS_SILU) {
+          p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
+        } else if (EPI == EPI_BIAS_ANCHOR) {
+          const int sel = p.anchor[m] ? 1 : 0;
+          p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
+        } else if (EPI == EPI_QKV_HEADMAJOR) {
+          const int dmodel = p.heads * 64;
+          const int c = n / dmodel;
+          const int rem = n - c * dmodel;
+          const int h = rem >> 6, j = rem & 63;
+          p.C[(((size_t)c * p.heads + h) * p.M + m) * 64 + j] = v;
+        }
+      }
+    }
+  }
+}
+
+// tuning knob (rap_set_tuning): 0 = v1 128x128, 2 = pipelined 128x128, 4 = pipelined 128x256 (N % 256 == 0, else falls back to 2)
+int g_rap_gemm_variant = 4;
+
+template <int EPI>
+static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int variant) {
+  const int mt = (p.M + GBM - 1) / GBM;
+  if (variant == 4 && p.N % 256 == 0) {
+    hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 4>), dim3(mt * (p.N / 256)), dim3(256), 0, stream, p);
+  } else if (variant == 0) {
+    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 2>), dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
+  }
+}
+
 int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p) {
   if (p.M <= 0) return RAP_OK;
   if (p.N % GBN != 0 || p.K % GBK != 0 || p.K <= 0) return RAP_ERR_INVALID;
   if ((p.lda & 3) || (p.ldw & 3)) return RAP_ERR_INVALID;
-  const int mt = (p.M + GBM - 1) / GBM, nt = p.N / GBN;
-  dim3 grid(mt * nt), block(256);
+  const int v = g_rap_gemm_variant;
   switch (epilogue) {
-    case EPI_BIAS: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS>, grid, block, 0, stream, p); break;
-    case EPI_BIAS_RESID: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS_RESID>, grid, block, 0, stream, p); break;
-    case EPI_BIAS_SILU: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS_SILU>, grid, block, 0, stream, p); break;
-    case EPI_GEGLU: hipLaunchKernelGGL(gemm_f32_kernel<EPI_GEGLU>, grid, block, 0, stream, p); break;
+    case EPI_BIAS: launch_gemm_variant<EPI_BIAS>(stream, p, v); break;
+    case EPI_BIAS_RESID: launch_gemm_variant<EPI_BIAS_RESID>(stream, p, v); break;
+    case EPI_BIAS_SILU: launch_gemm_variant<EPI_BIAS_SILU>(stream, p, v); break;
+    case EPI_GEGLU: launch_gemm_variant<EPI_GEGLU>(stream, p, v); break;
     case EPI_QKV_HEADMAJOR:
       if (p.N != 3 * p.heads * 64) return RAP_ERR_INVALID;
-      hipLaunchKernelGGL(gemm_f32_kernel<EPI_QKV_HEADMAJOR>, grid, block, 0, stream, p);
+      launch_gemm_variant<EPI_QKV_HEADMAJOR>(stream, p, v);
       break;
-    case EPI_BIAS_ANCHOR: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS_ANCHOR>, grid, block, 0, stream, p); break;
+    case EPI_BIAS_ANCHOR: launch_gemm_variant<EPI_BIAS_ANCHOR>(stream, p, v); break;
     default: return RAP_ERR_INVALID;
   }
   RAP_LAUNCH_CHECK();

@@ -37,9 +37,15 @@ def main():
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--only", default="", help="'attention' or 'gemm': restrict to one kernel family (PMC passes)")
+    ap.add_argument("--gemm-variant", type=int, default=-1)
+    ap.add_argument("--attn-variant", type=int, default=-1)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
+    if args.gemm_variant >= 0:
+        assert lib.rap_set_tuning(0, args.gemm_variant) == 0
+    if args.attn_variant >= 0:
+        assert lib.rap_set_tuning(1, args.attn_variant) == 0
     st = lambda: _lib.current_stream(dev)
     TP = args.batch * args.views * args.points
     d, H = 512, 8
@@ -59,7 +65,7 @@ def main():
             assert rc == 0, rc
         t = timeit(fn)
         fl = 2.0 * TP * N * K
-        rows.append({"kernel": f"gemm_f32[{name}]", "M": TP, "N": N, "K": K, "ms": t * 1e3, "tflops": fl / t / 1e12,
+        rows.append({"kernel": f"gemm_f32[{name}]", "variant": args.gemm_variant, "M": TP, "N": N, "K": K, "ms": t * 1e3, "tflops": fl / t / 1e12,
                      "frac_of_157.3TF": fl / t / 1e12 / 157.3})
 
     if args.only in ("", "gemm"):
@@ -87,7 +93,7 @@ def main():
             assert rc == 0, rc
         t = timeit(fn, iters=3 if not args.only else 1, warm=1 if not args.only else 0)
         fl = 4.0 * H * 64 * L * TP
-        rows.append({"kernel": f"attention_f32[{name} L={L}]", "ms": t * 1e3, "tflops": fl / t / 1e12,
+        rows.append({"kernel": f"attention_f32[{name} L={L}]", "variant": args.attn_variant, "ms": t * 1e3, "tflops": fl / t / 1e12,
                      "frac_of_157.3TF": fl / t / 1e12 / 157.3})
 
     if args.only == "attention":
