@@ -289,17 +289,20 @@ __device__ __forceinline__ void qk_subtile(const float* __restrict__ Kc, int sub
                                            f32x16& o0, f32x16& o1) {
   const float* kp = Kc + (sub * 32 + l31) * KLD + 4 * hi;
   SmState st;
+  f32x16 s2;     // second accumulation chain: a dependent MFMA never waits on its predecessor
 #pragma unroll
-  for (int r = 0; r < 16; ++r) sn[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { sn[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * g);
     sn = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[g * 4 + 0], sn, 0, 0, 0);
-    sn = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[g * 4 + 1], sn, 0, 0, 0);
+    s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[g * 4 + 1], s2, 0, 0, 0);
     if (WITH_SM) softmax_slice8(g, sp, mrun, lsum, o0, o1, st);
     sn = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[g * 4 + 2], sn, 0, 0, 0);
-    sn = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[g * 4 + 3], sn, 0, 0, 0);
+    s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[g * 4 + 3], s2, 0, 0, 0);
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sn[r] += s2[r];
   if (MASKED) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sn[r] = (mfma32_crow(r, hi) < nvalid) ? sn[r] : -1e30f;
@@ -476,7 +479,7 @@ int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, in
   return RAP_OK;
 }
 
-int g_rap_attn_variant = 3;
+int g_rap_attn_variant = 1;
 
 int launch_attention_f32(hipStream_t stream, const float* qkv, float* out, int TP, int heads, const AttnWorkItem* items,
                          int max_items) {

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, (WNT == 2 ? 2 : 1)) void gemm_f32_pipe_kernel(
 }
 
 // tuning knob (rap_set_tuning): 0 = v1 128x128, 2 = pipelined 128x128, 4 = pipelined 128x256 (N % 256 == 0, else falls back to 2)
-int g_rap_gemm_variant = 4;
+int g_rap_gemm_variant = 2;
 
 template <int EPI>
 static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int variant) {

@@ -387,3 +387,32 @@ def test_procrustes_empty_part_in_the_middle(dev):
     Rb, tb = O.solve_procrustes(src[50:].double(), tgt[50:].double())
     assert (R.cpu()[0, 0].double() - Ra).abs().max().item() < 2e-6 and (R.cpu()[0, 2].double() - Rb).abs().max().item() < 2e-6
     assert (t.cpu()[0, 2].double() - tb).abs().max().item() < 2e-6 and torch.equal(R.cpu()[0, 1], torch.zeros(3, 3))
+
+
+def test_attention_large_scan_geometry_one_head(lib, dev):
+    """BASELINE configs[4] geometry: 2 x 32768 points -> per-part L = 32768, per-sample L = 65536 (the longest
+    segments the path is specified for).  One head, checked in full against a chunked fp64 softmax on the GPU."""
+    T, H = 65536, 1
+    g = torch.Generator(device=dev).manual_seed(4)
+    q = F.normalize(torch.randn(T, 64, device=dev, generator=g), dim=-1) * 8
+    k = F.normalize(torch.randn(T, 64, device=dev, generator=g), dim=-1) * 8
+    v = torch.randn(T, 64, device=dev, generator=g)
+    hm = torch.stack([q, k, v]).unsqueeze(1).contiguous()          # [3][1][T][64]
+    for cu_list in ([0, 65536], [0, 32768, 65536]):
+        cu = torch.tensor(cu_list, dtype=torch.int32, device=dev)
+        nseg = len(cu_list) - 1
+        ws = workspace(dev, lib.rap_attention_workspace_bytes(T, nseg))
+        out = torch.empty((T, 64), device=dev)
+        _lib.check(lib.rap_attention_f32(_lib.ptr(hm), _lib.ptr(cu), nseg, _lib.ptr(out), T, H, _lib.ptr(ws), ws.numel(),
+                                         stream(dev)), "attn")
+        torch.cuda.synchronize()
+        worst = 0.0
+        for s in range(nseg):
+            a, b = cu_list[s], cu_list[s + 1]
+            kd, vd = k[a:b].double(), v[a:b].double()
+            for r0 in range(a, b, 4096):
+                sc = (q[r0:r0 + 4096].double() @ kd.T) * 0.125
+                ref = torch.softmax(sc, dim=-1) @ vd
+                worst = max(worst, (out[r0:r0 + 4096].double() - ref).abs().max().item())
+        print(f"large-scan attention {cu_list}: max abs err vs fp64 {worst:.2e}")
+        assert worst < 5e-6, worst

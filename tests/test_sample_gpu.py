@@ -149,3 +149,20 @@ def test_full_size_pair_properties(dev):
     for p in range(2):
         seg = slice(p * 4096, (p + 1) * 4096)
         assert (rig[seg] - (cond[seg] @ R[p].T + t[p])).abs().max().item() < 1e-5
+
+
+def test_multiview_rigidity_matches_oracle(dev):
+    """BASELINE configs[3] shape class (8 views per sample, per-step Procrustes rigidity), scaled so the CPU oracle
+    finishes in seconds: 2 samples x 8 views x {256..512} points, ragged."""
+    cfg, sd, model = get_model(2, 9, dev)
+    parts = [[512, 400, 300, 256, 512, 333, 280, 512], [256, 256, 300, 512, 444, 270, 380, 290]]
+    inp = S.make_inputs(parts, seed=55)
+    steps = 4
+    ref = O.sample(sd, cfg, inp, steps, True)
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=steps, rigidity_forcing=True)
+    out = flow.sample_and_register(to_dev(inp, dev), x_1=inp["x_1"].to(dev))
+    for k in ("end_point_trajectory", "trajectory", "R", "t"):
+        err = (out[k].cpu() - ref[k]).abs().max().item()
+        assert err < 5e-5, (k, err)
+    deg = O.rotation_error_deg(out["R"].cpu(), ref["R"]).max().item()
+    print(f"multiview: rot err {deg:.4f} deg, |dR| {(out['R'].cpu() - ref['R']).abs().max().item():.2e}")
