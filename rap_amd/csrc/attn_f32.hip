@@ -32,8 +32,14 @@
 #define KLD 68  // K LDS row stride (floats): 272 B = 17 slots -> conflict-free ds_read_b128
 #define VLD 64
 
-__global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                               int TP, int heads, const AttnWorkItem* __restrict__ items) {
+// NW = waves per block (4: 256 queries, two blocks per CU; 8: 512 queries, one block per CU).  With NW = 8 the
+// two waves that share a SIMD (w and w+4) belong to the SAME block and get different static priorities: with equal
+// priority two identical waves share the matrix pipe fairly, stay in lock-step and hit their softmax (VALU) phases
+// together, leaving the pipe idle; with a priority split the favoured wave runs its MFMA phases at full rate and
+// the other one fills its gaps (MI355X_MICROARCH.md "Two waves per SIMD", item 4).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                  int TP, int heads, const AttnWorkItem* __restrict__ items) {
   __shared__ __attribute__((aligned(16))) float smem[2 * AKV * KLD + 2 * AKV * VLD];
   float* Ks = smem;                    // [2][64][68]
   float* Vs = smem + 2 * AKV * KLD;    // [2][64][64]
@@ -53,6 +59,9 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
 
   const int qw0 = it.q0 + wave * AQ_WAVE;
   const bool wave_active = qw0 < len;   // waves beyond the segment still help stage K/V
+  if (NW == 8) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+  }
 
   // ---- Q fragments: qf[qt][g*4+j] = Q[q][8g + 4hi + j] * (log2(e)/8)
   const float qscale = 0.125f * 1.44269504088896340736f;
@@ -83,7 +92,8 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
   float lsum[2] = {0.f, 0.f};
 
   // ---- K/V staging coordinates: 4 float4 of K and 4 of V per thread per tile
-  const int srow = tid >> 4;          // 0..15 (+16*i)
+  constexpr int RS = 4 * NW;          // rows staged per pass (16 threads per 64-float row)
+  const int srow = tid >> 4;          // 0..RS-1 (+RS*i)
   const int sc4 = (tid & 15) * 4;
   float4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
   const int nkv = (len + AKV - 1) / AKV;
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
 
 #define ATTN_LOAD_ONE(T, I, RK, RV)                                          \
   {                                                                          \
-    int key_ = (T) * AKV + srow + 16 * (I);                                  \
+    int key_ = (T) * AKV + srow + RS * (I);                                  \
     key_ = key_ < len ? key_ : len - 1;                                      \
     RK = *reinterpret_cast<const float4*>(Kg + (size_t)key_ * 64 + sc4);     \
     RV = *reinterpret_cast<const float4*>(Vg + (size_t)key_ * 64 + sc4);     \
@@ -100,16 +110,20 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const float* __re
 #define ATTN_LOAD_TILE(T)          \
   ATTN_LOAD_ONE(T, 0, rk0, rv0)    \
   ATTN_LOAD_ONE(T, 1, rk1, rv1)    \
-  ATTN_LOAD_ONE(T, 2, rk2, rv2)    \
-  ATTN_LOAD_ONE(T, 3, rk3, rv3)
+  if constexpr (NW == 4) {         \
+    ATTN_LOAD_ONE(T, 2, rk2, rv2)  \
+    ATTN_LOAD_ONE(T, 3, rk3, rv3)  \
+  }
 #define ATTN_STORE_ONE(BUF, I, RK, RV)                                                            \
-  *reinterpret_cast<float4*>(&Ks[(BUF) * (AKV * KLD) + koff + 16 * (I) * KLD]) = RK;              \
-  *reinterpret_cast<float4*>(&Vs[(BUF) * (AKV * VLD) + voff + 16 * (I) * VLD]) = RV;
-#define ATTN_STORE_TILE(BUF)         \
-  ATTN_STORE_ONE(BUF, 0, rk0, rv0)   \
-  ATTN_STORE_ONE(BUF, 1, rk1, rv1)   \
-  ATTN_STORE_ONE(BUF, 2, rk2, rv2)   \
-  ATTN_STORE_ONE(BUF, 3, rk3, rv3)
+  *reinterpret_cast<float4*>(&Ks[(BUF) * (AKV * KLD) + koff + RS * (I) * KLD]) = RK;              \
+  *reinterpret_cast<float4*>(&Vs[(BUF) * (AKV * VLD) + voff + RS * (I) * VLD]) = RV;
+#define ATTN_STORE_TILE(BUF)           \
+  ATTN_STORE_ONE(BUF, 0, rk0, rv0)     \
+  ATTN_STORE_ONE(BUF, 1, rk1, rv1)     \
+  if constexpr (NW == 4) {             \
+    ATTN_STORE_ONE(BUF, 2, rk2, rv2)   \
+    ATTN_STORE_ONE(BUF, 3, rk3, rv3)   \
+  }
 
   ATTN_LOAD_TILE(0)
   ATTN_STORE_TILE(0)
@@ -343,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void attention_f32_v3_kernel(const float* _
 
   const int qw0 = it.q0 + wave * 32;
   const bool wave_active = qw0 < len;     // waves beyond the segment still help stage K/V and hit the barriers
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);   // static priority split per SIMD pair
 
   const float qscale = 0.125f * 1.44269504088896340736f;
   float qf[32];
@@ -458,12 +473,12 @@ __global__ __launch_bounds__(512, 2) void attention_f32_v3_kernel(const float* _
 // One thread walks the segment table (nseg is small: samples or parts of one batch) and emits one
 // work item per 256-query block; unused slots get seg_len = 0.  Runs once per sample() call.
 __global__ void build_attn_worklist_kernel(const int32_t* __restrict__ cu, int nseg, AttnWorkItem* __restrict__ items,
-                                           int max_items) {
+                                           int max_items, int bq) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   int n = 0;
   for (int s = 0; s < nseg; ++s) {
     const int a = cu[s], b = cu[s + 1];
-    for (int q0 = 0; q0 < b - a && n < max_items; q0 += RAP_ATTN_BQ) {
+    for (int q0 = 0; q0 < b - a && n < max_items; q0 += bq) {
       AttnWorkItem w; w.seg_start = a; w.seg_len = b - a; w.q0 = q0; w.pad = 0;
       items[n++] = w;
     }
@@ -471,22 +486,28 @@ __global__ void build_attn_worklist_kernel(const int32_t* __restrict__ cu, int n
   for (; n < max_items; ++n) { AttnWorkItem w; w.seg_start = 0; w.seg_len = 0; w.q0 = 0; w.pad = 0; items[n] = w; }
 }
 
+// tuning knob (rap_set_tuning key 1): 1 = v1 with 4 waves (256 queries per block), 5 = v1 with 8 waves + static priority
+// split (512 queries per block, the default), 3 = v3 (one query tile per wave, cross-sub-tile pipelining).
+int g_rap_attn_variant = 5;
+static int attn_block_queries() { return g_rap_attn_variant == 5 ? 512 : RAP_ATTN_BQ; }
+
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,
                                int max_items) {
   if (max_items <= 0) return RAP_OK;
-  hipLaunchKernelGGL(build_attn_worklist_kernel, dim3(1), dim3(64), 0, stream, cu_seqlens, nseg, items, max_items);
+  hipLaunchKernelGGL(build_attn_worklist_kernel, dim3(1), dim3(64), 0, stream, cu_seqlens, nseg, items, max_items,
+                     attn_block_queries());
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }
-
-int g_rap_attn_variant = 1;
 
 int launch_attention_f32(hipStream_t stream, const float* qkv, float* out, int TP, int heads, const AttnWorkItem* items,
                          int max_items) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0) return RAP_ERR_INVALID;
   if (g_rap_attn_variant == 1)
-    hipLaunchKernelGGL(attention_f32_kernel, dim3(max_items * heads), dim3(256), 0, stream, qkv, out, TP, heads, items);
+    hipLaunchKernelGGL(attention_f32_kernel<4>, dim3(max_items * heads), dim3(256), 0, stream, qkv, out, TP, heads, items);
+  else if (g_rap_attn_variant == 5)
+    hipLaunchKernelGGL(attention_f32_kernel<8>, dim3(max_items * heads), dim3(512), 0, stream, qkv, out, TP, heads, items);
   else
     hipLaunchKernelGGL(attention_f32_v3_kernel, dim3(max_items * heads), dim3(512), 0, stream, qkv, out, TP, heads, items);
   RAP_LAUNCH_CHECK();

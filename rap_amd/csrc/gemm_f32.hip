@@ -193,13 +193,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
 //    (110 KB LDS): 1.33x fewer L2->LDS bytes per flop than 128x128 and 128 MFMAs between barriers.
 //    WNT = 2 keeps the 128x128 tile at two blocks per CU.
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int WNT>
-__global__ __launch_bounds__(256, (WNT == 2 ? 2 : 1)) void gemm_f32_pipe_kernel(GemmParams p) {
+//  * WMW = 4: 8 waves (4 along M x 2 along N), 256x128 block tile, one block per CU; the two waves that share a
+//    SIMD (w, w+4) get different static priorities so they do not run in lock-step (see attn_f32.hip).
+template <int EPI, int WNT, int WMW>
+__global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 2 : (WNT == 2 ? 2 : 1))) void gemm_f32_pipe_kernel(GemmParams p) {
+  constexpr int BM = 64 * WMW;        // block tile along M
   constexpr int BN = 64 * WNT;        // block tile along N (two waves)
-  constexpr int NW4 = BN / 32;        // float4 of W staged per thread per k-tile
-  __shared__ __attribute__((aligned(16))) float smem[2 * (GBM + BN) * GLD];
-  float* As = smem;                      // [2][128][36]
-  float* Bs = smem + 2 * GBM * GLD;      // [2][BN][36]
+  constexpr int RP = 16 * WMW;        // rows staged per pass (8 threads per 32-float row)
+  constexpr int NW4 = BN / RP;        // float4 of W staged per thread per k-tile (A: always 4)
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * GLD];
+  float* As = smem;                      // [2][BM][36]
+  float* Bs = smem + 2 * BM * GLD;       // [2][BN][36]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -207,11 +211,14 @@ __global__ __launch_bounds__(256, (WNT == 2 ? 2 : 1)) void gemm_f32_pipe_kernel(
   const int hi = lane >> 5;
   const int l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
+  if (WMW == 4) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+  }
 
   const int nt = p.N / BN;
-  const int mt = (p.M + GBM - 1) / GBM;
+  const int mt = (p.M + BM - 1) / BM;
   const int logical = xcd_remap(blockIdx.x, mt * nt);
-  const int m0 = (logical / nt) * GBM;
+  const int m0 = (logical / nt) * BM;
   const int n0 = (logical % nt) * BN;
 
   const int srow = tid >> 3;
@@ -220,12 +227,12 @@ __global__ __launch_bounds__(256, (WNT == 2 ? 2 : 1)) void gemm_f32_pipe_kernel(
   const float* w_ptr[NW4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int r = m0 + srow + 32 * i;
+    int r = m0 + srow + RP * i;
     r = r < p.M ? r : p.M - 1;
     a_ptr[i] = p.A + (size_t)r * p.lda + sc4;
   }
 #pragma unroll
-  for (int i = 0; i < NW4; ++i) w_ptr[i] = p.W + (size_t)(n0 + srow + 32 * i) * p.ldw + sc4;
+  for (int i = 0; i < NW4; ++i) w_ptr[i] = p.W + (size_t)(n0 + srow + RP * i) * p.ldw + sc4;
 
   f32x16 acc[2][WNT];
 #pragma unroll
@@ -249,26 +256,27 @@ __global__ __launch_bounds__(256, (WNT == 2 ? 2 : 1)) void gemm_f32_pipe_kernel(
   sg_a0 = PG_LD(a_ptr[0], KT); sg_a1 = PG_LD(a_ptr[1], KT);                            \
   sg_a2 = PG_LD(a_ptr[2], KT); sg_a3 = PG_LD(a_ptr[3], KT);                            \
   sg_w0 = PG_LD(w_ptr[0], KT); sg_w1 = PG_LD(w_ptr[1], KT);                            \
-  sg_w2 = PG_LD(w_ptr[2], KT); sg_w3 = PG_LD(w_ptr[3], KT);                            \
-  if constexpr (WNT == 4) {                                                            \
+  if constexpr (NW4 >= 4) { sg_w2 = PG_LD(w_ptr[2], KT); sg_w3 = PG_LD(w_ptr[3], KT); } \
+  if constexpr (NW4 == 8) {                                                            \
     sg_w4 = PG_LD(w_ptr[4], KT); sg_w5 = PG_LD(w_ptr[5], KT);                          \
     sg_w6 = PG_LD(w_ptr[6], KT); sg_w7 = PG_LD(w_ptr[7], KT);                          \
   }
-#define PG_ST(BASE, I, V) *reinterpret_cast<float4*>(&(BASE)[st_off + (I) * 32 * GLD]) = (V)
+#define PG_ST(BASE, I, V) *reinterpret_cast<float4*>(&(BASE)[st_off + (I) * RP * GLD]) = (V)
 #define PG_STORE(BUF)                                                                  \
   {                                                                                    \
-    float* A_ = As + (BUF) * (GBM * GLD);                                              \
+    float* A_ = As + (BUF) * (BM * GLD);                                               \
     float* B_ = Bs + (BUF) * (BN * GLD);                                               \
     PG_ST(A_, 0, sg_a0); PG_ST(A_, 1, sg_a1); PG_ST(A_, 2, sg_a2); PG_ST(A_, 3, sg_a3); \
-    PG_ST(B_, 0, sg_w0); PG_ST(B_, 1, sg_w1); PG_ST(B_, 2, sg_w2); PG_ST(B_, 3, sg_w3); \
-    if constexpr (WNT == 4) {                                                          \
+    PG_ST(B_, 0, sg_w0); PG_ST(B_, 1, sg_w1);                                          \
+    if constexpr (NW4 >= 4) { PG_ST(B_, 2, sg_w2); PG_ST(B_, 3, sg_w3); }              \
+    if constexpr (NW4 == 8) {                                                          \
       PG_ST(B_, 4, sg_w4); PG_ST(B_, 5, sg_w5); PG_ST(B_, 6, sg_w6); PG_ST(B_, 7, sg_w7); \
     }                                                                                  \
   }
 #define PG_RD(BASE, OFF, I, G) (*reinterpret_cast<const float4*>(&(BASE)[(OFF) + (I) * 32 * GLD + 8 * (G)]))
 #define PG_READ(BUF, G, F)                                                             \
   {                                                                                    \
-    const float* A_ = As + (BUF) * (GBM * GLD);                                        \
+    const float* A_ = As + (BUF) * (BM * GLD);                                         \
     const float* B_ = Bs + (BUF) * (BN * GLD);                                         \
     F.a0 = PG_RD(A_, a_off, 0, G); F.a1 = PG_RD(A_, a_off, 1, G);                      \
     F.b0 = PG_RD(B_, b_off, 0, G); F.b1 = PG_RD(B_, b_off, 1, G);                      \
@@ -375,18 +383,22 @@ __global__ __launch_bounds__(256, (WNT == 2 ? 2 : 1)) void gemm_f32_pipe_kernel(
   }
 }
 
-// tuning knob (rap_set_tuning): 0 = v1 128x128, 2 = pipelined 128x128, 4 = pipelined 128x256 (N % 256 == 0, else falls back to 2)
-int g_rap_gemm_variant = 2;
+// tuning knob (rap_set_tuning key 0): 0 = v1 128x128, 2 = pipelined 128x128 (two 4-wave blocks per CU),
+// 4 = pipelined 128x256 (one 4-wave block per CU; N % 256 == 0, else falls back to 2),
+// 8 = pipelined 256x128, one 8-wave block per CU with a static priority split per SIMD pair (default).
+int g_rap_gemm_variant = 8;
 
 template <int EPI>
 static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int variant) {
   const int mt = (p.M + GBM - 1) / GBM;
-  if (variant == 4 && p.N % 256 == 0) {
-    hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 4>), dim3(mt * (p.N / 256)), dim3(256), 0, stream, p);
+  if (variant == 8) {
+    hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 2, 4>), dim3(((p.M + 255) / 256) * (p.N / GBN)), dim3(512), 0, stream, p);
+  } else if (variant == 4 && p.N % 256 == 0) {
+    hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 4, 2>), dim3(mt * (p.N / 256)), dim3(256), 0, stream, p);
   } else if (variant == 0) {
     hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
   } else {
-    hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 2>), dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 2, 2>), dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
   }
 }
 

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--views", type=int, default=2)
     ap.add_argument("--only", default="", help="'attention' or 'gemm': restrict to one kernel family (PMC passes)")
+    ap.add_argument("--pmc", action="store_true", help="one launch per kernel, no warm-up (for rocprofv3 --pmc passes)")
     ap.add_argument("--gemm-variant", type=int, default=-1)
     ap.add_argument("--attn-variant", type=int, default=-1)
     args = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
         def fn():
             rc = lib.rap_attention_f32(_lib.ptr(qkv), _lib.ptr(cu), nseg, _lib.ptr(out), TP, H, _lib.ptr(ws), ws.numel(), st())
             assert rc == 0, rc
-        t = timeit(fn, iters=3 if not args.only else 1, warm=1 if not args.only else 0)
+        t = timeit(fn, iters=1 if args.pmc else 3, warm=0 if args.pmc else 1)
         fl = 4.0 * H * 64 * L * TP
         rows.append({"kernel": f"attention_f32[{name} L={L}]", "variant": args.attn_variant, "ms": t * 1e3, "tflops": fl / t / 1e12,
                      "frac_of_157.3TF": fl / t / 1e12 / 157.3})
