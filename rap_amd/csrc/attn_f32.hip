@@ -31,6 +31,17 @@
 #define AKV 64
 #define KLD 68  // K LDS row stride (floats): 272 B = 17 slots -> conflict-free ds_read_b128
 #define VLD 64
+// scheduling fence: VALU (0x2), SALU (0x4) and transcendental (0x400) instructions may cross; DS, MFMA, VMEM may not
+#define ATTN_FENCE __builtin_amdgcn_sched_barrier(0x406);
+
+__device__ __forceinline__ float xhalf_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // NW = waves per block (4: 256 queries, two blocks per CU; 8: 512 queries, one block per CU).  With NW = 8 the
 // two waves that share a SIMD (w and w+4) belong to the SAME block and get different static priorities: with equal
@@ -141,20 +152,33 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
       for (int kt = 0; kt < 2; ++kt) {
         const int kbase = t * AKV + kt * 32;
         if (kbase >= len) break;
-        // ---- S^T = K Q^T  (32 keys x 2x32 queries)
+        // ---- S^T = K Q^T  (32 keys x 2x32 queries).  LDS fragments are fetched one group ahead of the MFMAs
+        // that consume them and fenced in place (ATTN_FENCE lets VALU/SALU cross, pins DS and MFMA): hipcc
+        // otherwise sinks each ds_read to just before its consumer and ~130 cycles of LDS latency are exposed per
+        // 8 MFMAs (v1.0 of this kernel: 86 % of the fp32 matrix peak).
         f32x16 st[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[0][r] = 0.f; st[1][r] = 0.f; }
         const float* kp = Kc + (kt * 32 + l31) * KLD + 4 * hi;
+        const float* vp = Vc + (kt * 32 + 4 * hi) * VLD + 2 * l31;
+        float4 kf = *reinterpret_cast<const float4*>(kp);
+        float2 vfa, vfb;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-          const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * g);
-          const float kv[4] = {kf.x, kf.y, kf.z, kf.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            st[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[j], qf[0][g * 4 + j], st[0], 0, 0, 0);
-            st[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[j], qf[1][g * 4 + j], st[1], 0, 0, 0);
-          }
+          float4 kn = kf;
+          if (g < 7) kn = *reinterpret_cast<const float4*>(kp + 8 * (g + 1));
+          else { vfa = *reinterpret_cast<const float2*>(vp); vfb = *reinterpret_cast<const float2*>(vp + VLD); }
+          ATTN_FENCE
+          st[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[0][g * 4 + 0], st[0], 0, 0, 0);
+          st[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[1][g * 4 + 0], st[1], 0, 0, 0);
+          st[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[0][g * 4 + 1], st[0], 0, 0, 0);
+          st[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[1][g * 4 + 1], st[1], 0, 0, 0);
+          st[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[0][g * 4 + 2], st[0], 0, 0, 0);
+          st[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[1][g * 4 + 2], st[1], 0, 0, 0);
+          st[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[0][g * 4 + 3], st[0], 0, 0, 0);
+          st[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[1][g * 4 + 3], st[1], 0, 0, 0);
+          ATTN_FENCE
+          kf = kn;
         }
         // ---- mask keys beyond the segment (only the last tile can be partial)
         if (kbase + 32 > len) {
@@ -165,13 +189,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
             st[1][r] = valid ? st[1][r] : -1e30f;
           }
         }
-        // ---- online softmax (lane-local except one cross-half max)
+        // ---- online softmax (lane-local except one cross-half max, a VALU v_permlane32_swap)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           float mx = st[qt][0];
 #pragma unroll
           for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[qt][r]);
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          mx = xhalf_max(mx);
           const float mnew = fmaxf(mrun[qt], mx);
           const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
           mrun[qt] = mnew;
@@ -189,16 +213,28 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
             o[qt][1][r] *= alpha;
           }
         }
-        // ---- O^T += V^T P^T : step r contracts keys {crow(r,0), crow(r,1)} = P register r
-        const float* vp = Vc + (kt * 32 + 4 * hi) * VLD + 2 * l31;
+        // ---- O^T += V^T P^T : step r contracts keys {crow(r,0), crow(r,1)} = P register r.  V fragments are
+        // fetched two steps (8 MFMAs) ahead.
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int krow = (r & 3) + 8 * (r >> 2);   // crow(r, 0); the +4*hi is in vp
-          const float2 vf = *reinterpret_cast<const float2*>(vp + krow * VLD);
-          o[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, st[0][r], o[0][0], 0, 0, 0);
-          o[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, st[0][r], o[0][1], 0, 0, 0);
-          o[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, st[1][r], o[1][0], 0, 0, 0);
-          o[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, st[1][r], o[1][1], 0, 0, 0);
+        for (int r = 0; r < 16; r += 2) {
+          float2 vna = vfa, vnb = vfb;
+          if (r + 2 < 16) {
+            const int k0 = ((r + 2) & 3) + 8 * ((r + 2) >> 2);   // crow(r+2, 0); the +4*hi is in vp
+            const int k1 = ((r + 3) & 3) + 8 * ((r + 3) >> 2);
+            vna = *reinterpret_cast<const float2*>(vp + k0 * VLD);
+            vnb = *reinterpret_cast<const float2*>(vp + k1 * VLD);
+          }
+          ATTN_FENCE
+          o[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vfa.x, st[0][r], o[0][0], 0, 0, 0);
+          o[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vfa.y, st[0][r], o[0][1], 0, 0, 0);
+          o[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vfa.x, st[1][r], o[1][0], 0, 0, 0);
+          o[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vfa.y, st[1][r], o[1][1], 0, 0, 0);
+          o[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vfb.x, st[0][r + 1], o[0][0], 0, 0, 0);
+          o[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vfb.y, st[0][r + 1], o[0][1], 0, 0, 0);
+          o[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vfb.x, st[1][r + 1], o[1][0], 0, 0, 0);
+          o[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vfb.y, st[1][r + 1], o[1][1], 0, 0, 0);
+          ATTN_FENCE
+          vfa = vna; vfb = vnb;
         }
       }
     }
@@ -213,7 +249,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int q = qw0 + qt * 32 + l31;
-    const float ltot = lsum[qt] + __shfl_xor(lsum[qt], 32, 64);
+    const float ltot = xhalf_sum(lsum[qt]);
     const float inv = 1.0f / ltot;
     if (q < len) {
       float* op = out + (size_t)(it.seg_start + q) * dmodel + head * 64;
@@ -250,14 +286,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
 // is still being read after the next tile's K has been opened, so a tile costs two barriers: one publishing
 // tile t+1, one retiring tile t before its buffer is overwritten by tile t+2.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float xhalf_max(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xhalf_sum(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 struct SmState { float mx_a, mnew, alpha, ps; };
 
@@ -306,14 +334,19 @@ __device__ __forceinline__ void qk_subtile(const float* __restrict__ Kc, int sub
   f32x16 s2;     // second accumulation chain: a dependent MFMA never waits on its predecessor
 #pragma unroll
   for (int r = 0; r < 16; ++r) { sn[r] = 0.f; s2[r] = 0.f; }
+  float4 kf = *reinterpret_cast<const float4*>(kp);
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
-    const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * g);
+    float4 kn = kf;
+    if (g < 7) kn = *reinterpret_cast<const float4*>(kp + 8 * (g + 1));    // one group ahead, fenced in place
+    ATTN_FENCE
     sn = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[g * 4 + 0], sn, 0, 0, 0);
     s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[g * 4 + 1], s2, 0, 0, 0);
     if (WITH_SM) softmax_slice8(g, sp, mrun, lsum, o0, o1, st);
     sn = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[g * 4 + 2], sn, 0, 0, 0);
     s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[g * 4 + 3], s2, 0, 0, 0);
+    ATTN_FENCE
+    kf = kn;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) sn[r] += s2[r];
@@ -327,12 +360,24 @@ __device__ __forceinline__ void qk_subtile(const float* __restrict__ Kc, int sub
 __device__ __forceinline__ void pv_subtile(const float* __restrict__ Vc, int sub, int hi, int l31, const f32x16& p,
                                            f32x16& o0, f32x16& o1) {
   const float* vp = Vc + (sub * 32 + 4 * hi) * VLD + 2 * l31;
+  float2 vfa = *reinterpret_cast<const float2*>(vp);
+  float2 vfb = *reinterpret_cast<const float2*>(vp + VLD);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int krow = (r & 3) + 8 * (r >> 2);
-    const float2 vf = *reinterpret_cast<const float2*>(vp + krow * VLD);
-    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, p[r], o0, 0, 0, 0);
-    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, p[r], o1, 0, 0, 0);
+  for (int r = 0; r < 16; r += 2) {
+    float2 vna = vfa, vnb = vfb;
+    if (r + 2 < 16) {
+      const int k0 = ((r + 2) & 3) + 8 * ((r + 2) >> 2);
+      const int k1 = ((r + 3) & 3) + 8 * ((r + 3) >> 2);
+      vna = *reinterpret_cast<const float2*>(vp + k0 * VLD);
+      vnb = *reinterpret_cast<const float2*>(vp + k1 * VLD);
+    }
+    ATTN_FENCE
+    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vfa.x, p[r], o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vfa.y, p[r], o1, 0, 0, 0);
+    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vfb.x, p[r + 1], o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vfb.y, p[r + 1], o1, 0, 0, 0);
+    ATTN_FENCE
+    vfa = vna; vfb = vnb;
   }
 }
 

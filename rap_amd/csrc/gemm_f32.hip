@@ -295,34 +295,48 @@ __global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 2 : (WNT == 2 ? 2 : 1))) voi
   __syncthreads();
   PG_READ(0, 0, f0)
 
+  // hipcc sinks an LDS read down to just before its first use; every PG_READ is therefore fenced with
+  // sched_barrier so that the next group's operands are IN FLIGHT during the current group's MFMAs
+  // (un-fenced, the four reads sat one MFMA ahead of their consumers and ~130 cycles of LDS latency were
+  // exposed at each of the four group boundaries of a k-tile).
+#define PG_FENCE __builtin_amdgcn_sched_barrier(0);
   int kt = 0;
   for (; kt + 1 < nk; ++kt) {
     const int cur = kt & 1;
     PG_LOAD(kt + 1)
-    __builtin_amdgcn_sched_barrier(0);
     PG_READ(cur, 1, f1)
+    PG_FENCE
     PG_MFMA(f0)                             // group 0
-    __builtin_amdgcn_sched_barrier(0);
+    PG_FENCE
     PG_READ(cur, 2, f0)
+    PG_FENCE
     PG_MFMA(f1)                             // group 1
-    __builtin_amdgcn_sched_barrier(0);
+    PG_FENCE
     PG_STORE(cur ^ 1)                       // tile kt+1 -> spare buffer (last read two barriers ago)
     PG_READ(cur, 3, f1)
+    PG_FENCE
     PG_MFMA(f0)                             // group 2
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                        // tile kt+1 visible; every wave has issued all its reads of tile kt
+    PG_FENCE
+    __syncthreads();                        // tile kt+1 visible; every wave has completed its reads of tile kt
     PG_READ(cur ^ 1, 0, f0)
+    PG_FENCE
     PG_MFMA(f1)                             // group 3 of tile kt covers the first reads of tile kt+1
-    __builtin_amdgcn_sched_barrier(0);
+    PG_FENCE
   }
   {
     const int cur = kt & 1;
     PG_READ(cur, 1, f1)
+    PG_FENCE
     PG_MFMA(f0)
+    PG_FENCE
     PG_READ(cur, 2, f0)
+    PG_FENCE
     PG_MFMA(f1)
+    PG_FENCE
     PG_READ(cur, 3, f1)
+    PG_FENCE
     PG_MFMA(f0)
+    PG_FENCE
     PG_MFMA(f1)
   }
 
