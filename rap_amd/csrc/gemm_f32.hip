@@ -397,15 +397,200 @@ __global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 2 : (WNT == 2 ? 2 : 1))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant (the default).  Ablation on MI355X (scripts/mfma_ablation.py) shows what costs the
+// register-staged loop its MFMA rate: a pure MFMA stream with LDS operand reads and a barrier per 64 MFMAs
+// sustains ~141 TF, adding the 8 global_load_dwordx4 + 8 ds_write_b128 per wave per k-tile drops it to ~122 TF.
+// Here the k-tiles go global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass,
+// 32 fewer VGPRs).  The DMA writes LDS lane-linearly (wave base + lane*16 B), so rows cannot be padded;
+// bank conflicts are avoided by an XOR swizzle of the 16-byte slot index, slot' = slot ^ ((row >> 1) & 7),
+// applied to the per-lane GLOBAL source address when staging and to the ds_read_b128 address when reading
+// (conflict-free for every 16-lane group of ds_read_b128: rows {0-3,12-15,20-27} x one logical slot map to
+// 16 distinct physical slots of the 256-byte bank row).
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(1024))) float smem[2 * 2 * 128 * 32];   // 64 KB: [A0 A1 B0 B1][128 rows][32 floats]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nt = p.N / GBN;
+  const int mt = (p.M + GBM - 1) / GBM;
+  const int logical = xcd_remap(blockIdx.x, mt * nt);
+  const int m0 = (logical / nt) * GBM;
+  const int n0 = (logical % nt) * GBN;
+
+  // DMA sources: chunk id = i*256 + tid -> (row = id >> 3, physical slot = id & 7) holds logical slot (slot ^ swz(row))
+  const float* a_src[4];
+  const float* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = i * 256 + tid;
+    const int row = id >> 3;
+    const int lslot = (id & 7) ^ ((row >> 1) & 7);
+    int r = m0 + row;
+    r = r < p.M ? r : p.M - 1;
+    a_src[i] = p.A + (size_t)r * p.lda + 4 * lslot;
+    w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + 4 * lslot;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  struct Frag { float4 a0, a1, b0, b1; } f0, f1;
+  const int nk = p.K / GBK;
+  const int sw = (l31 >> 1) & 7;
+  const int a_row = (wm * 64 + l31) * 32;
+  const int b_row = 2 * 4096 + (wn * 64 + l31) * 32;
+  const int co0 = ((0 + hi) ^ sw) * 4, co1 = ((2 + hi) ^ sw) * 4, co2 = ((4 + hi) ^ sw) * 4, co3 = ((6 + hi) ^ sw) * 4;
+
+  // The DMA is issued from inline asm: through the builtin, hipcc (ROCm 7.2) treats the transfer as an LDS write that
+  // may alias every later ds_read and drains it (s_waitcnt vmcnt(0)) before the first fragment read of the SAME
+  // iteration, which serialises the whole pipeline.  Hidden in asm, the transfer is retired by the explicit
+  // vmcnt(0) in front of the barrier that publishes the tile (DG_SYNC).
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);   // + chunk bytes below
+#define DG_DMA1(GSRC, LDSB)                                                                                   \
+  {                                                                                                           \
+    unsigned keep_;                                                                                           \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(GSRC), "s"(LDSB) : "memory");                                           \
+  }
+#define DG_DMA(KT, BUF)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
+    DG_DMA1(a_src[i] + (size_t)(KT) * GBK, lds_wave + (unsigned)(((BUF) * 4096 + i * 1024) * 4))              \
+    DG_DMA1(w_src[i] + (size_t)(KT) * GBK, lds_wave + (unsigned)((8192 + (BUF) * 4096 + i * 1024) * 4))       \
+  }
+#define DG_SYNC asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+#define DG_RD(OFF) (*reinterpret_cast<const float4*>(&smem[OFF]))
+#define DG_READ(BUF, CO, F)                                   \
+  F.a0 = DG_RD((BUF) * 4096 + a_row + (CO));                  \
+  F.a1 = DG_RD((BUF) * 4096 + a_row + 32 * 32 + (CO));        \
+  F.b0 = DG_RD((BUF) * 4096 + b_row + (CO));                  \
+  F.b1 = DG_RD((BUF) * 4096 + b_row + 32 * 32 + (CO));
+#define DG_MM(I, J, AV, BV) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV, acc[I][J], 0, 0, 0);
+#define DG_STEP(F, C) DG_MM(0, 0, F.a0.C, F.b0.C) DG_MM(0, 1, F.a0.C, F.b1.C) DG_MM(1, 0, F.a1.C, F.b0.C) DG_MM(1, 1, F.a1.C, F.b1.C)
+#define DG_MFMA(F) DG_STEP(F, x) DG_STEP(F, y) DG_STEP(F, z) DG_STEP(F, w)
+#define DG_FENCE __builtin_amdgcn_sched_barrier(0);
+
+  DG_DMA(0, 0)
+  DG_SYNC
+  DG_READ(0, co0, f0)
+
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {
+    const int cur = kt & 1;
+    DG_DMA(kt + 1, cur ^ 1)                 // spare buffer: every wave finished reading it before the last barrier
+    DG_READ(cur, co1, f1)
+    DG_FENCE
+    DG_MFMA(f0)
+    DG_FENCE
+    DG_READ(cur, co2, f0)
+    DG_FENCE
+    DG_MFMA(f1)
+    DG_FENCE
+    DG_READ(cur, co3, f1)
+    DG_FENCE
+    DG_MFMA(f0)
+    DG_FENCE
+    DG_SYNC                                 // tile kt+1 landed (vmcnt(0)) and visible; reads of tile kt complete
+    DG_READ(cur ^ 1, co0, f0)
+    DG_FENCE
+    DG_MFMA(f1)
+    DG_FENCE
+  }
+  {
+    const int cur = kt & 1;
+    DG_READ(cur, co1, f1)
+    DG_FENCE
+    DG_MFMA(f0)
+    DG_FENCE
+    DG_READ(cur, co2, f0)
+    DG_FENCE
+    DG_MFMA(f1)
+    DG_FENCE
+    DG_READ(cur, co3, f1)
+    DG_FENCE
+    DG_MFMA(f0)
+    DG_FENCE
+    DG_MFMA(f1)
+  }
+
+  // ---------------- epilogue (same as the other variants) ----------------
+  const int mw = m0 + wm * 64;
+  const int nw = n0 + wn * 64;
+  if (EPI == EPI_GEGLU) {
+    const int nout = (nw >> 1) + l31;
+    const float bh = p.bias ? p.bias[nw + l31] : 0.f;
+    const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + mi * 32 + mfma32_crow(r, hi);
+        if (m < p.M) {
+          const float h = acc[mi][0][r] + bh;
+          const float g = acc[mi][1][r] + bg;
+          const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+          p.C[(size_t)m * p.ldc + nout] = h * ge;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = nw + ni * 32 + l31;
+      const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + mi * 32 + mfma32_crow(r, hi);
+        if (m >= p.M) continue;
+        float v = acc[mi][ni][r] + bn;
+        if (EPI == EPI_BIAS) {
+          p.C[(size_t)m * p.ldc + n] = v;
+        } else if (EPI == EPI_BIAS_RESID) {
+          p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
+        } else if (EPI == EPI_BIAS_SILU) {
+          p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
+        } else if (EPI == EPI_BIAS_ANCHOR) {
+          const int sel = p.anchor[m] ? 1 : 0;
+          p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
+        } else if (EPI == EPI_QKV_HEADMAJOR) {
+          const int dmodel = p.heads * 64;
+          const int c = n / dmodel;
+          const int rem = n - c * dmodel;
+          const int h = rem >> 6, j = rem & 63;
+          p.C[(((size_t)c * p.heads + h) * p.M + m) * 64 + j] = v;
+        }
+      }
+    }
+  }
+}
+
 // tuning knob (rap_set_tuning key 0): 0 = v1 128x128, 2 = pipelined 128x128 (two 4-wave blocks per CU),
 // 4 = pipelined 128x256 (one 4-wave block per CU; N % 256 == 0, else falls back to 2),
-// 8 = pipelined 256x128, one 8-wave block per CU with a static priority split per SIMD pair (default).
-int g_rap_gemm_variant = 8;
+// 8 = pipelined 256x128, one 8-wave block per CU with a static priority split per SIMD pair,
+// 16 = LDS-DMA staged 128x128 (default).
+int g_rap_gemm_variant = 16;
 
 template <int EPI>
 static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int variant) {
   const int mt = (p.M + GBM - 1) / GBM;
-  if (variant == 8) {
+  if (variant == 16) {
+    hipLaunchKernelGGL(gemm_f32_dma_kernel<EPI>, dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
+  } else if (variant == 8) {
     hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 2, 4>), dim3(((p.M + 255) / 256) * (p.N / GBN)), dim3(512), 0, stream, p);
   } else if (variant == 4 && p.N % 256 == 0) {
     hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 4, 2>), dim3(mt * (p.N / 256)), dim3(256), 0, stream, p);
