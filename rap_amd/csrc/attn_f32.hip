@@ -531,9 +531,10 @@ __global__ void build_attn_worklist_kernel(const int32_t* __restrict__ cu, int n
   for (; n < max_items; ++n) { AttnWorkItem w; w.seg_start = 0; w.seg_len = 0; w.q0 = 0; w.pad = 0; items[n] = w; }
 }
 
-// tuning knob (rap_set_tuning key 1): 1 = v1 with 4 waves (256 queries per block), 5 = v1 with 8 waves + static priority
-// split (512 queries per block, the default), 3 = v3 (one query tile per wave, cross-sub-tile pipelining).
-int g_rap_attn_variant = 5;
+// tuning knob (rap_set_tuning key 1): 1 = v1 with 4 waves (256 queries per block, the default: 136 TF at the C1 shapes,
+// profiles/r01_run3_kernel_variant_sweep.jsonl), 5 = v1 with 8 waves + static priority split (512 queries per block,
+// 134 TF), 3 = v3 (one query tile per wave, cross-sub-tile pipelining, 124 TF).
+int g_rap_attn_variant = 1;
 static int attn_block_queries() { return g_rap_attn_variant == 5 ? 512 : RAP_ATTN_BQ; }
 
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,

@@ -1,0 +1,49 @@
+#!/bin/bash
+# One GPU-box session: parity tests, per-kernel variant sweep, the bench line, and a rocprofv3 kernel trace of the
+# same bench command.  Usage (from the repo root, through gpurun):  bash scripts/gpu_run.sh <tag> [stages...]
+# stages: tests sweep bench prof pmc   (default: all but pmc)
+set -u
+TAG=${1:-run}; shift || true
+STAGES=${*:-"tests sweep bench prof"}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+  echo "pytest exit $?" >> "$OUT/pytest_gpu.log"
+  tail -5 "$OUT/pytest_gpu.log"
+fi
+if has sweep; then
+  : > "$OUT/kernel_bench.jsonl"
+  for v in 2 4 8 16; do
+    timeout 300 python scripts/kernel_bench.py --only gemm --gemm-variant $v >> "$OUT/kernel_bench.jsonl" 2>> "$OUT/kernel_bench.err"
+  done
+  for v in 1 3 5; do
+    timeout 300 python scripts/kernel_bench.py --only attention --attn-variant $v >> "$OUT/kernel_bench.jsonl" 2>> "$OUT/kernel_bench.err"
+  done
+  timeout 300 python scripts/kernel_bench.py > "$OUT/kernel_bench_default.jsonl" 2>> "$OUT/kernel_bench.err"
+  cat "$OUT/kernel_bench.jsonl"
+fi
+if has bench; then
+  timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+  echo "bench exit $?"; cat "$OUT/bench.json"
+fi
+if has prof; then
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/prof_bench" -o bench -- \
+      python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$GRAFT_REPO_ROOT/$OUT/prof_bench.log" 2>&1 )
+  DB=$(find "$OUT/prof_bench" -name '*.db' | head -1)
+  if [ -n "$DB" ]; then python scripts/rocpd_summary.py "$DB" > "$OUT/bench_kernel_trace_stats.txt"; head -30 "$OUT/bench_kernel_trace_stats.txt"; fi
+  find "$OUT/prof_bench" -name '*.db' -size +20M -delete
+fi
+if has pmc; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d "$GRAFT_REPO_ROOT/$OUT/pmc_$c" -o pmc -- \
+        python "$GRAFT_REPO_ROOT/scripts/kernel_bench.py" --only attention --pmc > "$GRAFT_REPO_ROOT/$OUT/pmc_$c.log" 2>&1 )
+    DB=$(find "$OUT/pmc_$c" -name '*.db' | head -1)
+    if [ -n "$DB" ]; then python scripts/rocpd_summary.py "$DB" --pmc > "$OUT/pmc_$c.txt"; grep PMC "$OUT/pmc_$c.txt"; fi
+    find "$OUT/pmc_$c" -name '*.db' -size +20M -delete
+  done
+fi
+echo "gpu_run $TAG done"
