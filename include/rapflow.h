@@ -52,6 +52,16 @@ int rap_model_create(const rap_model_desc* desc, const float* d_weights, int64_t
                      rap_model** out);
 void rap_model_destroy(rap_model* m);
 
+/* Arithmetic type of the transformer blocks (qkv / out / feed-forward GEMMs and attention) for subsequent calls on `m`:
+ * 0 = fp32 (default; exact-fp32 MFMA, the parity configuration of BASELINE configs[1]),
+ * 1 = bf16 MFMA (BASELINE configs[2], [4]), 2 = fp16 MFMA.  Replaces the autocast context the reference runs its
+ * GPU inference under (Lightning precision "16-mixed", config/trainer/infer.yaml:6; attn_dtype, layer.py:106-128).
+ * Residual stream, LayerNorm, softmax, accumulation, embedding, final_mlp, Euler and Procrustes stay fp32
+ * (final_mlp is fp32 in the reference too, point_cloud_dit.py:183-184).  The first call per dtype allocates and
+ * fills the 16-bit weight copies.  rap_workspace_bytes depends on the current dtype. */
+int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* stream);
+int rap_model_compute_dtype(const rap_model* m);
+
 /* Bytes of caller-provided workspace for one call on a batch of TP points, B samples, `nseg_part`
  * part segments (B*P for rap_sample, VP for rap_dit_forward) and `rows` adaLN rows
  * (num_steps for rap_sample, B for rap_dit_forward). */
@@ -126,15 +136,36 @@ int rap_token_sample(const int32_t* cu_batch, int32_t B, int32_t* token_sample, 
 int rap_adaln_table(const rap_model* m, const float* t, int32_t rows, float* scratch, float* out, void* stream);
 
 
+/* ---- reduced-precision kernel-level entry points (dtype 1 = bf16, 2 = fp16; 16-bit tensors as uint16_t*) ---- */
+int rap_convert_h16(int32_t dtype, const float* src, uint16_t* dst, int64_t n, void* stream);
+/* C = A (M,K) W(N,K)^T, fp32 accumulate.  epilogue: 0 C half = acc + bias; 1 C fp32 = (resid +) acc + bias;
+ * 3 GEGLU on value/gate-interleaved W (C half (M,N/2)); 4 qkv split: q,k -> C half [2][H][M][64], v -> vt, the
+ * TRANSPOSED image [H][vt_nblk][64 d][64 pos] the attention kernel consumes: token t sits in block t >> 6 at
+ * pos = (t & 51) | ((t & 4) << 1) | ((t & 8) >> 1); vt_nblk * 64 >= M rounded up to 256; rows >= M are written as 0. */
+int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, void* C,
+                 int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const float* resid, int32_t ldr,
+                 int32_t heads, uint16_t* vt, int32_t vt_nblk, void* stream);
+/* flash_attn_varlen_qkvpacked_func equivalent on 16-bit operands (fp32 softmax): qk [2][H][TP][64], vt as above,
+ * out half (TP, H*64).  ws >= rap_attention_workspace_bytes(TP, nseg). */
+int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk, const int32_t* cu_seqlens,
+                      int32_t nseg, uint16_t* out, int64_t TP, int32_t heads, void* ws, size_t ws_bytes, void* stream);
+int rap_layernorm_mod_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* mod,
+                          int64_t mod_stride, const int32_t* token_row, void* stream);
+int rap_layernorm_affine_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* gain,
+                             const float* shift, void* stream);
+int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t heads, const float* gamma_q, const float* gamma_k,
+                   void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg) ----
  * When enabled, every attention and layer-GEMM launch inside rap_dit_forward / rap_sample is bracketed by two
  * hipEvents recorded on the launch stream.  rap_profile_collect synchronises on them and returns, per class
  * (0 attention per part, 1 attention per sample, 2 layer GEMMs), the summed milliseconds and the launch count
  * into HOST arrays of 3 entries.  Not thread-safe; off by default. */
 int rap_profile_enable(int on);
-/* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py): key 0 = GEMM {0: 128x128 v1, 2: pipelined
- * 128x128, 4: pipelined 128x256 (default)}, key 1 = attention {1: v1 two query tiles per wave, 3: pipelined (default)}.
- * All variants compute the same function. */
+/* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py): key 0 = fp32 GEMM {0: 128x128 v1, 2: pipelined
+ * 128x128, 4: pipelined 128x256, 8: 256x128 8-wave, 16: LDS-DMA staged 128x128 (default)}, key 1 = fp32 attention
+ * {1: 4-wave v1 (default), 3: pipelined, 5: 8-wave v1}, key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave (default),
+ * 2: 256x128 8-wave}.  All variants compute the same function. */
 int rap_set_tuning(int32_t key, int32_t value);
 int rap_profile_reset(void);
 int rap_profile_collect(float* h_ms_out, int64_t* h_count_out);

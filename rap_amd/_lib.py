@@ -13,6 +13,8 @@ from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librapflow.so")
 
+DTYPES = {"float32": 0, "fp32": 0, "bfloat16": 1, "bf16": 1, "float16": 2, "fp16": 2}
+
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP runtime error", -4: "allocation failure"}
 
 
@@ -32,6 +34,8 @@ SIGNATURES = {
     "rap_weight_count": (c_int64, [ctypes.POINTER(ModelDesc)]),
     "rap_model_create": (c_int32, [ctypes.POINTER(ModelDesc), _P, c_int64, _P, ctypes.POINTER(_P)]),
     "rap_model_destroy": (None, [_P]),
+    "rap_model_set_compute_dtype": (c_int32, [_P, c_int32, _P]),
+    "rap_model_compute_dtype": (c_int32, [_P]),
     "rap_workspace_bytes": (c_size_t, [_P, c_int64, c_int32, c_int32, c_int32]),
     "rap_dit_forward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, c_size_t, _P]),
     "rap_euler_step": (c_int32, [_P, _P, c_float, c_float, _P, _P, _P, c_int64, _P]),
@@ -53,6 +57,13 @@ SIGNATURES = {
     "rap_posenc_static": (c_int32, [_P, _P, _P, _P, c_int32, _P, c_int64, _P]),
     "rap_token_sample": (c_int32, [_P, c_int32, _P, _P]),
     "rap_adaln_table": (c_int32, [_P, _P, c_int32, _P, _P, _P]),
+    "rap_convert_h16": (c_int32, [c_int32, _P, _P, c_int64, _P]),
+    "rap_gemm_h16": (c_int32, [c_int32, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                               c_int32, c_int32, _P, c_int32, _P]),
+    "rap_attention_h16": (c_int32, [c_int32, _P, _P, c_int32, _P, c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
+    "rap_layernorm_mod_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P]),
+    "rap_layernorm_affine_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, _P, _P]),
+    "rap_qknorm_h16": (c_int32, [c_int32, _P, c_int64, c_int32, _P, _P, _P]),
     "rap_set_tuning": (c_int32, [c_int32, c_int32]),
     "rap_profile_enable": (c_int32, [c_int32]),
     "rap_profile_reset": (c_int32, []),

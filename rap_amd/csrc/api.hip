@@ -2,6 +2,7 @@
 // sequences of one velocity-network forward and of the whole Euler sampling loop.  Host code only;
 // every kernel lives in the sibling .hip files.
 #include "../../include/rapflow.h"
+#include "half.h"
 #include "kernels.h"
 
 #include <new>
@@ -74,9 +75,23 @@ struct LayerW {
   const float* bff2;      // (d)
 };
 
+// 16-bit copies of the transformer-block GEMM weights (one set per reduced-precision dtype, built on demand)
+struct LayerWH {
+  const u16* Wqkv[2];
+  const u16* Wout[2];
+  const u16* Wff1p;   // value/gate interleaved, as the fp32 packing
+  const u16* Wff2;
+};
+struct HalfWeights {
+  u16* blob = nullptr;
+  std::vector<LayerWH> layers;
+};
+
 struct rap_model {
   rap_model_desc desc;
   int d, L, H, F, E;
+  int dtype = RAP_DT_F32;     // arithmetic type of the transformer blocks (rap_model_set_compute_dtype)
+  HalfWeights half[3];        // indexed by dtype (slot 0 unused)
   float* raw = nullptr;       // copy of the caller's blob
   float* derived = nullptr;   // packed arrays
   const float* anchor_emb;    // (2,d)
@@ -99,9 +114,11 @@ static bool desc_ok(const rap_model_desc* d) {
 
 extern int g_rap_gemm_variant;   // gemm_f32.hip
 extern int g_rap_attn_variant;   // attn_f32.hip
+extern int g_rap_gemm_h16_variant;   // gemm_h16.hip
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16)) { g_rap_gemm_variant = value; return RAP_OK; }
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
+  if (key == 2 && value >= 0 && value <= 2) { g_rap_gemm_h16_variant = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 
@@ -212,14 +229,54 @@ extern "C" void rap_model_destroy(rap_model* m) {
   if (!m) return;
   if (m->raw) (void)hipFree(m->raw);
   if (m->derived) (void)hipFree(m->derived);
+  for (int i = 0; i < 3; ++i)
+    if (m->half[i].blob) (void)hipFree(m->half[i].blob);
   delete m;
 }
+
+extern "C" int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* stream_) {
+  if (!m) return RAP_ERR_INVALID;
+  if (dtype == RAP_DT_F32) { m->dtype = dtype; return RAP_OK; }
+  if (dtype != RAP_DT_BF16 && dtype != RAP_DT_F16) return RAP_ERR_INVALID;
+  HalfWeights& hw = m->half[dtype];
+  if (!hw.blob) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t d = m->d, L = m->L;
+    const size_t per_layer = 2 * (3 * d * d + d * d) + 8 * d * d + 4 * d * d;
+    if (hipMalloc((void**)&hw.blob, per_layer * L * sizeof(u16)) != hipSuccess) { hw.blob = nullptr; return RAP_ERR_ALLOC; }
+    u16* q = hw.blob;
+    int rc = RAP_OK;
+    auto conv = [&](const float* src, size_t n) -> const u16* {
+      u16* dst = q; q += n;
+      if (rc == RAP_OK) rc = launch_convert_h16(stream, dtype, src, dst, n);
+      return dst;
+    };
+    hw.layers.resize(L);
+    for (size_t i = 0; i < L; ++i) {
+      const LayerW& lw = m->layers[i];
+      LayerWH& lh = hw.layers[i];
+      for (int a = 0; a < 2; ++a) {
+        lh.Wqkv[a] = conv(lw.Wqkv[a], 3 * d * d);
+        lh.Wout[a] = conv(lw.Wout[a], d * d);
+      }
+      lh.Wff1p = conv(lw.Wff1p, 8 * d * d);
+      lh.Wff2 = conv(lw.Wff2, 4 * d * d);
+    }
+    if (rc != RAP_OK) { (void)hipFree(hw.blob); hw.blob = nullptr; hw.layers.clear(); return rc; }
+  }
+  m->dtype = dtype;
+  return RAP_OK;
+}
+extern "C" int rap_model_compute_dtype(const rap_model* m) { return m ? m->dtype : RAP_ERR_INVALID; }
 
 // ---------------------------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------------------------
 struct Workspace {
   float *base, *h, *xn, *qkv, *att, *ffmid, *ax, *v, *mod, *ada_scratch, *xt, *Rc, *tc, *tgrid;
+  float *hid1, *hid2, *astatic;        // head hidden layers (T,d), (T,d/2) and the static feature matrix (T,128): aliases
+  u16 *xnh, *qkh, *vth, *atth, *ffmidh; // reduced-precision mode: 16-bit activations (xn/qkv/att/ffmid are then unused)
+  int vt_nblk;
   double* proc_partials;
   int32_t *token_sample, *part_offsets;
   AttnWorkItem *items_batch, *items_part;
@@ -235,10 +292,26 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   const size_t T = (size_t)TP;
   w.base = (float*)take(T * d * 4);
   w.h = (float*)take(T * d * 4);
-  w.xn = (float*)take(T * d * 4);            // also head hidden 1 (TP,d)
-  w.qkv = (float*)take(T * 3 * d * 4);
-  w.att = (float*)take(T * d * 4);           // also head hidden 2 (TP,d/2)
-  w.ffmid = (float*)take(T * 4 * d * 4);     // also the static feature matrix (TP,128) during prepare
+  w.xn = w.qkv = w.att = w.ffmid = nullptr;
+  w.xnh = w.qkh = w.vth = w.atth = w.ffmidh = nullptr;
+  w.vt_nblk = 0;
+  if (m->dtype == RAP_DT_F32) {
+    w.xn = (float*)take(T * d * 4);            // also head hidden 1 (TP,d)
+    w.qkv = (float*)take(T * 3 * d * 4);
+    w.att = (float*)take(T * d * 4);           // also head hidden 2 (TP,d/2)
+    w.ffmid = (float*)take(T * 4 * d * 4);     // also the static feature matrix (TP,128) during prepare
+    w.hid1 = w.xn; w.hid2 = w.att; w.astatic = w.ffmid;
+  } else {
+    w.vt_nblk = (int)(align_up(T, 256) / 64);  // V^T image: whole 64-token blocks, padded to the largest GEMM M tile
+    w.xnh = (u16*)take(T * d * 2);
+    w.qkh = (u16*)take(T * 2 * d * 2);         // q,k [2][H][T][64]
+    w.vth = (u16*)take((size_t)w.vt_nblk * 64 * d * 2);   // [H][vt_nblk][64][64]
+    w.atth = (u16*)take(T * d * 2);
+    w.ffmidh = (u16*)take(T * 4 * d * 2);      // 8*T*d bytes: also hosts the fp32 head hidden layers / static features
+    w.hid1 = (float*)w.ffmidh;                 // (T,d) fp32   = 4*T*d bytes
+    w.hid2 = w.hid1 + T * d;                   // (T,d/2) fp32 = 2*T*d bytes
+    w.astatic = (float*)w.ffmidh;
+  }
   w.ax = (float*)take(T * 64 * 4);
   w.v = (float*)take(T * 3 * 4);
   w.xt = (float*)take(T * 3 * 4);
@@ -271,11 +344,12 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
                           int B, int nseg_part, int TP) {
   int rc;
   if ((rc = launch_token_sample(stream, cu_batch, B, w.token_sample))) return rc;
-  if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch))) return rc;
-  if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part))) return rc;
+  const int bq = m->dtype == RAP_DT_F32 ? 0 : RAP_ATTN_BQ;
+  if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch, bq))) return rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part, bq))) return rc;
   // base = [PE63(cond) | PE21(scale) | feat | 0] Wstatic^T + emb bias + anchor embedding   (embedding.py:155-179,
   // point_cloud_dit.py:119-139) -- everything in the embedding that does not depend on x_t.
-  float* astatic = w.ffmid;
+  float* astatic = w.astatic;
   if ((rc = launch_posenc_static(stream, cond, scales, w.token_sample, feat, m->F, astatic, TP))) return rc;
   GemmParams g{};
   g.A = astatic; g.lda = 128; g.W = m->Wstatic; g.ldw = 128; g.C = w.base; g.ldc = m->d;
@@ -296,8 +370,46 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
     g.resid = w.base; g.ldr = d;
     if ((rc = launch_gemm_f32(stream, EPI_BIAS_RESID, g))) return rc;
   }
+  const int dt = m->dtype;
   for (int i = 0; i < m->L; ++i) {
     const LayerW& lw = m->layers[i];
+    if (dt != RAP_DT_F32) {
+      // ---- reduced-precision block: 16-bit MFMA operands, fp32 accumulate, fp32 residual stream / LN / softmax
+      const LayerWH& lh = m->half[dt].layers[i];
+      for (int a = 0; a < 2; ++a) {
+        const int j = 2 * i + a;
+        if ((rc = launch_layernorm_mod_h16(stream, dt, w.h, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
+        GemmParamsH g{};
+        g.A = w.xnh; g.lda = d; g.W = lh.Wqkv[a]; g.ldw = d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
+        g.vt = w.vth; g.vt_nblk = w.vt_nblk;
+        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV, g); }
+        if (rc) return rc;
+        if ((rc = launch_qknorm_h16(stream, dt, w.qkh, TP, H, lw.gq[a], lw.gk[a]))) return rc;
+        {
+          ProfScope ps(stream, a);
+          rc = launch_attention_h16(stream, dt, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch,
+                                    a == 0 ? w.max_items_part : w.max_items_batch);
+        }
+        if (rc) return rc;
+        GemmParamsH o{};
+        o.A = w.atth; o.lda = d; o.W = lh.Wout[a]; o.ldw = d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = d;
+        o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d;
+        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, o); }
+        if (rc) return rc;
+      }
+      if ((rc = launch_layernorm_affine_h16(stream, dt, w.h, w.xnh, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
+      GemmParamsH f1{};
+      f1.A = w.xnh; f1.lda = d; f1.W = lh.Wff1p; f1.ldw = d; f1.C = w.ffmidh; f1.ldc = 4 * d; f1.M = TP; f1.N = 8 * d; f1.K = d;
+      f1.bias = lw.bff1p;
+      { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_GEGLU, f1); }
+      if (rc) return rc;
+      GemmParamsH f2{};
+      f2.A = w.ffmidh; f2.lda = 4 * d; f2.W = lh.Wff2; f2.ldw = 4 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 4 * d;
+      f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d;
+      { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, f2); }
+      if (rc) return rc;
+      continue;
+    }
     for (int a = 0; a < 2; ++a) {   // a = 0: per-part attention, a = 1: per-sample attention (layer.py:152-160)
       const int j = 2 * i + a;
       if ((rc = launch_layernorm_mod(stream, w.h, w.xn, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
@@ -338,13 +450,13 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
   }
   // final_mlp (point_cloud_dit.py:111-117): Lin+SiLU, Lin+SiLU, Lin(no bias)
   GemmParams h0{};
-  h0.A = w.h; h0.lda = d; h0.W = m->hW0; h0.ldw = d; h0.C = w.xn; h0.ldc = d; h0.M = TP; h0.N = d; h0.K = d; h0.bias = m->hb0;
+  h0.A = w.h; h0.lda = d; h0.W = m->hW0; h0.ldw = d; h0.C = w.hid1; h0.ldc = d; h0.M = TP; h0.N = d; h0.K = d; h0.bias = m->hb0;
   if ((rc = launch_gemm_f32(stream, EPI_BIAS_SILU, h0))) return rc;
   GemmParams h2{};
-  h2.A = w.xn; h2.lda = d; h2.W = m->hW2; h2.ldw = d; h2.C = w.att; h2.ldc = d / 2; h2.M = TP; h2.N = d / 2; h2.K = d;
+  h2.A = w.hid1; h2.lda = d; h2.W = m->hW2; h2.ldw = d; h2.C = w.hid2; h2.ldc = d / 2; h2.M = TP; h2.N = d / 2; h2.K = d;
   h2.bias = m->hb2;
   if ((rc = launch_gemm_f32(stream, EPI_BIAS_SILU, h2))) return rc;
-  return launch_head_out3(stream, w.att, d / 2, m->hW4, v_out, TP, d / 2);
+  return launch_head_out3(stream, w.hid2, d / 2, m->hW4, v_out, TP, d / 2);
 }
 
 extern "C" int rap_dit_forward(const rap_model* m, const float* x_t, const float* timesteps, const float* cond,
@@ -522,7 +634,7 @@ extern "C" int rap_attention_f32(const float* qkv_headmajor, const int32_t* cu_s
   const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
-  if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items))) return rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, 0))) return rc;
   return launch_attention_f32(stream, qkv_headmajor, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items);
 }
 
@@ -558,4 +670,45 @@ extern "C" int rap_adaln_table(const rap_model* m, const float* t, int32_t rows,
   if (!m || !t || !scratch || !out) return RAP_ERR_INVALID;
   return launch_adaln_table((hipStream_t)stream, t, rows, 2 * m->L, m->d, m->adaW1, m->adab1, m->adaW2, m->adab2, m->adaW3,
                             m->adab3, scratch, out);
+}
+
+// ---- reduced-precision kernel-level entry points (dtype: 1 = bf16, 2 = fp16; 16-bit tensors as uint16_t*) ----
+extern "C" int rap_convert_h16(int32_t dtype, const float* src, uint16_t* dst, int64_t n, void* stream) {
+  if (!src || !dst || n < 0) return RAP_ERR_INVALID;
+  return launch_convert_h16((hipStream_t)stream, dtype, src, dst, (size_t)n);
+}
+extern "C" int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw,
+                            void* C, int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const float* resid,
+                            int32_t ldr, int32_t heads, uint16_t* vt, int32_t vt_nblk, void* stream) {
+  if (!A || !W || !C) return RAP_ERR_INVALID;
+  GemmParamsH g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias;
+  g.resid = resid; g.ldr = ldr; g.heads = heads; g.vt = vt; g.vt_nblk = vt_nblk;
+  return launch_gemm_h16((hipStream_t)stream, dtype, epilogue, g);
+}
+extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk,
+                                 const int32_t* cu_seqlens, int32_t nseg, uint16_t* out, int64_t TP, int32_t heads, void* ws,
+                                 size_t ws_bytes, void* stream_) {
+  if (!qk || !vt || !cu_seqlens || !out || nseg < 0 || TP < 0 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
+  if (!ws || ws_bytes < rap_attention_workspace_bytes(TP, nseg)) return RAP_ERR_WORKSPACE;
+  const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, RAP_ATTN_BQ))) return rc;
+  return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items);
+}
+extern "C" int rap_layernorm_mod_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* mod,
+                                     int64_t mod_stride, const int32_t* token_row, void* stream) {
+  if (!x || !out || !mod) return RAP_ERR_INVALID;
+  return launch_layernorm_mod_h16((hipStream_t)stream, dtype, x, out, (int)TP, d, mod, (long)mod_stride, token_row);
+}
+extern "C" int rap_layernorm_affine_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* gain,
+                                        const float* shift, void* stream) {
+  if (!x || !out || !gain || !shift) return RAP_ERR_INVALID;
+  return launch_layernorm_affine_h16((hipStream_t)stream, dtype, x, out, (int)TP, d, gain, shift);
+}
+extern "C" int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t heads, const float* gamma_q,
+                              const float* gamma_k, void* stream) {
+  if (!qk || !gamma_q || !gamma_k) return RAP_ERR_INVALID;
+  return launch_qknorm_h16((hipStream_t)stream, dtype, qk, (int)TP, heads, gamma_q, gamma_k);
 }

@@ -538,10 +538,10 @@ int g_rap_attn_variant = 1;
 static int attn_block_queries() { return g_rap_attn_variant == 5 ? 512 : RAP_ATTN_BQ; }
 
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,
-                               int max_items) {
+                               int max_items, int block_queries) {
   if (max_items <= 0) return RAP_OK;
   hipLaunchKernelGGL(build_attn_worklist_kernel, dim3(1), dim3(64), 0, stream, cu_seqlens, nseg, items, max_items,
-                     attn_block_queries());
+                     block_queries > 0 ? block_queries : attn_block_queries());
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }

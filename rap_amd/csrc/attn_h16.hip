@@ -1,0 +1,203 @@
+// Variable-length, non-causal softmax attention on the bf16 / fp16 matrix cores (fp32 softmax state and accumulation).
+//
+// Reduced-precision twin of attn_f32.hip; replaces flash_attn.flash_attn_varlen_qkvpacked_func as the reference
+// runs it on a GPU (fp16 / bf16 `attn_dtype`, flow_model/layer.py:106-111 per part, :123-128 per sample).
+//
+// Layout: q,k head-major [2][H][TP][64] 16-bit (written by the QKV GEMM epilogue, normalised in place by qknorm);
+// v TRANSPOSED and blocked by 64 tokens, vt[H][block][64 d][64 pos] with pos = vt_pos(token & 63) (half.h);
+// out token-major (TP, H*64) 16-bit = the A operand of the out-projection GEMM.
+//
+// Design (gfx950 only; Dh = 64):
+//  * block = 256 queries of one (segment, head): 8 waves x 32 queries; K / V^T streamed in 64-key tiles through
+//    double-buffered LDS (global -> registers -> LDS; loads of tile t+1 are issued before the MFMAs of tile t and
+//    parked after them: one barrier per tile).  Key tiles are the GLOBAL 64-token blocks that intersect the
+//    segment (the V^T image is blocked that way); keys outside the segment are masked, so ragged segments cost
+//    at most one extra tile.
+//  * "swapped" products on v_mfma_f32_32x32x16_{bf16,f16}:
+//      S^T (key x query) = K (key x d) * Q^T (d x query)     A = K rows from LDS (one ds_read_b128 = 8 d), B = Q in VGPRs
+//      O^T (d x query)   = V^T (d x key) * P^T (key x query)  A = V^T rows from LDS (one ds_read_b128 = 8 keys), B = P
+//    A lane owns ONE query column and 16 of every 32 keys, so the online-softmax state is lane-local (one
+//    lane^32 exchange per tile for the row maximum).
+//  * No data movement between the two products: the 8 accumulator registers 8(s&1)..8(s&1)+7 of S^T sub-tile s>>1
+//    hold the keys 16s + 4hi + {0..3} and 16s + 8 + 4hi + {0..3}; vt_pos stores exactly those keys contiguously,
+//    so P is converted to 16 bit in place (v_cvt_pk) and fed back as the B operand: no LDS round trip, no shuffles.
+//  * LDS rows are 144 bytes (9 sixteen-byte slots): the 16 rows of each ds_read_b128 lane group hit 16 distinct slots.
+//  * softmax scale * log2(e) is applied inside the exponent's FMA (fp32 scores), exponentials are v_exp_f32.
+//  * grid = work items x heads with head = blockIdx % H (= the XCD: each XCD's L2 serves one head's K/V).
+#include "half.h"
+#include "kernels.h"
+
+#define HKV 64
+#define HLD 72   // LDS row stride in 16-bit elements (144 B)
+
+__device__ __forceinline__ float h_xhalf_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float h_xhalf_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
+                                                               int vt_nblk, u16* __restrict__ out, int TP, int heads,
+                                                               const AttnWorkItem* __restrict__ items) {
+  typedef typename H16<DT>::T8 T8;
+  __shared__ __attribute__((aligned(16))) u16 smem[4 * HKV * HLD];
+  u16* Ks = smem;                    // [2][64 keys][72]
+  u16* Vs = smem + 2 * HKV * HLD;    // [2][64 d][72]   (columns = vt_pos of the key)
+
+  const int head = blockIdx.x % heads;
+  const AttnWorkItem it = items[blockIdx.x / heads];
+  const int len = it.seg_len;
+  if (len <= 0) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int seg0 = it.seg_start, seg1 = it.seg_start + len;
+
+  const u16* Qg = qk + (size_t)head * TP * 64;
+  const u16* Kg = qk + (size_t)(heads + head) * TP * 64;
+  const u16* Vg = vt + (size_t)head * vt_nblk * (64 * 64);
+
+  const int qw0 = it.q0 + wave * 32;
+  const bool wave_active = qw0 < len;   // waves beyond the segment still help stage K/V
+
+  // ---- Q fragments (B operand of S^T): qf[s] = Q[q][16s + 8hi .. +7]
+  T8 qf[4];
+  {
+    int q = qw0 + l31;
+    q = q < len ? q : len - 1;
+    const u16* qp = Qg + (size_t)(seg0 + q) * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(qp + 16 * s));
+  }
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float mrun = -1e30f, lsum = 0.f;
+  const float c = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e)
+
+  // ---- staging: 512 threads, one 16-byte chunk of K and one of V^T per thread per tile
+  const int srow = tid >> 3, sch = (tid & 7) * 8;
+  const int b_first = seg0 >> 6;
+  const int ntile = ((seg1 - 1) >> 6) - b_first + 1;
+  const int soff = srow * HLD + sch;
+  uint4 rk, rv;
+#define HATT_LOAD(T)                                                                                 \
+  {                                                                                                  \
+    const int blk_ = b_first + (T);                                                                  \
+    int tok_ = blk_ * 64 + srow;                                                                     \
+    tok_ = tok_ < TP ? tok_ : TP - 1;                                                                \
+    rk = *reinterpret_cast<const uint4*>(Kg + (size_t)tok_ * 64 + sch);                              \
+    rv = *reinterpret_cast<const uint4*>(Vg + ((size_t)blk_ * 64 + srow) * 64 + sch);                \
+  }
+#define HATT_STORE(BUF)                                                                              \
+  *reinterpret_cast<uint4*>(Ks + (BUF) * (HKV * HLD) + soff) = rk;                                   \
+  *reinterpret_cast<uint4*>(Vs + (BUF) * (HKV * HLD) + soff) = rv;
+
+  HATT_LOAD(0)
+  HATT_STORE(0)
+  __syncthreads();
+
+  for (int t = 0; t < ntile; ++t) {
+    const int cur = t & 1;
+    const bool more = (t + 1) < ntile;
+    if (more) { HATT_LOAD(t + 1) }
+
+    if (wave_active) {
+      // ---- S^T = K Q^T : two 32-key sub-tiles x 32 queries
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      const u16* kp = Ks + cur * (HKV * HLD) + l31 * HLD + 8 * hi;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const T8 k0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 16 * s));
+        const T8 k1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 32 * HLD + 16 * s));
+        s0 = H16<DT>::mfma(k0, qf[s], s0);
+        s1 = H16<DT>::mfma(k1, qf[s], s1);
+      }
+      // ---- mask keys outside the segment (first / last tile only)
+      const int tile0 = (b_first + t) * 64;
+      if (tile0 < seg0 || tile0 + 64 > seg1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kg = tile0 + mfma32_crow(r, hi);
+          s0[r] = (kg >= seg0 && kg < seg1) ? s0[r] : -1e30f;
+          s1[r] = (kg + 32 >= seg0 && kg + 32 < seg1) ? s1[r] : -1e30f;
+        }
+      }
+      // ---- online softmax, lane-local except one cross-half max
+      float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+      mx = h_xhalf_max(mx);
+      const float mnew = fmaxf(mrun, mx);
+      const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);
+      mrun = mnew;
+      const float mc = mnew * c;
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -mc));
+        s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -mc));
+        ps += s0[r] + s1[r];
+      }
+      lsum = lsum * alpha + ps;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      // ---- O^T += V^T P^T : key step ks contracts the keys held in registers 8(ks&1)..+7 of sub-tile ks>>1
+      const u16* vp = Vs + cur * (HKV * HLD) + l31 * HLD + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int rb = 8 * (ks & 1);
+        T8 pb;
+        if ((ks >> 1) == 0)
+          pb = h16_pack8<DT>(s0[rb + 0], s0[rb + 1], s0[rb + 2], s0[rb + 3], s0[rb + 4], s0[rb + 5], s0[rb + 6], s0[rb + 7]);
+        else
+          pb = h16_pack8<DT>(s1[rb + 0], s1[rb + 1], s1[rb + 2], s1[rb + 3], s1[rb + 4], s1[rb + 5], s1[rb + 6], s1[rb + 7]);
+        const T8 v0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 16 * ks));
+        const T8 v1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 32 * HLD + 16 * ks));
+        o0 = H16<DT>::mfma(v0, pb, o0);
+        o1 = H16<DT>::mfma(v1, pb, o1);
+      }
+    }
+
+    if (more) { HATT_STORE(cur ^ 1) }
+    __syncthreads();
+  }
+
+  if (!wave_active) return;
+  // ---- normalise and store: lane owns query l31; register r of tile e is d = 32e + crow(r, hi): groups of 4 contiguous d
+  const int q = qw0 + l31;
+  const float inv = 1.0f / h_xhalf_sum(lsum);
+  if (q < len) {
+    u16* op = out + (size_t)(seg0 + q) * (heads * 64) + head * 64 + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<uint2*>(op + 8 * g) =
+          h16_pack4<DT>(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+      *reinterpret_cast<uint2*>(op + 32 + 8 * g) =
+          h16_pack4<DT>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+  }
+}
+
+int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
+                         int heads, const AttnWorkItem* items, int max_items) {
+  if (max_items <= 0 || TP <= 0) return RAP_OK;
+  if (heads <= 0 || vt_nblk * 64 < TP) return RAP_ERR_INVALID;
+  if (dtype == RAP_DT_BF16)
+    hipLaunchKernelGGL(attention_h16_kernel<RAP_DT_BF16>, dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out,
+                       TP, heads, items);
+  else if (dtype == RAP_DT_F16)
+    hipLaunchKernelGGL(attention_h16_kernel<RAP_DT_F16>, dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out,
+                       TP, heads, items);
+  else
+    return RAP_ERR_INVALID;
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}

@@ -1,0 +1,317 @@
+// bf16 / fp16 GEMM on the CDNA4 matrix cores:  C (M,N) = A (M,K) * W (N,K)^T  + fused epilogue, fp32 accumulate.
+//
+// The reduced-precision twin of gemm_f32.hip for the transformer blocks' dense layers (reference
+// flow_model/layer.py:73-74,81-82,89 under Lightning "16-mixed"/"bf16-mixed" autocast, trainer/infer.yaml:6):
+// qkv projection, attention out-projection, GEGLU feed-forward.  Embedding and the fp32 head stay on gemm_f32.
+//
+// Design (gfx950 only):
+//  * v_mfma_f32_32x32x16_{bf16,f16}: 8 k-values per lane per operand, 32 cycles per instruction per SIMD.
+//  * BK = 64 elements = one 128-byte line per row per k-tile -- byte-for-byte the LDS image of the fp32 kernel's
+//    LDS-DMA variant: tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass);
+//    the DMA writes LDS lane-linearly, so bank conflicts are removed by an XOR swizzle of the 16-byte slot index,
+//    slot' = slot ^ ((row >> 1) & 7), applied to the per-lane GLOBAL source address when staging and to the
+//    ds_read_b128 address when reading (conflict-free for every 16-lane group of ds_read_b128).
+//  * one ds_read_b128 = the 8 k-values of one MFMA operand; k-step g of a tile reads slot 2g + (lane >> 5).
+//  * block tile (32*TM*WM) x (32*TN*WN), WM x WN waves, each wave TM x TN MFMA tiles; double-buffered LDS, one
+//    barrier per k-tile, the DMA of tile t+1 is issued before the MFMAs of tile t and retired (vmcnt(0)) in front
+//    of the barrier that publishes it; operand fragments of k-step g+1 are read while step g's MFMAs issue.
+//    At 16x the fp32 MFMA rate the kernel is L2->LDS bandwidth bound at 128x128 (64 B/clk/CU needed vs ~56
+//    available), hence the 256x256 / 8-wave instantiation for the large shapes.
+//  * 1-D grid, XCD-aware remap, n-tile fastest (A panel stays in one XCD's L2).
+#include "half.h"
+#include "kernels.h"
+
+template <int EPI, int DT, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16_kernel(GemmParamsH p) {
+  typedef typename H16<DT>::T8 T8;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;   // 16-byte chunks per thread per k-tile
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [A0 A1 B0 B1]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nt = p.N / BN;
+  const int mt = (p.M + BM - 1) / BM;
+  const int logical = xcd_remap(blockIdx.x, mt * nt);
+  const int m0 = (logical / nt) * BM;
+  const int n0 = (logical % nt) * BN;
+
+  // DMA sources: chunk id = i*NT + tid -> (row = id >> 3, physical slot = id & 7) holds logical slot (slot ^ swz(row))
+  const u16* a_src[CA];
+  const u16* w_src[CB];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 3;
+    const int lslot = (id & 7) ^ ((row >> 1) & 7);
+    int r = m0 + row;
+    r = r < p.M ? r : p.M - 1;
+    a_src[i] = p.A + (size_t)r * p.lda + 8 * lslot;
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 3;
+    const int lslot = (id & 7) ^ ((row >> 1) & 7);
+    w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + 8 * lslot;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / 64;
+  const int sw = (l31 >> 1) & 7;
+  const int a_row = (wm * TM * 32 + l31) * 128;                       // byte offsets inside one A / B buffer
+  const int b_row = (wn * TN * 32 + l31) * 128;
+
+  // The DMA is issued from inline asm (see gemm_f32.hip: through the builtin hipcc drains it before the first
+  // fragment read of the same iteration).  m0 carries the wave-uniform LDS byte address of the 1 KiB piece.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+#define HG_DMA1(GSRC, LDSB)                                                                                   \
+  {                                                                                                           \
+    unsigned keep_;                                                                                           \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(GSRC), "s"(LDSB) : "memory");                                           \
+  }
+#define HG_DMA(KT, BUF)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < CA; ++i)                                                              \
+    HG_DMA1(a_src[i] + (size_t)(KT) * 64, lds_wave + (unsigned)((BUF) * ABYTES + i * NT * 16))                \
+  _Pragma("unroll") for (int i = 0; i < CB; ++i)                                                              \
+    HG_DMA1(w_src[i] + (size_t)(KT) * 64, lds_wave + (unsigned)(2 * ABYTES + (BUF) * BBYTES + i * NT * 16))
+#define HG_SYNC asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+#define HG_FENCE __builtin_amdgcn_sched_barrier(0);
+
+  struct Frag { uint4 a[TM]; uint4 b[TN]; };
+  Frag f0, f1;
+  auto read_frag = [&](Frag& f, int buf, int g) {
+    const int co = ((2 * g + hi) ^ sw) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      f.a[i] = *reinterpret_cast<const uint4*>(smem + buf * ABYTES + a_row + i * 32 * 128 + co);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      f.b[j] = *reinterpret_cast<const uint4*>(smem + 2 * ABYTES + buf * BBYTES + b_row + j * 32 * 128 + co);
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, f.a[i]), __builtin_bit_cast(T8, f.b[j]), acc[i][j]);
+  };
+
+  HG_DMA(0, 0)
+  HG_SYNC
+  read_frag(f0, 0, 0);
+
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {
+    const int cur = kt & 1;
+    HG_DMA(kt + 1, cur ^ 1)                 // spare buffer: every wave finished reading it before the last barrier
+    read_frag(f1, cur, 1);
+    HG_FENCE
+    mma(f0);
+    HG_FENCE
+    read_frag(f0, cur, 2);
+    HG_FENCE
+    mma(f1);
+    HG_FENCE
+    read_frag(f1, cur, 3);
+    HG_FENCE
+    mma(f0);
+    HG_FENCE
+    HG_SYNC                                 // tile kt+1 landed (vmcnt(0)) and visible; reads of tile kt complete
+    read_frag(f0, cur ^ 1, 0);
+    HG_FENCE
+    mma(f1);
+    HG_FENCE
+  }
+  {
+    const int cur = kt & 1;
+    read_frag(f1, cur, 1);
+    HG_FENCE
+    mma(f0);
+    HG_FENCE
+    read_frag(f0, cur, 2);
+    HG_FENCE
+    mma(f1);
+    HG_FENCE
+    read_frag(f1, cur, 3);
+    HG_FENCE
+    mma(f0);
+    HG_FENCE
+    mma(f1);
+  }
+
+  // ---------------- epilogue: acc[i][j][r] = C[mw + 32 i + crow(r, hi)][nw + 32 j + l31] ----------------
+  const int mw = m0 + wm * TM * 32;
+  const int nw = n0 + wn * TN * 32;
+  if constexpr (EPI == EPI_H_GEGLU) {
+    u16* C = reinterpret_cast<u16*>(p.C);
+#pragma unroll
+    for (int jp = 0; jp < TN / 2; ++jp) {
+      const int nout = ((nw + 64 * jp) >> 1) + l31;
+      const float bh = p.bias ? p.bias[nw + 64 * jp + l31] : 0.f;
+      const float bg = p.bias ? p.bias[nw + 64 * jp + 32 + l31] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + mfma32_crow(r, hi);
+          if (m < p.M) {
+            const float h = acc[i][2 * jp][r] + bh;
+            const float g = acc[i][2 * jp + 1][r] + bg;
+            const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+            C[(size_t)m * p.ldc + nout] = h16_from_f32<DT>(h * ge);
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + l31;
+    const float bn = p.bias ? p.bias[n] : 0.f;
+    if constexpr (EPI == EPI_H_QKV) {
+      const int dmodel = p.heads * 64;
+      const int c = (nw + j * 32) / dmodel;          // wave-uniform: a 32-column tile never straddles q|k|v or a head
+      const int rem = n - c * dmodel;
+      const int h = rem >> 6, jj = rem & 63;
+      if (c < 2) {
+        u16* dst = reinterpret_cast<u16*>(p.C) + ((size_t)(c * p.heads + h) * p.M) * 64 + jj;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mw + i * 32 + mfma32_crow(r, hi);
+            if (m < p.M) dst[(size_t)m * 64] = h16_from_f32<DT>(acc[i][j][r]);
+          }
+        }
+      } else {
+        // V goes out TRANSPOSED and blocked by 64 tokens: vt[h][token >> 6][d][vt_pos(token & 63)] -- the four rows
+        // of an accumulator register group are four consecutive tokens = one 8-byte store.  Rows >= M (tile padding)
+        // are written as zeros: masked keys must contribute 0 * finite in the P*V product.
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int mb = mw + i * 32 + 8 * g + 4 * hi;          // first of 4 consecutive tokens
+            float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+            v0 = (mb + 0 < p.M) ? v0 : 0.f; v1 = (mb + 1 < p.M) ? v1 : 0.f;
+            v2 = (mb + 2 < p.M) ? v2 : 0.f; v3 = (mb + 3 < p.M) ? v3 : 0.f;
+            u16* dst = p.vt + (((size_t)h * p.vt_nblk + (mb >> 6)) * 64 + jj) * 64 + vt_pos(mb & 63);
+            *reinterpret_cast<uint2*>(dst) = h16_pack4<DT>(v0, v1, v2, v3);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + mfma32_crow(r, hi);
+          if (m >= p.M) continue;
+          const float v = acc[i][j][r] + bn;
+          if constexpr (EPI == EPI_H_BIAS) {
+            reinterpret_cast<u16*>(p.C)[(size_t)m * p.ldc + n] = h16_from_f32<DT>(v);
+          } else {   // EPI_H_BIAS_RESID_F32
+            float* C = reinterpret_cast<float*>(p.C);
+            C[(size_t)m * p.ldc + n] = p.resid ? p.resid[(size_t)m * p.ldr + n] + v : v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// tuning knob (rap_set_tuning key 2): 0 = 128x128 tile, 4 waves, two blocks per CU; 1 = 256x256 tile, 8 waves
+// (wave tile 128x64), one block per CU; 2 = 256x128 tile, 8 waves (wave tile 64x64).
+int g_rap_gemm_h16_variant = 1;
+
+template <int EPI, int DT, int WM, int WN, int TM, int TN>
+static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool attr_done = false;
+  auto kern = gemm_h16_kernel<EPI, DT, WM, WN, TM, TN>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      rap_set_last_hip_error((int)hipGetLastError());
+      return RAP_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  const int mt = (p.M + BM - 1) / BM;
+  hipLaunchKernelGGL(kern, dim3(mt * (p.N / BN)), dim3(64 * WM * WN), LDS, stream, p);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
+template <int EPI, int DT>
+static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
+  const int v = g_rap_gemm_h16_variant;
+  if (v == 1 && p.N % 256 == 0) return launch_cfg<EPI, DT, 2, 4, 4, 2>(stream, p);
+  if (v == 2) return launch_cfg<EPI, DT, 4, 2, 2, 2>(stream, p);
+  return launch_cfg<EPI, DT, 2, 2, 2, 2>(stream, p);
+}
+
+template <int DT>
+static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
+  switch (epilogue) {
+    case EPI_H_BIAS: return launch_variant<EPI_H_BIAS, DT>(stream, p);
+    case EPI_H_BIAS_RESID_F32: return launch_variant<EPI_H_BIAS_RESID_F32, DT>(stream, p);
+    case EPI_H_GEGLU: return launch_variant<EPI_H_GEGLU, DT>(stream, p);
+    case EPI_H_QKV:
+      if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256) return RAP_ERR_INVALID;
+      return launch_variant<EPI_H_QKV, DT>(stream, p);
+    default: return RAP_ERR_INVALID;
+  }
+}
+
+int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p) {
+  if (p.M <= 0) return RAP_OK;
+  if (p.N % 128 != 0 || p.K % 64 != 0 || p.K <= 0) return RAP_ERR_INVALID;
+  if ((p.lda & 7) || (p.ldw & 7)) return RAP_ERR_INVALID;
+  if (dtype == RAP_DT_BF16) return launch_dt<RAP_DT_BF16>(stream, epilogue, p);
+  if (dtype == RAP_DT_F16) return launch_dt<RAP_DT_F16>(stream, epilogue, p);
+  return RAP_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 -> bf16 / fp16 conversion (weights at model creation; round to nearest even)
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void convert_h16_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n4) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    reinterpret_cast<uint2*>(dst)[i] = h16_pack4<DT>(v.x, v.y, v.z, v.w);
+  }
+}
+
+int launch_convert_h16(hipStream_t stream, int dtype, const float* src, u16* dst, size_t n) {
+  if (n == 0) return RAP_OK;
+  if (n % 4 != 0) return RAP_ERR_INVALID;
+  const size_t n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
+  if (dtype == RAP_DT_BF16) hipLaunchKernelGGL(convert_h16_kernel<RAP_DT_BF16>, dim3(grid), dim3(256), 0, stream, src, dst, n4);
+  else if (dtype == RAP_DT_F16) hipLaunchKernelGGL(convert_h16_kernel<RAP_DT_F16>, dim3(grid), dim3(256), 0, stream, src, dst, n4);
+  else return RAP_ERR_INVALID;
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}

@@ -1,0 +1,77 @@
+// 16-bit operand types of the reduced-precision velocity-network path (gfx950 only).
+//
+// DT = 1: bfloat16 (BASELINE configs[2]/[4] "bf16 MFMA"), DT = 2: IEEE half (what the reference's shipped GPU
+// configuration runs: Lightning "16-mixed" autocast + fp16 flash-attn, trainer/infer.yaml:6, layer.py:106-128).
+// Both feed v_mfma_f32_32x32x16_{bf16,f16}: 8 elements per lane per operand, fp32 accumulate, 32 cycles per
+// instruction per SIMD (16x the rate of the fp32-input MFMA the exact path uses).
+//
+// Operand layout of the 32x32x16 forms (A is 32 x 16, B is 16 x 32): lane l holds row/column (l & 31) and the
+// eight k-slots 8*(l >> 5) .. +7.  The contraction runs over (half-wave, slot) pairs, so ANY assignment of
+// logical k indices to (step, half-wave, slot) is valid as long as A and B use the same one -- the attention
+// kernel uses that freedom to feed P straight from the accumulator registers.
+#pragma once
+#include "common.h"
+
+#define RAP_DT_F32 0
+#define RAP_DT_BF16 1
+#define RAP_DT_F16 2
+
+typedef unsigned short u16;
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int DT> struct H16;
+
+template <> struct H16<RAP_DT_BF16> {
+  typedef __bf16 T;
+  typedef __bf16 T2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 T4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 T8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mfma(T8 a, T8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct H16<RAP_DT_F16> {
+  typedef _Float16 T;
+  typedef _Float16 T2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 T4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 T8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mfma(T8 a, T8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// round-to-nearest-even conversions (v_cvt_pk_{bf16,f16}_f32)
+template <int DT> __device__ __forceinline__ u16 h16_from_f32(float x) {
+  typename H16<DT>::T h = (typename H16<DT>::T)x;
+  return __builtin_bit_cast(u16, h);
+}
+template <int DT> __device__ __forceinline__ float h16_to_f32(u16 x) {
+  return (float)__builtin_bit_cast(typename H16<DT>::T, x);
+}
+template <int DT> __device__ __forceinline__ uint32_t h16_pack2(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, typename H16<DT>::T2));
+}
+template <int DT> __device__ __forceinline__ uint2 h16_pack4(float a, float b, float c, float d) {
+  f32x4 v = {a, b, c, d};
+  return __builtin_bit_cast(uint2, __builtin_convertvector(v, typename H16<DT>::T4));
+}
+template <int DT> __device__ __forceinline__ typename H16<DT>::T8 h16_pack8(float a, float b, float c, float d, float e,
+                                                                            float f, float g, float h) {
+  f32x8 v = {a, b, c, d, e, f, g, h};
+  return __builtin_convertvector(v, typename H16<DT>::T8);
+}
+template <int DT> __device__ __forceinline__ void h16_unpack8(uint4 raw, float (&out)[8]) {
+  const typename H16<DT>::T8 v = __builtin_bit_cast(typename H16<DT>::T8, raw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+}
+
+// Position of token `tok` inside its 64-token block of the transposed V image: bits 2 and 3 of the in-block index
+// are swapped, so that the eight keys a lane of the P*V MFMA contracts in one step (accumulator registers
+// 8(s&1)..8(s&1)+7 of the S^T tile = keys 16s + 4hi + {0..3} and 16s + 8 + 4hi + {0..3}) are CONTIGUOUS:
+// positions 16s + 8hi .. +7 -- one ds_read_b128 per MFMA, no cross-lane traffic between the two products.
+__host__ __device__ __forceinline__ int vt_pos(int tok_in_block) {
+  return (tok_in_block & ~12) | ((tok_in_block & 4) << 1) | ((tok_in_block & 8) >> 1);
+}

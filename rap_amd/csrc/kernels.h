@@ -34,8 +34,10 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p);
 // ---------------------------------------------------------------------------------------------
 #define RAP_ATTN_BQ 256
 struct AttnWorkItem { int seg_start, seg_len, q0, pad; };
+// block_queries: query rows per work item; 0 = what the selected fp32 attention variant uses (256 or 512),
+// the 16-bit attention kernel always takes 256.
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,
-                               int max_items);
+                               int max_items, int block_queries);
 int launch_attention_f32(hipStream_t stream, const float* qkv_headmajor, float* out, int TP, int heads,
                          const AttnWorkItem* items, int max_items);
 
@@ -81,3 +83,36 @@ int launch_copy_cols(hipStream_t stream, const float* src, int src_ld, int src_c
 int launch_geglu_interleave(hipStream_t stream, const float* W, const float* b, float* Wp, float* bp, int inner,
                             int K);
 int launch_fill_zero(hipStream_t stream, float* p, size_t n);
+
+// ---------------------------------------------------------------------------------------------
+// Reduced-precision (bf16 / fp16 MFMA, fp32 accumulate) twins of the transformer-block kernels.
+// dtype: RAP_DT_BF16 = 1, RAP_DT_F16 = 2 (half.h).  16-bit tensors are passed as uint16_t*.
+// ---------------------------------------------------------------------------------------------
+enum GemmEpilogueH {
+  EPI_H_BIAS = 0,            // C half (M,N) = acc (+ bias[n])
+  EPI_H_BIAS_RESID_F32 = 1,  // C fp32 (M,N) = (resid +) acc (+ bias[n])      (resid may alias C)
+  EPI_H_GEGLU = 3,           // W rows pre-interleaved [32 value | 32 gate]: C half (M,N/2) = (h + bh) * gelu_erf(g + bg)
+  EPI_H_QKV = 4,             // N = 3*H*64: q,k -> C half [2][H][M][64]; v -> vt half [H][vt_nblk][64 d][64 pos] (half.h vt_pos)
+};
+struct GemmParamsH {
+  const uint16_t* A; int lda;
+  const uint16_t* W; int ldw;
+  void* C; int ldc;
+  int M, N, K;
+  const float* bias;
+  const float* resid; int ldr;
+  int heads;
+  uint16_t* vt; int vt_nblk;
+};
+int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p);
+int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t* dst, size_t n);
+// attention on q,k half [2][H][TP][64] + transposed-blocked v (vt); out half (TP, H*64)
+int launch_attention_h16(hipStream_t stream, int dtype, const uint16_t* qk, const uint16_t* vt, int vt_nblk, uint16_t* out,
+                         int TP, int heads, const AttnWorkItem* items, int max_items);
+// LayerNorm with 16-bit output (fp32 statistics), same modulation forms as launch_layernorm_*
+int launch_layernorm_mod_h16(hipStream_t stream, int dtype, const float* x, uint16_t* out, int TP, int d, const float* mod,
+                             long mod_stride, const int32_t* token_row);
+int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const float* x, uint16_t* out, int TP, int d,
+                                const float* gain, const float* shift);
+int launch_qknorm_h16(hipStream_t stream, int dtype, uint16_t* qk, int TP, int heads, const float* gamma_q,
+                      const float* gamma_k);

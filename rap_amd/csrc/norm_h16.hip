@@ -1,0 +1,121 @@
+// HBM-bound normalisation kernels of the reduced-precision path: same arithmetic as norm.hip (fp32 statistics,
+// fp32 modulation), 16-bit outputs for the bf16 / fp16 GEMM and attention operands.
+//  * layernorm_h16_kernel: fp32 residual stream in, LN (+ adaLN modulation or affine), 16-bit out:
+//    3 KiB of traffic per 512-wide token (2 KiB read + 1 KiB write).
+//  * qknorm_h16_kernel: MultiHeadRMSNorm (flow_model/norm.py:28-33) in place on the 16-bit q and k planes.
+#include "half.h"
+#include "kernels.h"
+
+template <int NV, int DT>  // NV float4 per lane: d = 256 * NV
+__global__ __launch_bounds__(256) void layernorm_h16_kernel(const float* __restrict__ x, u16* __restrict__ out, int TP,
+                                                            const float* __restrict__ gain_base, const float* __restrict__ shift_base,
+                                                            long row_stride, const int32_t* __restrict__ token_row, int add_one) {
+  const int d = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= TP) return;
+  const float* xr = x + (size_t)row * d;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + e * e);
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  const long mrow = token_row ? (long)token_row[row] : 0;
+  const float* g = gain_base + mrow * row_stride;
+  const float* b = shift_base + mrow * row_stride;
+  const float one = add_one ? 1.0f : 0.0f;
+  u16* orow = out + (size_t)row * d;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const float4 gg = *reinterpret_cast<const float4*>(g + c);
+    const float4 bb = *reinterpret_cast<const float4*>(b + c);
+    const float ox = (v[i].x - mean) * rstd * (one + gg.x) + bb.x;
+    const float oy = (v[i].y - mean) * rstd * (one + gg.y) + bb.y;
+    const float oz = (v[i].z - mean) * rstd * (one + gg.z) + bb.z;
+    const float ow = (v[i].w - mean) * rstd * (one + gg.w) + bb.w;
+    *reinterpret_cast<uint2*>(orow + c) = h16_pack4<DT>(ox, oy, oz, ow);
+  }
+}
+
+template <int DT>
+static int launch_ln_h16(hipStream_t stream, const float* x, u16* out, int TP, int d, const float* gain, const float* shift,
+                         long row_stride, const int32_t* token_row, int add_one) {
+  if (TP <= 0) return RAP_OK;
+  if (d % 256 != 0 || d > 1024) return RAP_ERR_INVALID;
+  dim3 grid((TP + 3) / 4), block(256);
+  switch (d / 256) {
+    case 1: hipLaunchKernelGGL((layernorm_h16_kernel<1, DT>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
+    case 2: hipLaunchKernelGGL((layernorm_h16_kernel<2, DT>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
+    case 3: hipLaunchKernelGGL((layernorm_h16_kernel<3, DT>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
+    default: hipLaunchKernelGGL((layernorm_h16_kernel<4, DT>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
+  }
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
+int launch_layernorm_mod_h16(hipStream_t stream, int dtype, const float* x, u16* out, int TP, int d, const float* mod,
+                             long mod_stride, const int32_t* token_row) {
+  if (dtype == RAP_DT_BF16) return launch_ln_h16<RAP_DT_BF16>(stream, x, out, TP, d, mod, mod + d, mod_stride, token_row, 1);
+  if (dtype == RAP_DT_F16) return launch_ln_h16<RAP_DT_F16>(stream, x, out, TP, d, mod, mod + d, mod_stride, token_row, 1);
+  return RAP_ERR_INVALID;
+}
+int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const float* x, u16* out, int TP, int d, const float* gain,
+                                const float* shift) {
+  if (dtype == RAP_DT_BF16) return launch_ln_h16<RAP_DT_BF16>(stream, x, out, TP, d, gain, shift, 0, nullptr, 0);
+  if (dtype == RAP_DT_F16) return launch_ln_h16<RAP_DT_F16>(stream, x, out, TP, d, gain, shift, 0, nullptr, 0);
+  return RAP_ERR_INVALID;
+}
+
+// 8 lanes per (plane, head, token) row of 64 values (16 bytes per lane); 32 rows per 256-thread block.
+template <int DT>
+__global__ __launch_bounds__(256) void qknorm_h16_kernel(u16* __restrict__ qk, long rows_per_plane, int TP, int heads,
+                                                         const float* __restrict__ gamma_q, const float* __restrict__ gamma_k) {
+  const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (row >= 2 * rows_per_plane) return;
+  const int sub = threadIdx.x & 7;
+  const int plane = row >= rows_per_plane ? 1 : 0;
+  const long r = row - (long)plane * rows_per_plane;
+  const int head = (int)(r / TP);
+  u16* p = qk + row * 64 + sub * 8;
+  float v[8];
+  h16_unpack8<DT>(*reinterpret_cast<const uint4*>(p), v);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i] * v[i];
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float nrm = fmaxf(sqrtf(s), 1e-12f);
+  const float* g = (plane ? gamma_k : gamma_q) + head * 64 + sub * 8;
+  const float4 g0 = *reinterpret_cast<const float4*>(g);
+  const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
+  const typename H16<DT>::T8 o8 = h16_pack8<DT>(v[0] / nrm * g0.x * 8.0f, v[1] / nrm * g0.y * 8.0f, v[2] / nrm * g0.z * 8.0f,
+                                                v[3] / nrm * g0.w * 8.0f, v[4] / nrm * g1.x * 8.0f, v[5] / nrm * g1.y * 8.0f,
+                                                v[6] / nrm * g1.z * 8.0f, v[7] / nrm * g1.w * 8.0f);
+  *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, o8);
+}
+
+int launch_qknorm_h16(hipStream_t stream, int dtype, u16* qk, int TP, int heads, const float* gamma_q, const float* gamma_k) {
+  if (TP <= 0) return RAP_OK;
+  const long rows_per_plane = (long)heads * TP;
+  const long nblk = (2 * rows_per_plane + 31) / 32;
+  if (dtype == RAP_DT_BF16)
+    hipLaunchKernelGGL(qknorm_h16_kernel<RAP_DT_BF16>, dim3((unsigned)nblk), dim3(256), 0, stream, qk, rows_per_plane, TP, heads, gamma_q, gamma_k);
+  else if (dtype == RAP_DT_F16)
+    hipLaunchKernelGGL(qknorm_h16_kernel<RAP_DT_F16>, dim3((unsigned)nblk), dim3(256), 0, stream, qk, rows_per_plane, TP, heads, gamma_q, gamma_k);
+  else
+    return RAP_ERR_INVALID;
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}

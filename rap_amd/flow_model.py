@@ -45,7 +45,8 @@ class PointCloudDiT:
     def __init__(self, in_dim: int, out_dim: int, embed_dim: int, num_layers: int, num_heads: int,
                  dropout_rate: float = 0.0, softcap: float = 0.0, qk_norm: bool = True, attn_dtype: str = "float16",
                  final_mlp_act=None, max_points_per_part: int = 500, max_points_per_batch: int = 40000,
-                 scale_emb_on: bool = True, local_feat_concat_on: bool = True, local_feat_dim: int = 0):
+                 scale_emb_on: bool = True, local_feat_concat_on: bool = True, local_feat_dim: int = 0,
+                 compute_dtype: str | None = "float32"):
         if in_dim != 0:
             raise NotImplementedError("in_dim != 0 (PTv3 encoder latent) is off in every shipped config (rap_12.yaml:17)")
         if out_dim != 3:
@@ -62,9 +63,15 @@ class PointCloudDiT:
         self.in_dim, self.out_dim, self.embed_dim = in_dim, out_dim, embed_dim
         self.num_layers, self.num_heads, self.local_feat_dim = num_layers, num_heads, local_feat_dim
         self.max_points_per_part, self.max_points_per_batch = max_points_per_part, max_points_per_batch
-        # The kernels compute attention (and everything else) in fp32, i.e. at or above any attn_dtype the
-        # reference accepts; the string is kept for interface parity.
+        # attn_dtype is kept for interface parity.  What selects the arithmetic of the transformer blocks is
+        # compute_dtype (an extension): "float32" (default) = exact-fp32 MFMA everywhere, i.e. at or above any
+        # attn_dtype the reference accepts; "bfloat16" / "float16" = 16-bit MFMA GEMMs + attention with fp32
+        # accumulation (what the reference's GPU inference runs under Lightning "16-mixed" autocast,
+        # trainer/infer.yaml:6); None = follow torch autocast at call time, like the reference's nn.Linear layers do.
         self.attn_dtype = attn_dtype
+        if compute_dtype is not None and compute_dtype not in _lib.DTYPES:
+            raise ValueError(f"Unsupported compute_dtype: {compute_dtype}")
+        self.compute_dtype = compute_dtype
         self.cfg = dict(embed_dim=embed_dim, num_layers=num_layers, num_heads=num_heads, local_feat_dim=local_feat_dim)
         self._spec = weight_spec(self.cfg)
         self._sd: dict[str, torch.Tensor] | None = None
@@ -143,6 +150,24 @@ class PointCloudDiT:
             torch.cuda.current_stream(device).synchronize()   # blob may be freed after this
         self._handle, self._device = handle, device
 
+    def _dtype_code(self) -> int:
+        if self.compute_dtype is not None:
+            return _lib.DTYPES[self.compute_dtype]
+        if torch.is_autocast_enabled("cuda"):
+            return {torch.bfloat16: 1, torch.float16: 2}.get(torch.get_autocast_dtype("cuda"), 0)
+        return 0
+
+    def _activate(self, device: torch.device):
+        """Model resident on `device` with the transformer-block arithmetic type selected; returns the handle."""
+        self._ensure_model(device)
+        lib = _lib.load()
+        code = self._dtype_code()
+        if lib.rap_model_compute_dtype(self._handle) != code:
+            with torch.cuda.device(device):
+                _lib.check(lib.rap_model_set_compute_dtype(self._handle, code, _lib.current_stream(device)),
+                           "rap_model_set_compute_dtype")
+        return self._handle
+
     # ---- forward -------------------------------------------------------------------------------
     def forward(self, x, timesteps, cond_coord, local_features, latent_features, scales, anchor_indices,
                 cu_seqlens_batch, cu_seqlens_part, return_transformer_features: bool = False):
@@ -151,7 +176,7 @@ class PointCloudDiT:
             raise NotImplementedError("latent_features must be None (in_dim == 0)")
         _require_cuda(x, "x")
         device = x.device
-        self._ensure_model(device)
+        self._activate(device)
         lib = _lib.load()
         TP = x.shape[0]
         B = cu_seqlens_batch.shape[0] - 1

@@ -60,7 +60,7 @@ class RectifiedPointFlow:
         S = int(self.inference_sampling_steps)
         x_1 = torch.randn_like(cond) if x_1 is None else _f32c(x_1.to(device))    # modeling.py:664
         model = self.flow_model
-        model._ensure_model(device)
+        model._activate(device)
         lib = _lib.load()
         traj_x0 = torch.empty((S, TP, 3), dtype=torch.float32, device=device)     # sampler.py:47-49
         traj_xt = torch.empty((S, TP, 3), dtype=torch.float32, device=device)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: parity tests, per-kernel variant sweep, the bench line, and a rocprofv3 kernel trace of the
 # same bench command.  Usage (from the repo root, through gpurun):  bash scripts/gpu_run.sh <tag> [stages...]
-# stages: tests sweep bench prof pmc   (default: all but pmc)
+# stages: tests sweep h16 bench prof pmc   (default: tests sweep bench prof); PYTEST_ARGS overrides "-x -q"
 set -u
 TAG=${1:-run}; shift || true
 STAGES=${*:-"tests sweep bench prof"}
@@ -11,9 +11,18 @@ export TMPDIR=/tmp
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 
 if has tests; then
-  timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+  timeout 1500 python -m pytest tests -m gpu ${PYTEST_ARGS:--x -q} > "$OUT/pytest_gpu.log" 2>&1
   echo "pytest exit $?" >> "$OUT/pytest_gpu.log"
-  tail -5 "$OUT/pytest_gpu.log"
+  grep -E "^(FAILED|ERROR)|passed|failed" "$OUT/pytest_gpu.log" | tail -40
+fi
+if has h16; then
+  : > "$OUT/kernel_bench_h16.jsonl"
+  for v in 0 1 2; do
+    timeout 300 python scripts/kernel_bench.py --dtype bfloat16 --only gemm --h16-gemm-variant $v >> "$OUT/kernel_bench_h16.jsonl" 2>> "$OUT/kernel_bench.err"
+  done
+  timeout 300 python scripts/kernel_bench.py --dtype bfloat16 --only attention >> "$OUT/kernel_bench_h16.jsonl" 2>> "$OUT/kernel_bench.err"
+  timeout 300 python scripts/kernel_bench.py --dtype float16 >> "$OUT/kernel_bench_h16.jsonl" 2>> "$OUT/kernel_bench.err"
+  cat "$OUT/kernel_bench_h16.jsonl"; tail -5 "$OUT/kernel_bench.err"
 fi
 if has sweep; then
   : > "$OUT/kernel_bench.jsonl"

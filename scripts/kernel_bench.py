@@ -31,6 +31,72 @@ def timeit(fn, iters=5, warm=2):
     return a.elapsed_time(b) / iters * 1e-3
 
 
+def bench_h16(args, lib, dev, st, TP, d, H, g):
+    """16-bit MFMA twins at the same shapes; peak = 2.5 PFLOP/s dense bf16/fp16 (MI355X_MICROARCH.md)."""
+    dt = _lib.DTYPES[args.dtype]
+    tdt = {1: torch.bfloat16, 2: torch.float16}[dt]
+    PEAK = 2500.0
+    rows = []
+    if args.h16_gemm_variant >= 0:
+        assert lib.rap_set_tuning(2, args.h16_gemm_variant) == 0
+    nblk = (TP + 255) // 256 * 256 // 64
+
+    def gemm_case(name, epi, N, K, out_half, Cw=None, heads=0):
+        A = torch.randn(TP, K, device=dev, generator=g).to(tdt)
+        W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(tdt)
+        bias = torch.randn(N, device=dev, generator=g)
+        Cw = Cw or N
+        C = torch.zeros(TP * Cw, device=dev, dtype=tdt if out_half else torch.float32)
+        vt = torch.zeros(H * nblk * 64 * 64, device=dev, dtype=tdt) if epi == 4 else None
+        resid = C if epi == 1 else None
+        def fn():
+            rc = lib.rap_gemm_h16(dt, epi, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(C), Cw, TP, N, K, _lib.ptr(bias),
+                                  _lib.ptr(resid), Cw if epi == 1 else 0, heads, _lib.ptr(vt), nblk if epi == 4 else 0, st())
+            assert rc == 0, rc
+        t = timeit(fn)
+        fl = 2.0 * TP * N * K
+        rows.append({"kernel": f"gemm_h16[{name}]", "dtype": args.dtype, "variant": args.h16_gemm_variant, "M": TP, "N": N, "K": K,
+                     "ms": t * 1e3, "tflops": fl / t / 1e12, "frac_of_2500TF": fl / t / 1e12 / PEAK})
+
+    if args.only in ("", "gemm"):
+        gemm_case("qkv split + V^T", 4, 3 * d, d, True, Cw=2 * d, heads=H)
+        gemm_case("out_proj +bias +resid (fp32 out)", 1, d, d, False)
+        gemm_case("ff1 GEGLU", 3, 8 * d, d, True, Cw=4 * d)
+        gemm_case("ff2 +bias +resid (fp32 out)", 1, d, 4 * d, False)
+    if args.only in ("", "attention"):
+        qk = torch.nn.functional.normalize(torch.randn(2, H, TP, 64, device=dev, generator=g), dim=-1) * 8
+        qk = qk.to(tdt)
+        vt = torch.randn(H, nblk, 64, 64, device=dev, generator=g).to(tdt)
+        out = torch.empty(TP, d, device=dev, dtype=tdt)
+        for name, L in (("per part", args.points), ("per sample", args.points * args.views)):
+            cu = torch.arange(0, TP + 1, L, dtype=torch.int32, device=dev)
+            nseg = cu.numel() - 1
+            ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, nseg))
+            def fn():
+                rc = lib.rap_attention_h16(dt, _lib.ptr(qk), _lib.ptr(vt), nblk, _lib.ptr(cu), nseg, _lib.ptr(out), TP, H,
+                                           _lib.ptr(ws), ws.numel(), st())
+                assert rc == 0, rc
+            t = timeit(fn, iters=1 if args.pmc else 5, warm=0 if args.pmc else 2)
+            fl = 4.0 * H * 64 * L * TP
+            rows.append({"kernel": f"attention_h16[{name} L={L}]", "dtype": args.dtype, "ms": t * 1e3, "tflops": fl / t / 1e12,
+                         "frac_of_2500TF": fl / t / 1e12 / PEAK})
+    if args.only == "":
+        x = torch.randn(TP, d, device=dev, generator=g); y = torch.empty(TP, d, device=dev, dtype=tdt)
+        mod = torch.randn(2 * d, device=dev, generator=g)
+        def mem_case(name, fn, nbytes):
+            t = timeit(fn, iters=10, warm=2)
+            rows.append({"kernel": name, "dtype": args.dtype, "ms": t * 1e3, "algorithmic_GB": nbytes / 1e9, "GBps": nbytes / t / 1e9,
+                         "frac_of_8TBps": nbytes / t / 8e12})
+        mem_case("layernorm_mod_h16 (fp32 in, 16-bit out)",
+                 lambda: lib.rap_layernorm_mod_h16(dt, _lib.ptr(x), _lib.ptr(y), TP, d, _lib.ptr(mod), 0, _lib.ptr(None), st()), TP * d * 6)
+        qk2 = torch.randn(2, H, TP, 64, device=dev, generator=g).to(tdt)
+        gq = torch.ones(H, 64, device=dev)
+        mem_case("qknorm_h16 (q,k in place)", lambda: lib.rap_qknorm_h16(dt, _lib.ptr(qk2), TP, H, _lib.ptr(gq), _lib.ptr(gq), st()),
+                 2 * TP * d * 2 * 2)
+    for r in rows:
+        print(json.dumps(r))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
@@ -40,6 +106,8 @@ def main():
     ap.add_argument("--pmc", action="store_true", help="one launch per kernel, no warm-up (for rocprofv3 --pmc passes)")
     ap.add_argument("--gemm-variant", type=int, default=-1)
     ap.add_argument("--attn-variant", type=int, default=-1)
+    ap.add_argument("--dtype", default="float32", help="float32 | bfloat16 | float16 (16-bit: GEMM / attention / LN / qknorm twins)")
+    ap.add_argument("--h16-gemm-variant", type=int, default=-1)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -52,6 +120,8 @@ def main():
     d, H = 512, 8
     g = torch.Generator(device=dev).manual_seed(0)
     rows = []
+    if args.dtype != "float32":
+        return bench_h16(args, lib, dev, st, TP, d, H, g)
 
     def gemm_case(name, epi, N, K, ldc=None, heads=0):
         A = torch.randn(TP, K, device=dev, generator=g)

@@ -1,0 +1,418 @@
+"""GPU tests of the reduced-precision (bf16 / fp16 MFMA, fp32 accumulate) twins of the transformer-block kernels,
+through the C ABI.
+
+What is compared with what:
+  * kernel level: the kernel on 16-bit operands vs an fp64 evaluation of the same formula ON THE SAME ROUNDED
+    OPERANDS -- the difference is accumulation order plus the rounding of 16-bit outputs, so the bounds are a few
+    ulps of the output type (bf16 ulp 2^-8 relative, fp16 2^-11) or fp32-class for fp32 outputs;
+  * model level: velocity / sampling results vs the fp32 golden vectors of the reference; north_star asks for a
+    MEASURED deviation for the bf16 path, not a fixed bar -- the asserted bounds below are
+    what was measured on MI355X with margin, and the measured values are printed.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import rap_amd
+from conftest import load_golden
+from oracle import rap_oracle as O
+from rap_amd import _lib, synthetic as S
+from rap_amd.flow_model import workspace
+
+pytestmark = pytest.mark.gpu
+
+TORCH_DT = {1: torch.bfloat16, 2: torch.float16}
+ULP = {1: 2.0 ** -8, 2: 2.0 ** -11}     # largest relative error of one round-to-nearest into the type
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+def stream(dev):
+    return _lib.current_stream(dev)
+
+
+def vt_pos(t):
+    return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+
+
+def to_h(x, dt):
+    """fp32 tensor -> rounded 16-bit tensor (torch's RNE == v_cvt_pk_*)"""
+    return x.to(TORCH_DT[dt])
+
+
+def gemm_h(lib, dev, dt, epi, A, W, C, M, N, K, bias=None, resid=None, heads=0, vt=None, vt_nblk=0, ldc=None):
+    rc = lib.rap_gemm_h16(dt, epi, _lib.ptr(A), A.stride(0), _lib.ptr(W), W.stride(0), _lib.ptr(C), ldc if ldc else N, M, N, K,
+                          _lib.ptr(bias), _lib.ptr(resid), resid.stride(0) if resid is not None else 0, heads, _lib.ptr(vt),
+                          vt_nblk, stream(dev))
+    _lib.check(rc, "rap_gemm_h16")
+    torch.cuda.synchronize()
+
+
+@pytest.fixture(params=[0, 1, 2], ids=["tile128x128", "tile256x256", "tile256x128"])
+def tile_variant(request, lib):
+    assert lib.rap_set_tuning(2, request.param) == 0
+    yield request.param
+    assert lib.rap_set_tuning(2, 1) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# conversion, GEMM
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [1, 2])
+def test_convert_is_round_to_nearest_even(lib, dev, dt):
+    g = torch.Generator().manual_seed(1)
+    x = torch.cat([torch.randn(4096, generator=g) * 10.0 ** torch.randint(-6, 5, (4096,), generator=g).float(),
+                   torch.tensor([0.0, -0.0, 1.0, 1.00390625, 1.001953125, 65504.0, 1e-8, -3.0])])
+    x = x[: x.numel() // 4 * 4].contiguous()
+    out = torch.empty(x.numel(), dtype=torch.int16, device=dev)
+    _lib.check(lib.rap_convert_h16(dt, _lib.ptr(x.to(dev)), _lib.ptr(out), x.numel(), stream(dev)), "convert")
+    torch.cuda.synchronize()
+    ref = to_h(x, dt).view(torch.int16)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(1, 256, 64), (100, 256, 128), (300, 512, 512), (1000, 512, 2048), (257, 1536, 512)])
+def test_gemm_h16_fp32_out_matches_fp64_on_rounded_operands(lib, dev, dt, tile_variant, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = to_h(torch.randn(M, K, generator=g), dt); W = to_h(torch.randn(N, K, generator=g) / K ** 0.5, dt)
+    b = torch.randn(N, generator=g); h = torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().T + b.double()
+    C = torch.full((M, N), float("nan"), device=dev)
+    gemm_h(lib, dev, dt, 1, A.to(dev), W.to(dev), C, M, N, K, bias=b.to(dev))
+    # exact products (16-bit x 16-bit fits fp32), fp32 accumulation of K O(1/sqrt(K)) terms
+    assert (C.cpu().double() - ref).abs().max().item() < 2e-5
+    C = h.to(dev).clone()
+    gemm_h(lib, dev, dt, 1, A.to(dev), W.to(dev), C, M, N, K, bias=b.to(dev), resid=C)      # in place
+    assert (C.cpu().double() - (ref + h.double())).abs().max().item() < 2e-5
+    # 16-bit output
+    Ch = torch.full((M, N), float("nan"), dtype=TORCH_DT[dt], device=dev)
+    gemm_h(lib, dev, dt, 0, A.to(dev), W.to(dev), Ch, M, N, K, bias=b.to(dev))
+    err = (Ch.cpu().double() - ref).abs() / (ref.abs() + 1e-3)
+    assert err.max().item() < ULP[dt] * 1.01 + 1e-6, err.max().item()     # one rounding into the output type
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_gemm_h16_is_transpose_safe_identity_check(lib, dev, dt, tile_variant):
+    """A = I with an asymmetric W catches a swapped row/col in the MFMA C/D mapping and a wrong k-slot order."""
+    K = 256; N = 256; M = 256
+    A = to_h(torch.eye(M, K), dt)
+    W = to_h((torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 64.0, dt)     # exactly representable
+    C = torch.empty((M, N), device=dev)
+    gemm_h(lib, dev, dt, 1, A.to(dev), W.to(dev), C, M, N, K)
+    assert torch.equal(C.cpu(), W.float().T.contiguous())
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_gemm_h16_geglu(lib, dev, dt, tile_variant):
+    g = torch.Generator().manual_seed(4)
+    M, K, inner = 200, 128, 256
+    A = torch.randn(M, K, generator=g); W = torch.randn(2 * inner, K, generator=g) / K ** 0.5; b = torch.randn(2 * inner, generator=g)
+    Wd, bd = W.to(dev), b.to(dev)
+    Wp, bp = torch.empty_like(Wd), torch.empty_like(bd)
+    _lib.check(lib.rap_geglu_interleave(_lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(Wp), _lib.ptr(bp), inner, K, stream(dev)), "interleave")
+    Ah, Wh, Wph = to_h(A, dt), to_h(W, dt), to_h(Wp.cpu(), dt)
+    u = Ah.double() @ Wh.double().T + b.double()
+    ref = u[:, :inner] * F.gelu(u[:, inner:])
+    C = torch.full((M, inner), float("nan"), dtype=TORCH_DT[dt], device=dev)
+    gemm_h(lib, dev, dt, 3, Ah.to(dev), Wph.to(dev), C, M, 2 * inner, K, bias=bp, ldc=inner)
+    err = (C.cpu().double() - ref).abs() / (ref.abs() + 1e-2)
+    assert err.max().item() < 1.2 * ULP[dt], err.max().item()
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("M", [150, 256, 1000])
+def test_gemm_h16_qkv_split_and_transposed_v(lib, dev, dt, tile_variant, M):
+    g = torch.Generator().manual_seed(5)
+    H, K = 4, 128                      # N = 768: a multiple of every tile width
+    N = 3 * H * 64
+    A = to_h(torch.randn(M, K, generator=g), dt); W = to_h(torch.randn(N, K, generator=g) / K ** 0.5, dt)
+    ref = (A.double() @ W.double().T).reshape(M, 3, H, 64).permute(1, 2, 0, 3)   # [3][H][M][64]
+    nblk = (M + 255) // 256 * 256 // 64
+    qk = torch.full((2, H, M, 64), float("nan"), dtype=TORCH_DT[dt], device=dev)
+    vt = torch.full((H, nblk, 64, 64), float("nan"), dtype=TORCH_DT[dt], device=dev)
+    gemm_h(lib, dev, dt, 4, A.to(dev), W.to(dev), qk, M, N, K, heads=H, vt=vt, vt_nblk=nblk)
+    err = (qk.cpu().double() - ref[:2]).abs() / (ref[:2].abs() + 1e-2)
+    assert err.max().item() < 1.01 * ULP[dt], err.max().item()
+    # vt[h][t >> 6][d][vt_pos(t & 63)] == v[h][t][d]; padding rows of every M tile that was touched are zero
+    vtc = vt.cpu().double()
+    t = torch.arange(M)
+    got = vtc[:, t >> 6, :, vt_pos(t & 63)]            # (M, H, 64): advanced indices first
+    want = ref[2].permute(1, 0, 2)                     # (M, H, 64)
+    errv = (got - want).abs() / (want.abs() + 1e-2)
+    assert errv.max().item() < 1.01 * ULP[dt], errv.max().item()
+    m_tiles = {0: 128, 1: 256, 2: 256}[tile_variant]
+    tp = torch.arange(M, (M + m_tiles - 1) // m_tiles * m_tiles)
+    if tp.numel():
+        pad = vtc[:, tp >> 6, :, vt_pos(tp & 63)]
+        assert torch.equal(pad, torch.zeros_like(pad))
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_gemm_h16_full_size_linearity_property(lib, dev, dt):
+    """BASELINE configs[1]/[2] row count: C(A1 + A2) == C(A1) + C(A2) when A1, A2 have disjoint supports (exact in any
+    arithmetic: every product is either x*w or 0*w), plus agreement with the exact-fp32 GEMM on the same rounded data."""
+    M, N, K = 262144, 512, 512
+    g = torch.Generator(device=dev).manual_seed(0)
+    A = torch.randn(M, K, device=dev, generator=g); W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    Ah, Wh = to_h(A, dt), to_h(W, dt)
+    mask = (torch.rand(M, K, device=dev, generator=g) < 0.5)
+    A1, A2 = torch.where(mask, Ah, torch.zeros_like(Ah)), torch.where(mask, torch.zeros_like(Ah), Ah)
+    C, C1, C2, Cf = (torch.empty(M, N, device=dev) for _ in range(4))
+    gemm_h(lib, dev, dt, 1, Ah, Wh, C, M, N, K)
+    gemm_h(lib, dev, dt, 1, A1, Wh, C1, M, N, K)
+    gemm_h(lib, dev, dt, 1, A2, Wh, C2, M, N, K)
+    assert (C - (C1 + C2)).abs().max().item() < 2e-5
+    Af, Wf = Ah.float(), Wh.float()
+    _lib.check(lib.rap_gemm_f32(0, _lib.ptr(Af), K, _lib.ptr(Wf), K, _lib.ptr(Cf), N, M, N, K, _lib.ptr(None), _lib.ptr(None), 0,
+                                _lib.ptr(None), _lib.ptr(None), 0, stream(dev)), "gemm_f32")
+    torch.cuda.synchronize()
+    assert (C - Cf).abs().max().item() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def pack_qkv(q, k, v, dt, dev):
+    """q,k,v (H,TP,64) fp32 -> (qk [2][H][TP][64], vt [H][nblk][64][64], nblk) as the QKV GEMM epilogue writes them."""
+    H, TP, _ = q.shape
+    nblk = (TP + 255) // 256 * 256 // 64
+    qk = torch.stack([to_h(q, dt), to_h(k, dt)]).contiguous().to(dev)
+    vt = torch.zeros((H, nblk, 64, 64), dtype=TORCH_DT[dt])
+    t = torch.arange(TP)
+    vt[:, t >> 6, :, vt_pos(t & 63)] = to_h(v, dt).permute(1, 0, 2)
+    return qk, vt.to(dev), nblk
+
+
+def run_attention_h(lib, dev, dt, q, k, v, cu):
+    H, TP, _ = q.shape
+    qk, vt, nblk = pack_qkv(q, k, v, dt, dev)
+    cu_d = cu.to(device=dev, dtype=torch.int32)
+    nseg = cu.numel() - 1
+    ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, nseg))
+    out = torch.full((TP, H * 64), float("nan"), dtype=TORCH_DT[dt], device=dev)
+    rc = lib.rap_attention_h16(dt, _lib.ptr(qk), _lib.ptr(vt), nblk, _lib.ptr(cu_d), nseg, _lib.ptr(out), TP, H, _lib.ptr(ws),
+                               ws.numel(), stream(dev))
+    _lib.check(rc, "rap_attention_h16")
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def attention_ref64(q, k, v, cu, dt):
+    """fp64 softmax attention per segment on the ROUNDED operands; returns (TP, H*64) and the per-row bound scale."""
+    qh, kh, vh = (to_h(x, dt).double() for x in (q, k, v))
+    H, TP, _ = q.shape
+    out = torch.zeros(TP, H * 64, dtype=torch.float64)
+    for a, b in zip(cu[:-1].tolist(), cu[1:].tolist()):
+        if b == a:
+            continue
+        s = qh[:, a:b] @ kh[:, a:b].transpose(1, 2) / 8.0
+        p = torch.softmax(s, dim=-1)
+        out[a:b] = (p @ vh[:, a:b]).permute(1, 0, 2).reshape(b - a, H * 64)
+    return out
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("H", [1, 8])
+def test_attention_h16_ragged_segments(lib, dev, dt, H):
+    g = torch.Generator().manual_seed(11 + H)
+    lens = [1, 63, 64, 65, 300, 0, 257, 1000, 31, 512]          # unaligned starts, empty segment, multi-block segments
+    cu = torch.tensor([0] + lens).cumsum(0)
+    TP = int(cu[-1])
+    q = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8 * (0.5 + torch.rand(H, 1, 64, generator=g))
+    k = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8 * (0.5 + torch.rand(H, 1, 64, generator=g))
+    v = torch.randn(H, TP, 64, generator=g)
+    out = run_attention_h(lib, dev, dt, q, k, v, cu)
+    ref = attention_ref64(q, k, v, cu, dt)
+    assert not torch.isnan(out.float()).any()
+    err = (out.double() - ref).abs().max().item()
+    # P is rounded to the operand type before P*V (1 ulp relative per probability, signs of v random) and the output is
+    # rounded once more: a few ulps of max|v| ~ 4
+    assert err < 8 * ULP[dt], err
+    print(f"attention dt={dt} H={H}: max abs err vs fp64 {err:.2e}")
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_attention_h16_single_token_segments_return_v(lib, dev, dt):
+    g = torch.Generator().manual_seed(3)
+    TP, H = 130, 2
+    q, k, v = (torch.randn(H, TP, 64, generator=g) for _ in range(3))
+    out = run_attention_h(lib, dev, dt, q, k, v, torch.arange(TP + 1))
+    want = to_h(v, dt).permute(1, 0, 2).reshape(TP, H * 64)
+    assert torch.equal(out, want)        # softmax over one key is exactly 1
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_attention_h16_sharp_softmax_and_late_maximum(lib, dev, dt):
+    """One key dominates, placed in the LAST tile (forces the running-max rescale on the final step) and the first tile."""
+    g = torch.Generator().manual_seed(9)
+    H, L = 2, 700
+    for spike_at in (L - 1, 0, 350):
+        q = torch.randn(H, L, 64, generator=g); k = torch.randn(H, L, 64, generator=g) * 0.1; v = torch.randn(H, L, 64, generator=g)
+        k[:, spike_at] = q[:, 5] * 4.0      # q5 . k_spike / 8 is huge for query 5, large for the others' projections
+        out = run_attention_h(lib, dev, dt, q, k, v, torch.tensor([0, L]))
+        ref = attention_ref64(q, k, v, torch.tensor([0, L]), dt)
+        err = (out.double() - ref).abs().max().item()
+        assert err < 8 * ULP[dt], (spike_at, err)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_attention_h16_full_size_agrees_with_fp32_kernel(lib, dev, dt):
+    """BASELINE geometry (segments of 4096 and 8192 tokens, 8 heads): the 16-bit kernel vs the exact-fp32 kernel on the
+    same rounded q,k,v; rows of the implied softmax sum to one (v = ones -> out = 1)."""
+    H, L, nseg = 8, 4096, 4
+    TP = L * nseg
+    g = torch.Generator().manual_seed(21)
+    q = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8
+    k = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8
+    v = torch.randn(H, TP, 64, generator=g)
+    for seg in (L, 2 * L):
+        cu = torch.arange(0, TP + 1, seg)
+        out = run_attention_h(lib, dev, dt, q, k, v, cu)
+        qkv32 = torch.stack([to_h(q, dt).float(), to_h(k, dt).float(), to_h(v, dt).float()]).contiguous().to(dev)
+        o32 = torch.empty(TP, H * 64, device=dev)
+        ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, cu.numel() - 1))
+        _lib.check(lib.rap_attention_f32(_lib.ptr(qkv32), _lib.ptr(cu.to(device=dev, dtype=torch.int32)), cu.numel() - 1, _lib.ptr(o32),
+                                         TP, H, _lib.ptr(ws), ws.numel(), stream(dev)), "attention_f32")
+        torch.cuda.synchronize()
+        err = (out.float() - o32.cpu()).abs().max().item()
+        assert err < 4 * ULP[dt], (seg, err)
+        ones = run_attention_h(lib, dev, dt, q, k, torch.ones_like(v), cu)
+        assert (ones.float() - 1.0).abs().max().item() <= 2 * ULP[dt]
+
+
+# ---------------------------------------------------------------------------------------------
+# normalisation kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [1, 2])
+def test_layernorm_h16(lib, dev, dt):
+    g = torch.Generator().manual_seed(2)
+    TP, d, rows = 777, 512, 3
+    x = torch.randn(TP, d, generator=g) * 3 + 0.5
+    mod = torch.randn(rows, 4, 2 * d, generator=g) * 0.3
+    token_row = torch.randint(0, rows, (TP,), generator=g, dtype=torch.int32)
+    out = torch.empty(TP, d, dtype=TORCH_DT[dt], device=dev)
+    md = mod.to(dev)
+    j = 2
+    rc = lib.rap_layernorm_mod_h16(dt, _lib.ptr(x.to(dev)), _lib.ptr(out), TP, d, _lib.ptr(md[0, j]), 4 * 2 * d,
+                                   _lib.ptr(token_row.to(dev)), stream(dev))
+    _lib.check(rc, "ln_mod_h16"); torch.cuda.synchronize()
+    xn = F.layer_norm(x.double(), (d,), eps=1e-5)
+    ref = xn * (1 + mod[token_row.long(), j, :d].double()) + mod[token_row.long(), j, d:].double()
+    err = (out.cpu().double() - ref).abs() / (ref.abs() + 1e-2)
+    assert err.max().item() < 1.01 * ULP[dt] + 1e-4, err.max().item()
+    gain, shift = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    rc = lib.rap_layernorm_affine_h16(dt, _lib.ptr(x.to(dev)), _lib.ptr(out), TP, d, _lib.ptr(gain.to(dev)), _lib.ptr(shift.to(dev)),
+                                      stream(dev))
+    _lib.check(rc, "ln_affine_h16"); torch.cuda.synchronize()
+    ref = xn * gain.double() + shift.double()
+    err = (out.cpu().double() - ref).abs() / (ref.abs() + 1e-2)
+    assert err.max().item() < 1.01 * ULP[dt] + 1e-4, err.max().item()
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_qknorm_h16(lib, dev, dt):
+    g = torch.Generator().manual_seed(6)
+    TP, H = 301, 8
+    qk = to_h(torch.randn(2, H, TP, 64, generator=g) * 2, dt)
+    gq, gk = torch.rand(H, 64, generator=g) + 0.5, torch.rand(H, 64, generator=g) + 0.5
+    buf = qk.to(dev).clone()
+    _lib.check(lib.rap_qknorm_h16(dt, _lib.ptr(buf), TP, H, _lib.ptr(gq.to(dev)), _lib.ptr(gk.to(dev)), stream(dev)), "qknorm_h16")
+    torch.cuda.synchronize()
+    x = qk.double()
+    ref = x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12) * torch.stack([gq, gk])[:, :, None, :].double() * 8.0
+    err = (buf.cpu().double() - ref).abs() / (ref.abs() + 1e-2)
+    assert err.max().item() < 1.01 * ULP[dt] + 1e-4, err.max().item()
+
+
+# ---------------------------------------------------------------------------------------------
+# model level: measured deviation of the 16-bit paths from the fp32 reference goldens
+# ---------------------------------------------------------------------------------------------
+_MODELS = {}
+
+
+def get_model(num_layers, seed, dev, compute_dtype):
+    key = (num_layers, seed, compute_dtype)
+    if key not in _MODELS:
+        cfg = dict(S.RAP_12); cfg["num_layers"] = num_layers
+        sd = S.make_weights(cfg, seed)
+        m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=num_layers, num_heads=8, local_feat_dim=32,
+                                  compute_dtype=compute_dtype)
+        m.load_state_dict(sd)
+        _MODELS[key] = (cfg, sd, m.to(dev))
+    return _MODELS[key]
+
+
+# bounds = measured worst case on MI355X x ~3 (the measured numbers are printed; DESIGN.md section 2 quotes them)
+FWD_REL_BOUND = {"bfloat16": 6e-2, "float16": 1e-2}
+
+
+@pytest.mark.parametrize("cdt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("name", ["l2_ragged_rigid", "l2_emptypart_rigid", "l12_small_rigid", "l12_pair512_free"])
+def test_forward_h16_deviation_from_fp32_golden(name, cdt, dev):
+    g, inp = load_golden(name)
+    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev, cdt)
+    cu_b, cu_p = O.prepare_cu_seqlens(inp)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    out = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
+                local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev), return_transformer_features=True)
+    v_ref = torch.from_numpy(g["fwd_velocity"])
+    v = out["velocity"].cpu()
+    assert torch.isfinite(v).all()
+    rel = (v - v_ref).abs().max().item() / v_ref.abs().max().item()
+    rms = ((v - v_ref).pow(2).mean().sqrt() / v_ref.pow(2).mean().sqrt()).item()
+    print(f"{name} {cdt}: velocity max-abs/max {rel:.3e}  rel-rms {rms:.3e}")
+    assert rel < FWD_REL_BOUND[cdt], rel
+
+
+@pytest.mark.parametrize("cdt", ["bfloat16", "float16"])
+def test_sample_h16_deviation_and_invariants(cdt, dev):
+    """Whole sampling call in 16-bit arithmetic on a golden case with rigidity forcing: the deviation of the registered
+    cloud / poses from the fp32 reference is REPORTED and loosely bounded; the invariants that do not depend on
+    precision are asserted exactly: with rigidity forcing the last x_t is a rigid image of cond, rotations are proper."""
+    g, inp = load_golden("l12_small_rigid")
+    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev, cdt)
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=int(g["num_steps"]), rigidity_forcing=True)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    res = flow.sample_rectified_flow(d, None, x_1=d["x_1"])
+    R, t = flow.last_poses
+    x0 = res["end_point_trajectory"].cpu(); x0_ref = torch.from_numpy(g["end_point_trajectory"])
+    assert torch.isfinite(x0).all()
+    e0 = (x0[-1] - x0_ref[-1]).abs().max().item()
+    eR = torch.linalg.matrix_norm(R.cpu() - torch.from_numpy(g["R"])).max().item()
+    print(f"l12_small_rigid {cdt}: final x0 max abs dev {e0:.3e}, |dR|_F {eR:.3e}")
+    valid = torch.from_numpy(g["in_points_per_part"]) > 0
+    Rv = R.cpu()[valid]
+    assert (torch.linalg.det(Rv) - 1).abs().max().item() < 1e-4
+    assert (Rv @ Rv.transpose(1, 2) - torch.eye(3)).abs().max().item() < 1e-4
+    assert e0 < 0.25, e0     # normalised units; the cloud spans ~[-0.67, 0.67]
+
+
+def test_autocast_selects_the_16bit_path(dev):
+    """compute_dtype=None follows torch autocast like the reference's nn.Linear layers (Lightning '16-mixed')."""
+    g, inp = load_golden("l2_ragged_rigid")
+    cfg, sd, m32 = get_model(2, int(g["weight_seed"]), dev, "float32")
+    _, _, mauto = get_model(2, int(g["weight_seed"]), dev, None)
+    cu_b, cu_p = O.prepare_cu_seqlens(inp)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    args = dict(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
+                local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev))
+    v32 = m32(**args)
+    v_plain = mauto(**args)
+    assert torch.equal(v32, v_plain)                       # no autocast -> the exact fp32 path
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        v_bf = mauto(**args)
+    _, _, mbf = get_model(2, int(g["weight_seed"]), dev, "bfloat16")
+    assert torch.equal(v_bf, mbf(**args))
+    assert not torch.equal(v_bf, v32)
