@@ -32,13 +32,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_16BIT_MATRIX_TFLOPS = 2500.0  # same table: "Peak BF16/FP16 MFMA ~2.5 PF dense"
+DTYPE_TAG = {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}
 CPU_BASELINE_THREADS = 16
 
 
-def pmc_traffic():
+def pmc_traffic(dtype="float32"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside this
     process; the passes are separate runs of scripts/kernel_bench.py, summarised in profiles/)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if dtype == "float32" else "pmc_traffic_h16.json")
     try:
         with open(path) as f:
             j = json.load(f)
@@ -60,6 +62,11 @@ def parse_args():
     ap.add_argument("--rigidity", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dtype", default="float32", choices=list(DTYPE_TAG),
+                    help="arithmetic of the transformer blocks for the HEADLINE number: float32 = BASELINE configs[1] (default); "
+                         "bfloat16 = the per-GPU shard of configs[2]; float16 = the reference's shipped GPU precision")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the extra bf16 measurement of the same workload that a float32 run appends as 'reduced_precision'")
     return ap.parse_args()
 
 
@@ -119,50 +126,98 @@ def main():
 
     cfg = dict(S.RAP_12); cfg["num_layers"] = args.layers
     sd = S.make_weights(cfg, 0)
-    model = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
-                                  num_heads=cfg["num_heads"], local_feat_dim=cfg["local_feat_dim"], attn_dtype="float32")
-    model.load_state_dict(sd)
-    model.to(dev)
-    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=args.flow_steps,
-                                      rigidity_forcing=bool(args.rigidity))
     # rank r owns pairs [r*batch, (r+1)*batch) of the global job; synthetic, seeded per pair
     inp = S.make_inputs([[args.points] * args.views for _ in range(args.batch)], seed=1234 + rank * args.batch)
     data = {k: v.to(dev) for k, v in inp.items()}
     x_1 = data["x_1"]
     pts_per_rank = args.batch * args.views * args.points
     lib = _lib.load()
-
-    def one_step():
-        out = flow.sample_and_register(data, x_1=x_1)
-        final = out["end_point_trajectory"][-1]
-        if distributed:
-            return gather_registrations(final, out["R"], out["t"]), out
-        return (final, out["R"], out["t"]), out
+    profile = not args.no_profile
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    profile = not args.no_profile
-    if profile:
-        lib.rap_profile_reset(); lib.rap_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gathered, last = one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof_ms = (ctypes.c_float * 3)(); prof_n = (ctypes.c_int64 * 3)()
-    if profile:
-        lib.rap_profile_enable(0)
-        _lib.check(lib.rap_profile_collect(prof_ms, prof_n), "rap_profile_collect")
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def run_mode(dtype, steps, warmup):
+        """W untimed + K timed sample calls with the transformer blocks in `dtype`; returns (elapsed, prof, last, flow)."""
+        model = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
+                                      num_heads=cfg["num_heads"], local_feat_dim=cfg["local_feat_dim"],
+                                      attn_dtype=dtype, compute_dtype=dtype)
+        model.load_state_dict(sd)
+        model.to(dev)
+        flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=args.flow_steps,
+                                          rigidity_forcing=bool(args.rigidity))
+
+        def one_step():
+            out = flow.sample_and_register(data, x_1=x_1)
+            final = out["end_point_trajectory"][-1]
+            if distributed:
+                return gather_registrations(final, out["R"], out["t"]), out
+            return (final, out["R"], out["t"]), out
+
+        for _ in range(warmup):
+            one_step()
+        barrier()
+        if profile:
+            lib.rap_profile_reset(); lib.rap_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gathered, last = one_step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof_ms = (ctypes.c_float * 3)(); prof_n = (ctypes.c_int64 * 3)()
+        if profile:
+            lib.rap_profile_enable(0)
+            _lib.check(lib.rap_profile_collect(prof_ms, prof_n), "rap_profile_collect")
+        if distributed:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, (list(prof_ms), list(prof_n)), last
+
+    def roofline_of(dtype, prof, elapsed):
+        prof_ms, prof_n = prof
+        if not (profile and prof_n[0] > 0 and prof_n[1] > 0):
+            return None
+        peak = PEAK_FP32_MATRIX_TFLOPS if dtype == "float32" else PEAK_16BIT_MATRIX_TFLOPS
+        f_part, f_samp = attention_flops_per_forward(args.batch, args.views, args.points, args.layers)
+        n_launch = int(prof_n[0] + prof_n[1])
+        flops = f_part * int(prof_n[0]) + f_samp * int(prof_n[1])
+        secs = (prof_ms[0] + prof_ms[1]) * 1e-3
+        achieved = flops / secs / 1e12
+        elem = 4 if dtype == "float32" else 2
+        traffic, source = pmc_traffic(dtype)
+        return {
+            "kernel": "attention_f32_kernel" if dtype == "float32" else "attention_h16_kernel", "bound": "mfma",
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": source,
+            "algorithmic_bytes_per_launch": 4 * elem * args.batch * args.views * args.points * 512,
+            "launches": n_launch, "avg_launch_ms": 1e3 * secs / n_launch, "flops_per_launch_avg": flops / n_launch,
+            "per_part": {"launches": int(prof_n[0]), "avg_ms": prof_ms[0] / max(1, prof_n[0]),
+                         "tflops": f_part * int(prof_n[0]) / (prof_ms[0] * 1e-3) / 1e12},
+            "per_sample": {"launches": int(prof_n[1]), "avg_ms": prof_ms[1] / max(1, prof_n[1]),
+                           "tflops": f_samp * int(prof_n[1]) / (prof_ms[1] * 1e-3) / 1e12},
+            "gemm": {"launches": int(prof_n[2]), "total_ms": float(prof_ms[2]),
+                     "tflops": (args.batch * args.views * args.points * 10.486e6 * (int(prof_n[2]) / 6))
+                               / (prof_ms[2] * 1e-3) / 1e12 if prof_n[2] else None},
+            "fraction_of_step_time": {"attention": secs / elapsed, "gemm": prof_ms[2] * 1e-3 / elapsed},
+        }
+
+    elapsed, prof, last = run_mode(args.dtype, args.steps, args.warmup)
+    secondary = None
+    if args.dtype == "float32" and not args.no_secondary:
+        # the same workload with bf16 MFMA blocks (BASELINE configs[2]'s per-GPU shard), reported beside the fp32 headline
+        e2, p2, l2 = run_mode("bfloat16", args.steps, args.warmup)
+        a, b = l2["end_point_trajectory"][-1], last["end_point_trajectory"][-1]
+        secondary = {
+            "dtype": "bf16", "value": pts_per_rank * world * args.steps / e2, "unit": "points/s", "ms_per_step": 1e3 * e2 / args.steps,
+            "workload": "same batch, bf16 MFMA transformer blocks (fp32 accumulate / residual / LN / softmax / head)",
+            "roofline": roofline_of("bfloat16", p2, e2),
+            "deviation_from_fp32_path": {"final_cloud_max_abs": float((a - b).abs().max()),
+                                         "R_frob_max": float(torch.linalg.matrix_norm(l2["R"] - last["R"]).max()),
+                                         "t_max_abs": float((l2["t"] - last["t"]).abs().max())}}
+        del l2
 
     result = None
     if rank == 0:
@@ -171,36 +226,22 @@ def main():
         result = {
             "metric": "registered points/sec @20 flow steps, 2-view N=4096", "value": value, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: batch={args.batch} pairs/GPU x {args.views} views x {args.points} pts, "
-                                   f"{args.flow_steps} Euler flow steps, rap_{args.layers} (d=512, H=8), fp32, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_TAG[args.dtype], "data": "synthetic",
+            "config": {"workload": f"{'configs[1]' if args.dtype == 'float32' else 'configs[2] per-GPU shard'}: "
+                                   f"batch={args.batch} pairs/GPU x {args.views} views x {args.points} pts, "
+                                   f"{args.flow_steps} Euler flow steps, rap_{args.layers} (d=512, H=8), "
+                                   f"{'fp32 (exact-fp32 MFMA)' if args.dtype == 'float32' else args.dtype + ' MFMA blocks, fp32 accumulate/residual/head'}, "
                                    f"rigidity_forcing={'on' if args.rigidity else 'off'}, final per-view SE(3) fit",
                        "pairs_per_gpu": args.batch, "views": args.views, "points_per_view": args.points,
                        "flow_steps": args.flow_steps, "num_layers": args.layers, "rigidity_forcing": bool(args.rigidity),
                        "sharding": f"independent pairs, {world} rank(s), one RCCL all-gather of clouds+poses per step"},
         }
-        if profile and prof_n[0] > 0 and prof_n[1] > 0:
-            f_part, f_samp = attention_flops_per_forward(args.batch, args.views, args.points, args.layers)
-            n_launch = int(prof_n[0] + prof_n[1])
-            flops = f_part * int(prof_n[0]) + f_samp * int(prof_n[1])
-            secs = (prof_ms[0] + prof_ms[1]) * 1e-3
-            achieved = flops / secs / 1e12
-            result["roofline"] = {
-                "kernel": "attention_f32_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": pmc_traffic()[0],
-                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": pmc_traffic()[1],
-                "algorithmic_bytes_per_launch": 4 * 4 * args.batch * args.views * args.points * 512,
-                "launches": n_launch, "avg_launch_ms": 1e3 * secs / n_launch,
-                "flops_per_launch_avg": flops / n_launch,
-                "per_part": {"launches": int(prof_n[0]), "avg_ms": prof_ms[0] / max(1, prof_n[0]),
-                             "tflops": f_part * int(prof_n[0]) / (prof_ms[0] * 1e-3) / 1e12},
-                "per_sample": {"launches": int(prof_n[1]), "avg_ms": prof_ms[1] / max(1, prof_n[1]),
-                               "tflops": f_samp * int(prof_n[1]) / (prof_ms[1] * 1e-3) / 1e12},
-                "gemm": {"launches": int(prof_n[2]), "total_ms": float(prof_ms[2]),
-                         "tflops": (args.batch * args.views * args.points * 10.486e6 * (int(prof_n[2]) / 6))
-                                   / (prof_ms[2] * 1e-3) / 1e12 if prof_n[2] else None},
-                "fraction_of_step_time": {"attention": secs / elapsed, "gemm": prof_ms[2] * 1e-3 / elapsed},
-            }
+        roof = roofline_of(args.dtype, prof, elapsed)
+        if roof:
+            result["roofline"] = roof
+        if secondary:
+            secondary["speedup_vs_fp32_path"] = secondary["value"] / value
+            result["reduced_precision"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             n0 = args.views * args.points
             x0_first = last["end_point_trajectory"][0][:n0]

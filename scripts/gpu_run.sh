@@ -36,7 +36,7 @@ if has sweep; then
   cat "$OUT/kernel_bench.jsonl"
 fi
 if has bench; then
-  timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+  timeout 900 python bench.py ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err"
   echo "bench exit $?"; cat "$OUT/bench.json"
 fi
 if has prof; then

@@ -74,7 +74,8 @@ def test_convert_is_round_to_nearest_even(lib, dev, dt):
                    torch.tensor([0.0, -0.0, 1.0, 1.00390625, 1.001953125, 65504.0, 1e-8, -3.0])])
     x = x[: x.numel() // 4 * 4].contiguous()
     out = torch.empty(x.numel(), dtype=torch.int16, device=dev)
-    _lib.check(lib.rap_convert_h16(dt, _lib.ptr(x.to(dev)), _lib.ptr(out), x.numel(), stream(dev)), "convert")
+    xd = x.to(dev)     # keep every device operand alive until the synchronize (the caching allocator recycles temporaries)
+    _lib.check(lib.rap_convert_h16(dt, _lib.ptr(xd), _lib.ptr(out), x.numel(), stream(dev)), "convert")
     torch.cuda.synchronize()
     ref = to_h(x, dt).view(torch.int16)
     assert torch.equal(out.cpu(), ref)
@@ -97,8 +98,8 @@ def test_gemm_h16_fp32_out_matches_fp64_on_rounded_operands(lib, dev, dt, tile_v
     # 16-bit output
     Ch = torch.full((M, N), float("nan"), dtype=TORCH_DT[dt], device=dev)
     gemm_h(lib, dev, dt, 0, A.to(dev), W.to(dev), Ch, M, N, K, bias=b.to(dev))
-    err = (Ch.cpu().double() - ref).abs() / (ref.abs() + 1e-3)
-    assert err.max().item() < ULP[dt] * 1.01 + 1e-6, err.max().item()     # one rounding into the output type
+    err = (Ch.cpu().double() - ref).abs() - ULP[dt] * 1.01 * ref.abs()     # one rounding into the output type ...
+    assert err.max().item() < 2e-5, err.max().item()                       # ... on top of the fp32 accumulation error
 
 
 @pytest.mark.parametrize("dt", [1, 2])
@@ -301,18 +302,17 @@ def test_layernorm_h16(lib, dev, dt):
     mod = torch.randn(rows, 4, 2 * d, generator=g) * 0.3
     token_row = torch.randint(0, rows, (TP,), generator=g, dtype=torch.int32)
     out = torch.empty(TP, d, dtype=TORCH_DT[dt], device=dev)
-    md = mod.to(dev)
+    md, xd, trd = mod.to(dev), x.to(dev), token_row.to(dev)
     j = 2
-    rc = lib.rap_layernorm_mod_h16(dt, _lib.ptr(x.to(dev)), _lib.ptr(out), TP, d, _lib.ptr(md[0, j]), 4 * 2 * d,
-                                   _lib.ptr(token_row.to(dev)), stream(dev))
+    rc = lib.rap_layernorm_mod_h16(dt, _lib.ptr(xd), _lib.ptr(out), TP, d, _lib.ptr(md[0, j]), 4 * 2 * d, _lib.ptr(trd), stream(dev))
     _lib.check(rc, "ln_mod_h16"); torch.cuda.synchronize()
     xn = F.layer_norm(x.double(), (d,), eps=1e-5)
     ref = xn * (1 + mod[token_row.long(), j, :d].double()) + mod[token_row.long(), j, d:].double()
     err = (out.cpu().double() - ref).abs() / (ref.abs() + 1e-2)
     assert err.max().item() < 1.01 * ULP[dt] + 1e-4, err.max().item()
     gain, shift = torch.randn(d, generator=g), torch.randn(d, generator=g)
-    rc = lib.rap_layernorm_affine_h16(dt, _lib.ptr(x.to(dev)), _lib.ptr(out), TP, d, _lib.ptr(gain.to(dev)), _lib.ptr(shift.to(dev)),
-                                      stream(dev))
+    gd, sd = gain.to(dev), shift.to(dev)
+    rc = lib.rap_layernorm_affine_h16(dt, _lib.ptr(xd), _lib.ptr(out), TP, d, _lib.ptr(gd), _lib.ptr(sd), stream(dev))
     _lib.check(rc, "ln_affine_h16"); torch.cuda.synchronize()
     ref = xn * gain.double() + shift.double()
     err = (out.cpu().double() - ref).abs() / (ref.abs() + 1e-2)
@@ -326,7 +326,8 @@ def test_qknorm_h16(lib, dev, dt):
     qk = to_h(torch.randn(2, H, TP, 64, generator=g) * 2, dt)
     gq, gk = torch.rand(H, 64, generator=g) + 0.5, torch.rand(H, 64, generator=g) + 0.5
     buf = qk.to(dev).clone()
-    _lib.check(lib.rap_qknorm_h16(dt, _lib.ptr(buf), TP, H, _lib.ptr(gq.to(dev)), _lib.ptr(gk.to(dev)), stream(dev)), "qknorm_h16")
+    gqd, gkd = gq.to(dev), gk.to(dev)
+    _lib.check(lib.rap_qknorm_h16(dt, _lib.ptr(buf), TP, H, _lib.ptr(gqd), _lib.ptr(gkd), stream(dev)), "qknorm_h16")
     torch.cuda.synchronize()
     x = qk.double()
     ref = x / x.norm(dim=-1, keepdim=True).clamp_min(1e-12) * torch.stack([gq, gk])[:, :, None, :].double() * 8.0
@@ -352,8 +353,9 @@ def get_model(num_layers, seed, dev, compute_dtype):
     return _MODELS[key]
 
 
-# bounds = measured worst case on MI355X x ~3 (the measured numbers are printed; DESIGN.md section 2 quotes them)
-FWD_REL_BOUND = {"bfloat16": 6e-2, "float16": 1e-2}
+# bounds = measured worst case on MI355X x ~3.5 (r01 run 4: bf16 0.9-2.2e-3, fp16 1.2-2.7e-4 of max|v|; the measured
+# numbers are printed; DESIGN.md section 2 quotes them)
+FWD_REL_BOUND = {"bfloat16": 8e-3, "float16": 1e-3}
 
 
 @pytest.mark.parametrize("cdt", ["bfloat16", "float16"])
@@ -395,7 +397,8 @@ def test_sample_h16_deviation_and_invariants(cdt, dev):
     Rv = R.cpu()[valid]
     assert (torch.linalg.det(Rv) - 1).abs().max().item() < 1e-4
     assert (Rv @ Rv.transpose(1, 2) - torch.eye(3)).abs().max().item() < 1e-4
-    assert e0 < 0.25, e0     # normalised units; the cloud spans ~[-0.67, 0.67]
+    # measured (r01 run 4): bf16 1.1e-3 / 8.0e-4, fp16 1.0e-4 / 6.2e-5; normalised units, the cloud spans ~[-0.67, 0.67]
+    assert e0 < {"bfloat16": 5e-3, "float16": 5e-4}[cdt] and eR < {"bfloat16": 5e-3, "float16": 5e-4}[cdt], (e0, eR)
 
 
 def test_autocast_selects_the_16bit_path(dev):
