@@ -39,7 +39,17 @@ __device__ __forceinline__ float h_xhalf_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <int DT>
+// ABL: timing-only ablations (scripts/kernel_bench.py --h16-attn-variant; results are NOT attention): bit 0 = no softmax
+// VALU (P = raw S), bit 1 = no K/V streaming (every tile re-uses the first one: no global loads, LDS writes, barriers),
+// bit 3 = no transcendental, bit 4 = no O rescale, bit 5 = no row-maximum chain.
+// OPT: bit 0 = row maximum through v_max3_f32, bit 1 = deferred rescale (threshold DEFER_THR in the base-2 exponent).
+#define DEFER_THR 11.5f   // = 8 in natural-log units: P <= e^8
+__device__ __forceinline__ float hmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+template <int DT, int ABL, int OPT>
 __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
                                                                int vt_nblk, u16* __restrict__ out, int TP, int heads,
                                                                const AttnWorkItem* __restrict__ items) {
@@ -103,8 +113,8 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   __syncthreads();
 
   for (int t = 0; t < ntile; ++t) {
-    const int cur = t & 1;
-    const bool more = (t + 1) < ntile;
+    const int cur = (ABL & 2) ? 0 : (t & 1);
+    const bool more = (ABL & 2) ? false : (t + 1) < ntile;
     if (more) { HATT_LOAD(t + 1) }
 
     if (wave_active) {
@@ -113,6 +123,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
       const u16* kp = Ks + cur * (HKV * HLD) + l31 * HLD + 8 * hi;
+      if (OPT & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const T8 k0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 16 * s));
@@ -120,6 +131,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
         s0 = H16<DT>::mfma(k0, qf[s], s0);
         s1 = H16<DT>::mfma(k1, qf[s], s1);
       }
+      if (OPT & 4) __builtin_amdgcn_s_setprio(0);
       // ---- mask keys outside the segment (first / last tile only)
       const int tile0 = (b_first + t) * 64;
       if (tile0 < seg0 || tile0 + 64 > seg1) {
@@ -131,26 +143,72 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
         }
       }
       // ---- online softmax, lane-local except one cross-half max
-      float mx = fmaxf(s0[0], s1[0]);
+      if (!(ABL & 1)) {
+        float mx;
+        if (ABL & 32) {
+          mx = 8.0f;                                  // timing-only: no row-maximum chain
+        } else if (OPT & 1) {
+          float ma = hmax3(s0[0], s0[1], s0[2]), mb = hmax3(s1[0], s1[1], s1[2]);   // two independent v_max3_f32 chains
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-      mx = h_xhalf_max(mx);
-      const float mnew = fmaxf(mrun, mx);
-      const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);
-      mrun = mnew;
-      const float mc = mnew * c;
-      float ps = 0.f;
+          for (int r = 3; r < 15; r += 2) { ma = hmax3(ma, s0[r], s0[r + 1]); mb = hmax3(mb, s1[r], s1[r + 1]); }
+          mx = hmax3(ma, mb, fmaxf(s0[15], s1[15]));
+          mx = h_xhalf_max(mx);
+        } else {
+          mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c, -mc));
-        s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c, -mc));
-        ps += s0[r] + s1[r];
-      }
-      lsum = lsum * alpha + ps;
+          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+          mx = h_xhalf_max(mx);
+        }
+        if (OPT & 2) {
+          // deferred rescale: keep the running maximum as long as no row of the wave grew by more than DEFER_THR in the
+          // exponent (P <= 2^DEFER_THR: no overflow in bf16 / fp16 / the fp32 sums); O and l are rescaled only then.
+          // Textbook order: the decision precedes this tile's exponentials and follows the previous tile's P*V.
+          if (!__all((mx - mrun) * c <= DEFER_THR)) {
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);
+            mrun = mnew;
+            lsum *= alpha;
+            if (!(ABL & 16)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+              for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            }
+          }
+        } else {
+          const float mnew = fmaxf(mrun, mx);
+          const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);
+          mrun = mnew;
+          lsum *= alpha;
+          if (!(ABL & 16)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+          }
+        }
+        // exponent FMA and the row sum on the packed fp32 pipe (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per issue
+        // slot): the kernel is VALU-issue bound (PMC: ~10 VALU per MFMA at ~4.8 cycles each vs 32 cycles per MFMA).
+        const f32x2 c2 = {c, c};
+        const f32x2 nmc2 = {-mrun * c, -mrun * c};
+        f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          f32x2 a = {s0[2 * k], s0[2 * k + 1]};
+          f32x2 b = {s1[2 * k], s1[2 * k + 1]};
+          a = __builtin_elementwise_fma(a, c2, nmc2);
+          b = __builtin_elementwise_fma(b, c2, nmc2);
+          if (ABL & 8) {                              // timing-only: no transcendental
+            a *= 0.001f; b *= 0.001f;
+          } else {
+            a.x = __builtin_amdgcn_exp2f(a.x); a.y = __builtin_amdgcn_exp2f(a.y);
+            b.x = __builtin_amdgcn_exp2f(b.x); b.y = __builtin_amdgcn_exp2f(b.y);
+          }
+          s0[2 * k] = a.x; s0[2 * k + 1] = a.y;
+          s1[2 * k] = b.x; s1[2 * k + 1] = b.y;
+          ps2 += a + b;
+        }
+        lsum += ps2.x + ps2.y;
+      } else { lsum += s0[0]; }
       // ---- O^T += V^T P^T : key step ks contracts the keys held in registers 8(ks&1)..+7 of sub-tile ks>>1
       const u16* vp = Vs + cur * (HKV * HLD) + l31 * HLD + 8 * hi;
+      if (OPT & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int rb = 8 * (ks & 1);
@@ -164,10 +222,11 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
         o0 = H16<DT>::mfma(v0, pb, o0);
         o1 = H16<DT>::mfma(v1, pb, o1);
       }
+      if (OPT & 4) __builtin_amdgcn_s_setprio(0);
     }
 
     if (more) { HATT_STORE(cur ^ 1) }
-    __syncthreads();
+    if (!(ABL & 2)) __syncthreads();
   }
 
   if (!wave_active) return;
@@ -186,18 +245,33 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   }
 }
 
+// tuning knob (rap_set_tuning key 3): 0 = the kernel (v_max3 row maximum + deferred rescale); 8 = v1 (fmaxf chain, rescale
+// every tile); 4 = max3 only; 1..3, 6, 7 = timing-only ablations (bf16 only), see ABL above.
+int g_rap_attn_h16_variant = 0;
+
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
                          int heads, const AttnWorkItem* items, int max_items) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0 || vt_nblk * 64 < TP) return RAP_ERR_INVALID;
-  if (dtype == RAP_DT_BF16)
-    hipLaunchKernelGGL(attention_h16_kernel<RAP_DT_BF16>, dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out,
-                       TP, heads, items);
-  else if (dtype == RAP_DT_F16)
-    hipLaunchKernelGGL(attention_h16_kernel<RAP_DT_F16>, dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out,
-                       TP, heads, items);
-  else
+#define HATT_LAUNCH(DTV, ABLV, OPTV) \
+  hipLaunchKernelGGL((attention_h16_kernel<DTV, ABLV, OPTV>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items)
+  if (dtype == RAP_DT_BF16) {
+    switch (g_rap_attn_h16_variant) {
+      case 1: HATT_LAUNCH(RAP_DT_BF16, 1, 0); break;
+      case 2: HATT_LAUNCH(RAP_DT_BF16, 2, 0); break;
+      case 3: HATT_LAUNCH(RAP_DT_BF16, 3, 0); break;
+      case 4: HATT_LAUNCH(RAP_DT_BF16, 0, 7); break;     // + s_setprio(1) around the MFMA clusters
+      case 5: HATT_LAUNCH(RAP_DT_BF16, 0, 3); break;     // max3 + deferred rescale
+      case 6: HATT_LAUNCH(RAP_DT_BF16, 8, 3); break;     // ... without transcendentals
+      case 7: HATT_LAUNCH(RAP_DT_BF16, 32, 3); break;    // ... without the max chain
+      case 8: HATT_LAUNCH(RAP_DT_BF16, 0, 0); break;     // v1: fmaxf chain, rescale every tile
+      default: HATT_LAUNCH(RAP_DT_BF16, 0, 3); break;
+    }
+  } else if (dtype == RAP_DT_F16) {
+    if (g_rap_attn_h16_variant == 8) HATT_LAUNCH(RAP_DT_F16, 0, 0); else HATT_LAUNCH(RAP_DT_F16, 0, 3);
+  } else {
     return RAP_ERR_INVALID;
+  }
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }

@@ -21,6 +21,21 @@
 #include "half.h"
 #include "kernels.h"
 
+// exact-erf GELU through the Abramowitz-Stegun 7.1.26 complementary error function (|error| <= 1.5e-7, far below
+// one rounding of the 16-bit output): q = erfc(|g| / sqrt 2);  gelu(g) = g < 0 ? g q / 2 : g (1 - q / 2).
+// ~15 VALU instructions instead of erff's ~45 -- at 16x the fp32 MFMA rate the GEGLU epilogue was as long as the k-loop.
+__device__ __forceinline__ float gelu_erf_fast(float g) {
+  const float x = fabsf(g) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
+  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  poly = __builtin_fmaf(t, poly, 1.421413741f);
+  poly = __builtin_fmaf(t, poly, -0.284496736f);
+  poly = __builtin_fmaf(t, poly, 0.254829592f);
+  poly *= t;
+  const float q = poly * __builtin_amdgcn_exp2f(-x * x * 1.44269504088896340736f);
+  return g < 0.f ? 0.5f * g * q : g * (1.0f - 0.5f * q);
+}
+
 template <int EPI, int DT, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16_kernel(GemmParamsH p) {
   typedef typename H16<DT>::T8 T8;
@@ -156,83 +171,132 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
     mma(f1);
   }
 
-  // ---------------- epilogue: acc[i][j][r] = C[mw + 32 i + crow(r, hi)][nw + 32 j + l31] ----------------
+  // ---------------- epilogue ----------------
+  // acc[i][j][r] = C[mw + 32 i + crow(r, hi)][nw + 32 j + l31]: a lane owns ONE column, so direct stores would be
+  // 2- or 4-byte scatters (measured: the out-projection ran at 147 TF, 4x its HBM floor).  Every wave therefore
+  // transposes its tile through a private LDS slab (the operand buffers are dead by now) and writes whole rows with
+  // 16-byte stores; the fp32 residual is read the same way.
+  static_assert(TN == 2, "wave tiles are 64 columns wide: one head / one GEGLU value+gate group");
+  constexpr int STG_BYTES = 64 * 144;            // largest slab: the V^T image of 64 tokens (64 d rows of 144 bytes)
+  static_assert(64 * WM * WN / 64 * STG_BYTES <= 2 * (BM + BN) * 128, "staging slabs must fit the operand buffers");
+  __syncthreads();
+  unsigned char* stg = smem + wave * STG_BYTES;
   const int mw = m0 + wm * TM * 32;
-  const int nw = n0 + wn * TN * 32;
+  const int nw = n0 + wn * 64;
+
   if constexpr (EPI == EPI_H_GEGLU) {
     u16* C = reinterpret_cast<u16*>(p.C);
+    u16* sh = reinterpret_cast<u16*>(stg);       // [32 rows][32 outputs]
+    const float bh = p.bias ? p.bias[nw + l31] : 0.f;
+    const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
 #pragma unroll
-    for (int jp = 0; jp < TN / 2; ++jp) {
-      const int nout = ((nw + 64 * jp) >> 1) + l31;
-      const float bh = p.bias ? p.bias[nw + 64 * jp + l31] : 0.f;
-      const float bg = p.bias ? p.bias[nw + 64 * jp + 32 + l31] : 0.f;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int r = 0; r < 16; ++r) {
+        const float h = acc[i][0][r] + bh;
+        const float g = acc[i][1][r] + bg;
+        sh[mfma32_crow(r, hi) * 32 + l31] = h16_from_f32<DT>(h * gelu_erf_fast(g));
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mw + i * 32 + mfma32_crow(r, hi);
-          if (m < p.M) {
-            const float h = acc[i][2 * jp][r] + bh;
-            const float g = acc[i][2 * jp + 1][r] + bg;
-            const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
-            C[(size_t)m * p.ldc + nout] = h16_from_f32<DT>(h * ge);
-          }
-        }
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 16 + (lane >> 2), col = (lane & 3) * 8;
+        const uint4 v = *reinterpret_cast<const uint4*>(sh + row * 32 + col);
+        const int m = mw + i * 32 + row;
+        if (m < p.M) *reinterpret_cast<uint4*>(C + (size_t)m * p.ldc + (nw >> 1) + col) = v;
       }
     }
     return;
   }
+  if constexpr (EPI == EPI_H_BIAS_RESID_F32) {
+    float* C = reinterpret_cast<float*>(p.C);
+    float* sf = reinterpret_cast<float*>(stg);   // [32 rows][64 columns]
+    const float b0 = p.bias ? p.bias[nw + l31] : 0.f;
+    const float b1 = p.bias ? p.bias[nw + 32 + l31] : 0.f;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = nw + j * 32 + l31;
-    const float bn = p.bias ? p.bias[n] : 0.f;
-    if constexpr (EPI == EPI_H_QKV) {
-      const int dmodel = p.heads * 64;
-      const int c = (nw + j * 32) / dmodel;          // wave-uniform: a 32-column tile never straddles q|k|v or a head
-      const int rem = n - c * dmodel;
-      const int h = rem >> 6, jj = rem & 63;
-      if (c < 2) {
-        u16* dst = reinterpret_cast<u16*>(p.C) + ((size_t)(c * p.heads + h) * p.M) * 64 + jj;
+    for (int i = 0; i < TM; ++i) {
+      float4 rr[8];
+      if (p.resid) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = mw + i * 32 + mfma32_crow(r, hi);
-            if (m < p.M) dst[(size_t)m * 64] = h16_from_f32<DT>(acc[i][j][r]);
-          }
-        }
-      } else {
-        // V goes out TRANSPOSED and blocked by 64 tokens: vt[h][token >> 6][d][vt_pos(token & 63)] -- the four rows
-        // of an accumulator register group are four consecutive tokens = one 8-byte store.  Rows >= M (tile padding)
-        // are written as zeros: masked keys must contribute 0 * finite in the P*V product.
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int mb = mw + i * 32 + 8 * g + 4 * hi;          // first of 4 consecutive tokens
-            float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
-            v0 = (mb + 0 < p.M) ? v0 : 0.f; v1 = (mb + 1 < p.M) ? v1 : 0.f;
-            v2 = (mb + 2 < p.M) ? v2 : 0.f; v3 = (mb + 3 < p.M) ? v3 : 0.f;
-            u16* dst = p.vt + (((size_t)h * p.vt_nblk + (mb >> 6)) * 64 + jj) * 64 + vt_pos(mb & 63);
-            *reinterpret_cast<uint2*>(dst) = h16_pack4<DT>(v0, v1, v2, v3);
-          }
+        for (int it = 0; it < 8; ++it) {
+          int m = mw + i * 32 + it * 4 + (lane >> 4);
+          m = m < p.M ? m : p.M - 1;
+          rr[it] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + nw + (lane & 15) * 4);
         }
       }
-    } else {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int r = 0; r < 16; ++r) {
+        sf[mfma32_crow(r, hi) * 64 + l31] = acc[i][0][r] + b0;
+        sf[mfma32_crow(r, hi) * 64 + 32 + l31] = acc[i][1][r] + b1;
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mw + i * 32 + mfma32_crow(r, hi);
-          if (m >= p.M) continue;
-          const float v = acc[i][j][r] + bn;
-          if constexpr (EPI == EPI_H_BIAS) {
-            reinterpret_cast<u16*>(p.C)[(size_t)m * p.ldc + n] = h16_from_f32<DT>(v);
-          } else {   // EPI_H_BIAS_RESID_F32
-            float* C = reinterpret_cast<float*>(p.C);
-            C[(size_t)m * p.ldc + n] = p.resid ? p.resid[(size_t)m * p.ldr + n] + v : v;
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4), col = (lane & 15) * 4;
+        float4 v = *reinterpret_cast<const float4*>(sf + row * 64 + col);
+        if (p.resid) { v.x += rr[it].x; v.y += rr[it].y; v.z += rr[it].z; v.w += rr[it].w; }
+        const int m = mw + i * 32 + row;
+        if (m < p.M) *reinterpret_cast<float4*>(C + (size_t)m * p.ldc + nw + col) = v;
+      }
+    }
+    return;
+  }
+  if constexpr (EPI == EPI_H_BIAS || EPI == EPI_H_QKV) {
+    u16* sh = reinterpret_cast<u16*>(stg);
+    int c = 0, h = 0;
+    if constexpr (EPI == EPI_H_QKV) {
+      const int dmodel = p.heads * 64;
+      c = nw / dmodel;                             // wave-uniform: the 64-column wave tile is one head of q, k or v
+      h = (nw - c * dmodel) >> 6;
+    }
+    if (EPI == EPI_H_QKV && c == 2) {
+      // V goes out TRANSPOSED and blocked by 64 tokens: vt[h][token >> 6][d][vt_pos(token & 63)].  Two 32-token slabs
+      // (= one block) are staged as [64 d][64 pos] (row stride 144 B) and written as one contiguous 8 KiB block.
+      // Rows >= M (tile padding) are zeros: masked keys must contribute 0 * finite in the P*V product.
+#pragma unroll
+      for (int ip = 0; ip < TM / 2; ++ip) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int i = 2 * ip + ii;
+              const int mb = mw + i * 32 + 8 * g + 4 * hi;          // first of 4 consecutive tokens
+              float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+              v0 = (mb + 0 < p.M) ? v0 : 0.f; v1 = (mb + 1 < p.M) ? v1 : 0.f;
+              v2 = (mb + 2 < p.M) ? v2 : 0.f; v3 = (mb + 3 < p.M) ? v3 : 0.f;
+              const int pos0 = 32 * ii + 16 * (g >> 1) + 8 * hi + 4 * (g & 1);   // = vt_pos(32 ii + 8 g + 4 hi)
+              *reinterpret_cast<uint2*>(sh + (j * 32 + l31) * 72 + pos0) = h16_pack4<DT>(v0, v1, v2, v3);
+            }
           }
         }
+        u16* dst = p.vt + ((size_t)h * p.vt_nblk + ((mw + 64 * ip) >> 6)) * (64 * 64);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int d = it * 8 + (lane >> 3), ch = (lane & 7) * 8;
+          *reinterpret_cast<uint4*>(dst + d * 64 + ch) = *reinterpret_cast<const uint4*>(sh + d * 72 + ch);
+        }
+      }
+      return;
+    }
+    const float b0 = (EPI == EPI_H_BIAS && p.bias) ? p.bias[nw + l31] : 0.f;
+    const float b1 = (EPI == EPI_H_BIAS && p.bias) ? p.bias[nw + 32 + l31] : 0.f;
+    u16* C = reinterpret_cast<u16*>(p.C);
+    // q / k plane [c][h][m][64]: the wave's rows are contiguous 128-byte lines; EPI_H_BIAS: row-major (M, ldc)
+    const size_t row_stride = (EPI == EPI_H_QKV) ? 64 : (size_t)p.ldc;
+    u16* base = (EPI == EPI_H_QKV) ? C + ((size_t)(c * p.heads + h) * p.M) * 64 : C + nw;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sh[mfma32_crow(r, hi) * 64 + l31] = h16_from_f32<DT>(acc[i][0][r] + b0);
+        sh[mfma32_crow(r, hi) * 64 + 32 + l31] = h16_from_f32<DT>(acc[i][1][r] + b1);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), col = (lane & 7) * 8;
+        const uint4 v = *reinterpret_cast<const uint4*>(sh + row * 64 + col);
+        const int m = mw + i * 32 + row;
+        if (m < p.M) *reinterpret_cast<uint4*>(base + (size_t)m * row_stride + col) = v;
       }
     }
   }

@@ -39,6 +39,8 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
     rows = []
     if args.h16_gemm_variant >= 0:
         assert lib.rap_set_tuning(2, args.h16_gemm_variant) == 0
+    if args.h16_attn_variant >= 0:
+        assert lib.rap_set_tuning(3, args.h16_attn_variant) == 0
     nblk = (TP + 255) // 256 * 256 // 64
 
     def gemm_case(name, epi, N, K, out_half, Cw=None, heads=0):
@@ -78,7 +80,7 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
                 assert rc == 0, rc
             t = timeit(fn, iters=1 if args.pmc else 5, warm=0 if args.pmc else 2)
             fl = 4.0 * H * 64 * L * TP
-            rows.append({"kernel": f"attention_h16[{name} L={L}]", "dtype": args.dtype, "ms": t * 1e3, "tflops": fl / t / 1e12,
+            rows.append({"kernel": f"attention_h16[{name} L={L}]", "dtype": args.dtype, "variant": args.h16_attn_variant, "ms": t * 1e3, "tflops": fl / t / 1e12,
                          "frac_of_2500TF": fl / t / 1e12 / PEAK})
     if args.only == "":
         x = torch.randn(TP, d, device=dev, generator=g); y = torch.empty(TP, d, device=dev, dtype=tdt)
@@ -108,6 +110,7 @@ def main():
     ap.add_argument("--attn-variant", type=int, default=-1)
     ap.add_argument("--dtype", default="float32", help="float32 | bfloat16 | float16 (16-bit: GEMM / attention / LN / qknorm twins)")
     ap.add_argument("--h16-gemm-variant", type=int, default=-1)
+    ap.add_argument("--h16-attn-variant", type=int, default=-1, help="timing-only ablations of the 16-bit attention kernel")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
