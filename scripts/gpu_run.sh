@@ -40,19 +40,24 @@ if has bench; then
   echo "bench exit $?"; cat "$OUT/bench.json"
 fi
 if has prof; then
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/prof_bench" -o bench -- \
-      python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$GRAFT_REPO_ROOT/$OUT/prof_bench.log" 2>&1 )
-  DB=$(find "$OUT/prof_bench" -name '*.db' | head -1)
-  if [ -n "$DB" ]; then python scripts/rocpd_summary.py "$DB" > "$OUT/bench_kernel_trace_stats.txt"; head -30 "$OUT/bench_kernel_trace_stats.txt"; fi
-  find "$OUT/prof_bench" -name '*.db' -size +20M -delete
+  for DT in float32 bfloat16; do
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/prof_bench_$DT" -o bench -- \
+        python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --dtype $DT > "$GRAFT_REPO_ROOT/$OUT/prof_bench_$DT.log" 2>&1 )
+    DB=$(find "$OUT/prof_bench_$DT" -name '*.db' | head -1)
+    if [ -n "$DB" ]; then python scripts/rocpd_summary.py "$DB" > "$OUT/bench_${DT}_kernel_trace_stats.txt"; head -16 "$OUT/bench_${DT}_kernel_trace_stats.txt"; fi
+    find "$OUT/prof_bench_$DT" -name '*.db' -delete
+  done
 fi
 if has pmc; then
-  for c in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d "$GRAFT_REPO_ROOT/$OUT/pmc_$c" -o pmc -- \
-        python "$GRAFT_REPO_ROOT/scripts/kernel_bench.py" --only attention --pmc > "$GRAFT_REPO_ROOT/$OUT/pmc_$c.log" 2>&1 )
-    DB=$(find "$OUT/pmc_$c" -name '*.db' | head -1)
-    if [ -n "$DB" ]; then python scripts/rocpd_summary.py "$DB" --pmc > "$OUT/pmc_$c.txt"; grep PMC "$OUT/pmc_$c.txt"; fi
-    find "$OUT/pmc_$c" -name '*.db' -size +20M -delete
+  for DT in float32 bfloat16; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d "$GRAFT_REPO_ROOT/$OUT/pmc_${DT}_$c" -o pmc -- \
+          python "$GRAFT_REPO_ROOT/scripts/kernel_bench.py" --dtype $DT --only attention --pmc > "$GRAFT_REPO_ROOT/$OUT/pmc_${DT}_$c.log" 2>&1 )
+      DB=$(find "$OUT/pmc_${DT}_$c" -name '*.db' | head -1)
+      if [ -n "$DB" ]; then python scripts/rocpd_summary.py "$DB" --pmc | grep -E "PMC.*attention" | sed "s/^/$DT /" >> "$OUT/pmc_traffic.txt"; fi
+      find "$OUT/pmc_${DT}_$c" -name '*.db' -delete
+    done
   done
+  cat "$OUT/pmc_traffic.txt"
 fi
 echo "gpu_run $TAG done"

@@ -166,3 +166,17 @@ def test_multiview_rigidity_matches_oracle(dev):
         assert err < 5e-5, (k, err)
     deg = O.rotation_error_deg(out["R"].cpu(), ref["R"]).max().item()
     print(f"multiview: rot err {deg:.4f} deg, |dR| {(out['R'].cpu() - ref['R']).abs().max().item():.2e}")
+
+
+def test_multiview_full_geometry_first_step_matches_oracle(dev):
+    """BASELINE configs[3] at its real point counts (1 sample x 8 views x 2048 points: per-part attention over 2048 keys,
+    per-sample attention over 16384), 2-layer model, first step of the 30-step grid with the rigidity projection,
+    against the CPU oracle."""
+    cfg, sd, model = get_model(2, 9, dev)
+    inp = S.make_uniform_inputs(1, 8, 2048, seed=99)
+    ref = O.sample(sd, cfg, inp, 30, True, max_steps=1)
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=30, rigidity_forcing=True)
+    out = flow.sample_and_register(to_dev(inp, dev), x_1=inp["x_1"].to(dev))
+    for k in ("end_point_trajectory", "trajectory"):
+        err = (out[k][:1].cpu() - ref[k][:1]).abs().max().item()
+        assert err < 5e-5, (k, err)
