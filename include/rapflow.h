@@ -146,9 +146,13 @@ int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda
                  int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const float* resid, int32_t ldr,
                  int32_t heads, uint16_t* vt, int32_t vt_nblk, void* stream);
 /* flash_attn_varlen_qkvpacked_func equivalent on 16-bit operands (fp32 softmax): qk [2][H][TP][64], vt as above,
- * out half (TP, H*64).  ws >= rap_attention_workspace_bytes(TP, nseg). */
+ * out half (TP, H*64).  ws >= rap_attention_workspace_bytes(TP, nseg).
+ * logit_bound: NULL, or H device floats B[h] with q.k/8 <= B[h] <= 40 for every query/key pair of head h GUARANTEED by
+ * the caller (after the reference's qk-norm B = 8 max|gamma_q| max|gamma_k|): selects the bounded-softmax kernel
+ * (p = exp(s - B), no running maximum; bf16 only -- other dtypes ignore it).  Same softmax, different evaluation order. */
 int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk, const int32_t* cu_seqlens,
-                      int32_t nseg, uint16_t* out, int64_t TP, int32_t heads, void* ws, size_t ws_bytes, void* stream);
+                      int32_t nseg, uint16_t* out, int64_t TP, int32_t heads, const float* logit_bound, void* ws,
+                      size_t ws_bytes, void* stream);
 int rap_layernorm_mod_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* mod,
                           int64_t mod_stride, const int32_t* token_row, void* stream);
 int rap_layernorm_affine_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* gain,

@@ -86,12 +86,15 @@ struct HalfWeights {
   u16* blob = nullptr;
   std::vector<LayerWH> layers;
 };
+#define RAP_MAX_LOGIT_BOUND 40.0f   // exp(-2*40) is still a normal fp32 / bf16 number
 
 struct rap_model {
   rap_model_desc desc;
   int d, L, H, F, E;
   int dtype = RAP_DT_F32;     // arithmetic type of the transformer blocks (rap_model_set_compute_dtype)
   HalfWeights half[3];        // indexed by dtype (slot 0 unused)
+  float* logit_bound = nullptr;   // (L, 2, H) per-head bounds on q.k/8 after qk-norm; null until a 16-bit dtype is selected
+  bool bounded_ok = false;        // every bound <= RAP_MAX_LOGIT_BOUND: the bounded-softmax attention kernel may be used
   float* raw = nullptr;       // copy of the caller's blob
   float* derived = nullptr;   // packed arrays
   const float* anchor_emb;    // (2,d)
@@ -120,7 +123,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16)) { g_rap_gemm_variant = value; return RAP_OK; }
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
   if (key == 2 && value >= 0 && value <= 2) { g_rap_gemm_h16_variant = value; return RAP_OK; }
-  if (key == 3 && value >= 0 && value <= 8) { g_rap_attn_h16_variant = value; return RAP_OK; }
+  if (key == 3 && value >= 0 && value <= 11) { g_rap_attn_h16_variant = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 
@@ -233,6 +236,7 @@ extern "C" void rap_model_destroy(rap_model* m) {
   if (m->derived) (void)hipFree(m->derived);
   for (int i = 0; i < 3; ++i)
     if (m->half[i].blob) (void)hipFree(m->half[i].blob);
+  if (m->logit_bound) (void)hipFree(m->logit_bound);
   delete m;
 }
 
@@ -265,6 +269,23 @@ extern "C" int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* st
       lh.Wff2 = conv(lw.Wff2, 4 * d * d);
     }
     if (rc != RAP_OK) { (void)hipFree(hw.blob); hw.blob = nullptr; hw.layers.clear(); return rc; }
+  }
+  if (!m->logit_bound) {
+    // logit bounds from the qk-norm gains (a property of the weights); model creation may synchronise, so read them
+    // back once to decide whether the bounded-softmax kernel is admissible for this checkpoint
+    hipStream_t stream = (hipStream_t)stream_;
+    const int n = m->L * 2 * m->H;
+    if (hipMalloc((void**)&m->logit_bound, (size_t)n * sizeof(float)) != hipSuccess) { m->logit_bound = nullptr; return RAP_ERR_ALLOC; }
+    for (int i = 0; i < m->L; ++i)
+      for (int a = 0; a < 2; ++a) {
+        const int rc = launch_qk_logit_bound(stream, m->layers[i].gq[a], m->layers[i].gk[a], m->H, m->logit_bound + (size_t)(2 * i + a) * m->H);
+        if (rc) return rc;
+      }
+    std::vector<float> hb(n);
+    RAP_HIP_CHECK(hipMemcpyAsync(hb.data(), m->logit_bound, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    RAP_HIP_CHECK(hipStreamSynchronize(stream));
+    m->bounded_ok = true;
+    for (float b : hb) if (!(b <= RAP_MAX_LOGIT_BOUND)) m->bounded_ok = false;
   }
   m->dtype = dtype;
   return RAP_OK;
@@ -389,8 +410,9 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         if ((rc = launch_qknorm_h16(stream, dt, w.qkh, TP, H, lw.gq[a], lw.gk[a]))) return rc;
         {
           ProfScope ps(stream, a);
+          const float* bound = m->bounded_ok ? m->logit_bound + (size_t)j * H : nullptr;
           rc = launch_attention_h16(stream, dt, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch,
-                                    a == 0 ? w.max_items_part : w.max_items_batch);
+                                    a == 0 ? w.max_items_part : w.max_items_batch, bound);
         }
         if (rc) return rc;
         GemmParamsH o{};
@@ -689,15 +711,15 @@ extern "C" int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, 
   return launch_gemm_h16((hipStream_t)stream, dtype, epilogue, g);
 }
 extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk,
-                                 const int32_t* cu_seqlens, int32_t nseg, uint16_t* out, int64_t TP, int32_t heads, void* ws,
-                                 size_t ws_bytes, void* stream_) {
+                                 const int32_t* cu_seqlens, int32_t nseg, uint16_t* out, int64_t TP, int32_t heads,
+                                 const float* logit_bound, void* ws, size_t ws_bytes, void* stream_) {
   if (!qk || !vt || !cu_seqlens || !out || nseg < 0 || TP < 0 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
   if (!ws || ws_bytes < rap_attention_workspace_bytes(TP, nseg)) return RAP_ERR_WORKSPACE;
   const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
   if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, RAP_ATTN_BQ))) return rc;
-  return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items);
+  return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound);
 }
 extern "C" int rap_layernorm_mod_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* mod,
                                      int64_t mod_stride, const int32_t* token_row, void* stream) {

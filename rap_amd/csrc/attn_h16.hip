@@ -42,7 +42,8 @@ __device__ __forceinline__ float h_xhalf_sum(float v) {
 // ABL: timing-only ablations (scripts/kernel_bench.py --h16-attn-variant; results are NOT attention): bit 0 = no softmax
 // VALU (P = raw S), bit 1 = no K/V streaming (every tile re-uses the first one: no global loads, LDS writes, barriers),
 // bit 3 = no transcendental, bit 4 = no O rescale, bit 5 = no row-maximum chain.
-// OPT: bit 0 = row maximum through v_max3_f32, bit 1 = deferred rescale (threshold DEFER_THR in the base-2 exponent).
+// OPT: bit 0 = row maximum through v_max3_f32, bit 1 = deferred rescale (threshold DEFER_THR in the base-2 exponent),
+// bit 2 = s_setprio(1) around the MFMA clusters (measured: no gain), bit 3 = bounded softmax (see below).
 #define DEFER_THR 11.5f   // = 8 in natural-log units: P <= e^8
 __device__ __forceinline__ float hmax3(float a, float b, float c) {
   float r;
@@ -52,7 +53,8 @@ __device__ __forceinline__ float hmax3(float a, float b, float c) {
 template <int DT, int ABL, int OPT>
 __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
                                                                int vt_nblk, u16* __restrict__ out, int TP, int heads,
-                                                               const AttnWorkItem* __restrict__ items) {
+                                                               const AttnWorkItem* __restrict__ items,
+                                                               const float* __restrict__ bound) {
   typedef typename H16<DT>::T8 T8;
   __shared__ __attribute__((aligned(16))) u16 smem[4 * HKV * HLD];
   u16* Ks = smem;                    // [2][64 keys][72]
@@ -87,7 +89,9 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float mrun = -1e30f, lsum = 0.f;
+  // OPT bit 3: bounded softmax -- the caller guarantees q.k/8 <= bound[head] (after qk-norm: 8 max|gamma_q| max|gamma_k|), so
+  // the fixed offset bound replaces the running maximum: p = exp(s - bound), no max chain, no rescale, no branch.
+  float mrun = (OPT & 8) ? bound[head] * 8.0f : -1e30f, lsum = 0.f;
   const float c = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e)
 
   // ---- staging: 512 threads, one 16-byte chunk of K and one of V^T per thread per tile
@@ -145,7 +149,9 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
       // ---- online softmax, lane-local except one cross-half max
       if (!(ABL & 1)) {
         float mx;
-        if (ABL & 32) {
+        if (OPT & 8) {
+          mx = mrun;                                  // bounded: nothing to track
+        } else if (ABL & 32) {
           mx = 8.0f;                                  // timing-only: no row-maximum chain
         } else if (OPT & 1) {
           float ma = hmax3(s0[0], s0[1], s0[2]), mb = hmax3(s1[0], s1[1], s1[2]);   // two independent v_max3_f32 chains
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
           for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
           mx = h_xhalf_max(mx);
         }
-        if (OPT & 2) {
+        if (OPT & 8) {
+        } else if (OPT & 2) {
           // deferred rescale: keep the running maximum as long as no row of the wave grew by more than DEFER_THR in the
           // exponent (P <= 2^DEFER_THR: no overflow in bf16 / fp16 / the fp32 sums); O and l are rescaled only then.
           // Textbook order: the decision precedes this tile's exponentials and follows the previous tile's P*V.
@@ -245,16 +252,218 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   }
 }
 
-// tuning knob (rap_set_tuning key 3): 0 = the kernel (v_max3 row maximum + deferred rescale); 8 = v1 (fmaxf chain, rescale
+// ---------------------------------------------------------------------------------------------
+// "ping-pong" schedule (rap_set_tuning(3, 11); NOT the default): the two waves that share a SIMD (w and w+4 of the 8-wave block) run the SAME tile loop half an
+// iteration apart, held in anti-phase by two barriers per key tile:
+//
+//     phase p     :  waves 0-3  M(i): S(i) = K(i) Q^T, O += V(i-1) P(i-1)   16 MFMA   |  waves 4-7  V(i-1): softmax -> P(i-1)
+//     phase p + 1 :  waves 0-3  V(i): softmax of S(i) -> P(i)               ~100 VALU |  waves 4-7  M(i)
+//
+// so on every SIMD one wave is in its matrix segment while its partner is in its VALU segment (MI355X_MICROARCH.md "Two
+// waves per SIMD"): the matrix pipe and the vector pipe are both busy all the time instead of taking turns, which is
+// what v1 was suspected of (all waves of a block leave the barrier in the same segment).  MEASURED on MI355X: 800 TF vs
+// v1's 940 -- the SIMD's issue port, not phase alignment, is the limit (PMC: ~10 VALU per MFMA at ~4.8 issue cycles each
+// + 8 per MFMA ~ 55 issue cycles per 32-cycle MFMA), and the second barrier per tile costs more than the anti-phase
+// buys.  Kept selectable because it is the cleanest A/B for that question.  Works with the online softmax
+// (the rescale branch lives in the V segment) and with the bounded one; one query tile per wave, ~128 VGPRs, two blocks
+// per CU.  K(j+1) and V(j) are fetched in phase 2j (global -> registers), parked in LDS in phase 2j+1 and first read in
+// phase 2j+2; K and V are double-buffered.
+// ---------------------------------------------------------------------------------------------
+template <int DT, bool BOUNDED>
+__global__ __launch_bounds__(512, 4) void attention_h16_pp_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
+                                                                  int vt_nblk, u16* __restrict__ out, int TP, int heads,
+                                                                  const AttnWorkItem* __restrict__ items,
+                                                                  const float* __restrict__ bound) {
+  typedef typename H16<DT>::T8 T8;
+  __shared__ __attribute__((aligned(16))) u16 smem[4 * HKV * HLD];
+  u16* Ks = smem;                    // [2][64 keys][72]
+  u16* Vs = smem + 2 * HKV * HLD;    // [2][64 d][72]
+
+  const int head = blockIdx.x % heads;
+  const AttnWorkItem it = items[blockIdx.x / heads];
+  const int len = it.seg_len;
+  if (len <= 0) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int grp = wave >> 2;         // 0: leads, 1: trails by one phase
+  const int seg0 = it.seg_start, seg1 = it.seg_start + len;
+
+  const u16* Qg = qk + (size_t)head * TP * 64;
+  const u16* Kg = qk + (size_t)(heads + head) * TP * 64;
+  const u16* Vg = vt + (size_t)head * vt_nblk * (64 * 64);
+
+  // waves w and w+4 share a SIMD; give them ADJACENT query tiles so that a block still covers 256 consecutive queries
+  const int qw0 = it.q0 + ((wave & 3) * 2 + grp) * 32;
+  const bool wave_active = qw0 < len;
+
+  T8 qf[4];
+  {
+    int q = qw0 + l31;
+    q = q < len ? q : len - 1;
+    const u16* qp = Qg + (size_t)(seg0 + q) * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(qp + 16 * s));
+  }
+  f32x16 o0, o1, s0, s1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; s0[r] = 0.f; s1[r] = 0.f; }
+  T8 pb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) pb[ks] = (T8)0;
+  const float c = 0.125f * 1.44269504088896340736f;
+  float mrun = BOUNDED ? bound[head] * 8.0f : -1e30f;     // BOUNDED: the fixed exponent offset (scores are q.k, bound is on q.k/8)
+  f32x2 l2 = {0.f, 0.f};
+
+  const int srow = tid >> 3, sch = (tid & 7) * 8;
+  const int b_first = seg0 >> 6;
+  const int ntile = ((seg1 - 1) >> 6) - b_first + 1;
+  const int soff = srow * HLD + sch;
+  uint4 rk, rv;
+  {  // K(0)
+    int tok = b_first * 64 + srow;
+    tok = tok < TP ? tok : TP - 1;
+    rk = *reinterpret_cast<const uint4*>(Kg + (size_t)tok * 64 + sch);
+    *reinterpret_cast<uint4*>(Ks + soff) = rk;
+  }
+  __syncthreads();
+
+  const int nphase = 2 * ntile + 2;
+  for (int p = 0; p < nphase; ++p) {
+    const int j = p >> 1;                       // staging pair j = {K(j+1), V(j)}
+    if ((p & 1) == 0 && j < ntile) {
+      const int blk = b_first + j;
+      int tok = (blk + 1) * 64 + srow;
+      tok = tok < TP ? tok : TP - 1;
+      rk = *reinterpret_cast<const uint4*>(Kg + (size_t)tok * 64 + sch);          // K(j+1) (a harmless over-read after the last tile)
+      rv = *reinterpret_cast<const uint4*>(Vg + ((size_t)blk * 64 + srow) * 64 + sch);
+    }
+    const int lp = p - grp;
+    if (wave_active && lp >= 0 && lp <= 2 * ntile) {
+      const int i = lp >> 1;
+      if ((lp & 1) == 0) {
+        // ---------------- M segment: S(i) = K(i) Q^T and O += V(i-1) P(i-1), four independent accumulator chains
+        const u16* kp = Ks + (i & 1) * (HKV * HLD) + l31 * HLD + 8 * hi;
+        const u16* vp = Vs + ((i + 1) & 1) * (HKV * HLD) + l31 * HLD + 8 * hi;
+        if (i < ntile && i >= 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const T8 k0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 16 * s));
+            const T8 k1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 32 * HLD + 16 * s));
+            const T8 v0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 16 * s));
+            const T8 v1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 32 * HLD + 16 * s));
+            s0 = H16<DT>::mfma(k0, qf[s], s0);
+            o0 = H16<DT>::mfma(v0, pb[s], o0);
+            s1 = H16<DT>::mfma(k1, qf[s], s1);
+            o1 = H16<DT>::mfma(v1, pb[s], o1);
+          }
+        } else if (i < ntile) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const T8 k0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 16 * s));
+            const T8 k1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 32 * HLD + 16 * s));
+            s0 = H16<DT>::mfma(k0, qf[s], s0);
+            s1 = H16<DT>::mfma(k1, qf[s], s1);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const T8 v0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 16 * s));
+            const T8 v1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 32 * HLD + 16 * s));
+            o0 = H16<DT>::mfma(v0, pb[s], o0);
+            o1 = H16<DT>::mfma(v1, pb[s], o1);
+          }
+        }
+      } else {
+        // ---------------- V segment: softmax of S(i) -> P(i)
+        const int tile0 = (b_first + i) * 64;
+        if (tile0 < seg0 || tile0 + 64 > seg1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kg = tile0 + mfma32_crow(r, hi);
+            s0[r] = (kg >= seg0 && kg < seg1) ? s0[r] : -1e30f;
+            s1[r] = (kg + 32 >= seg0 && kg + 32 < seg1) ? s1[r] : -1e30f;
+          }
+        }
+        if (!BOUNDED) {
+          float ma = hmax3(s0[0], s0[1], s0[2]), mb = hmax3(s1[0], s1[1], s1[2]);
+#pragma unroll
+          for (int r = 3; r < 15; r += 2) { ma = hmax3(ma, s0[r], s0[r + 1]); mb = hmax3(mb, s1[r], s1[r + 1]); }
+          float mx = hmax3(ma, mb, fmaxf(s0[15], s1[15]));
+          mx = h_xhalf_max(mx);
+          if (!__all((mx - mrun) * c <= DEFER_THR)) {          // the previous tile's P*V (M segment) is complete here
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);
+            mrun = mnew;
+            l2 *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+          }
+        }
+        const f32x2 c2 = {c, c};
+        const f32x2 nmc2 = {-mrun * c, -mrun * c};
+#pragma unroll
+        for (int h8 = 0; h8 < 4; ++h8) {
+          f32x2 e[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = 8 * (h8 & 1) + 2 * k;
+            f32x2 a = (h8 < 2) ? f32x2{s0[r], s0[r + 1]} : f32x2{s1[r], s1[r + 1]};
+            a = __builtin_elementwise_fma(a, c2, nmc2);
+            a.x = __builtin_amdgcn_exp2f(a.x);
+            a.y = __builtin_amdgcn_exp2f(a.y);
+            l2 += a;
+            e[k] = a;
+          }
+          pb[h8] = h16_pack8<DT>(e[0].x, e[0].y, e[1].x, e[1].y, e[2].x, e[2].y, e[3].x, e[3].y);
+        }
+      }
+    }
+    if ((p & 1) == 1 && j < ntile) {
+      *reinterpret_cast<uint4*>(Ks + ((j + 1) & 1) * (HKV * HLD) + soff) = rk;
+      *reinterpret_cast<uint4*>(Vs + (j & 1) * (HKV * HLD) + soff) = rv;
+    }
+    __syncthreads();
+  }
+  if (!wave_active) return;
+  const int q = qw0 + l31;
+  const float inv = 1.0f / h_xhalf_sum(l2.x + l2.y);
+  if (q < len) {
+    u16* op = out + (size_t)(seg0 + q) * (heads * 64) + head * 64 + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<uint2*>(op + 8 * g) =
+          h16_pack4<DT>(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+      *reinterpret_cast<uint2*>(op + 32 + 8 * g) =
+          h16_pack4<DT>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+  }
+}
+
+// tuning knob (rap_set_tuning key 3): 0 = v1 (bounded softmax when per-head logit bounds are supplied -- bf16 only -- else
+// v_max3 row maximum + deferred rescale); 5 = v1 online softmax even with bounds; 11 = ping-pong schedule (slower, see above); 8 = first v1 (fmaxf chain, rescale
 // every tile); 4 = max3 only; 1..3, 6, 7 = timing-only ablations (bf16 only), see ABL above.
 int g_rap_attn_h16_variant = 0;
 
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
-                         int heads, const AttnWorkItem* items, int max_items) {
+                         int heads, const AttnWorkItem* items, int max_items, const float* bound) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0 || vt_nblk * 64 < TP) return RAP_ERR_INVALID;
+#define HPP_LAUNCH(DTV, BV) \
+  hipLaunchKernelGGL((attention_h16_pp_kernel<DTV, BV>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound)
+  if (g_rap_attn_h16_variant == 11) {
+    if (dtype == RAP_DT_BF16) { if (bound) HPP_LAUNCH(RAP_DT_BF16, true); else HPP_LAUNCH(RAP_DT_BF16, false); }
+    else if (dtype == RAP_DT_F16) HPP_LAUNCH(RAP_DT_F16, false);
+    else return RAP_ERR_INVALID;
+    RAP_LAUNCH_CHECK();
+    return RAP_OK;
+  }
 #define HATT_LAUNCH(DTV, ABLV, OPTV) \
-  hipLaunchKernelGGL((attention_h16_kernel<DTV, ABLV, OPTV>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items)
+  hipLaunchKernelGGL((attention_h16_kernel<DTV, ABLV, OPTV>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound)
   if (dtype == RAP_DT_BF16) {
     switch (g_rap_attn_h16_variant) {
       case 1: HATT_LAUNCH(RAP_DT_BF16, 1, 0); break;
@@ -265,7 +474,9 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
       case 6: HATT_LAUNCH(RAP_DT_BF16, 8, 3); break;     // ... without transcendentals
       case 7: HATT_LAUNCH(RAP_DT_BF16, 32, 3); break;    // ... without the max chain
       case 8: HATT_LAUNCH(RAP_DT_BF16, 0, 0); break;     // v1: fmaxf chain, rescale every tile
-      default: HATT_LAUNCH(RAP_DT_BF16, 0, 3); break;
+      default:
+        if (bound) HATT_LAUNCH(RAP_DT_BF16, 0, 8); else HATT_LAUNCH(RAP_DT_BF16, 0, 3);
+        break;
     }
   } else if (dtype == RAP_DT_F16) {
     if (g_rap_attn_h16_variant == 8) HATT_LAUNCH(RAP_DT_F16, 0, 0); else HATT_LAUNCH(RAP_DT_F16, 0, 3);

@@ -107,8 +107,11 @@ struct GemmParamsH {
 int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p);
 int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t* dst, size_t n);
 // attention on q,k half [2][H][TP][64] + transposed-blocked v (vt); out half (TP, H*64)
+// bound: optional per-head upper bounds (device, H floats) on the logits q.k/8 -- enables the bounded-softmax kernel (bf16)
 int launch_attention_h16(hipStream_t stream, int dtype, const uint16_t* qk, const uint16_t* vt, int vt_nblk, uint16_t* out,
-                         int TP, int heads, const AttnWorkItem* items, int max_items);
+                         int TP, int heads, const AttnWorkItem* items, int max_items, const float* bound);
+// per-head logit bounds of one attention branch after qk-norm: out[h] = 8 * max_j|gamma_q[h][j]| * max_j|gamma_k[h][j]|
+int launch_qk_logit_bound(hipStream_t stream, const float* gamma_q, const float* gamma_k, int heads, float* out);
 // LayerNorm with 16-bit output (fp32 statistics), same modulation forms as launch_layernorm_*
 int launch_layernorm_mod_h16(hipStream_t stream, int dtype, const float* x, uint16_t* out, int TP, int d, const float* mod,
                              long mod_stride, const int32_t* token_row);

@@ -119,3 +119,19 @@ int launch_qknorm_h16(hipStream_t stream, int dtype, u16* qk, int TP, int heads,
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }
+
+// Upper bound of the attention logits of one (layer, branch) after MultiHeadRMSNorm: q = x/|x| * gamma_q * 8, so
+// |q| <= 8 max|gamma_q| (same for k) and q.k/8 <= 8 max|gamma_q| max|gamma_k|.  One wave per head.
+__global__ __launch_bounds__(64) void qk_logit_bound_kernel(const float* __restrict__ gq, const float* __restrict__ gk,
+                                                            float* __restrict__ out) {
+  const int h = blockIdx.x, lane = threadIdx.x;
+  float a = fabsf(gq[h * 64 + lane]), b = fabsf(gk[h * 64 + lane]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
+  if (lane == 0) out[h] = 8.0f * a * b * 1.001f;      // 0.1 % slack for the fp32 roundings inside qknorm
+}
+int launch_qk_logit_bound(hipStream_t stream, const float* gamma_q, const float* gamma_k, int heads, float* out) {
+  hipLaunchKernelGGL(qk_logit_bound_kernel, dim3(heads), dim3(64), 0, stream, gamma_q, gamma_k, out);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}

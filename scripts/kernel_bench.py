@@ -70,17 +70,18 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
         qk = qk.to(tdt)
         vt = torch.randn(H, nblk, 64, 64, device=dev, generator=g).to(tdt)
         out = torch.empty(TP, d, device=dev, dtype=tdt)
+        bound = torch.full((H,), 8.01, device=dev) if args.bounded else None     # |q| = |k| = 8  ->  q.k/8 <= 8
         for name, L in (("per part", args.points), ("per sample", args.points * args.views)):
             cu = torch.arange(0, TP + 1, L, dtype=torch.int32, device=dev)
             nseg = cu.numel() - 1
             ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, nseg))
             def fn():
                 rc = lib.rap_attention_h16(dt, _lib.ptr(qk), _lib.ptr(vt), nblk, _lib.ptr(cu), nseg, _lib.ptr(out), TP, H,
-                                           _lib.ptr(ws), ws.numel(), st())
+                                           _lib.ptr(bound), _lib.ptr(ws), ws.numel(), st())
                 assert rc == 0, rc
             t = timeit(fn, iters=1 if args.pmc else 5, warm=0 if args.pmc else 2)
             fl = 4.0 * H * 64 * L * TP
-            rows.append({"kernel": f"attention_h16[{name} L={L}]", "dtype": args.dtype, "variant": args.h16_attn_variant, "ms": t * 1e3, "tflops": fl / t / 1e12,
+            rows.append({"kernel": f"attention_h16[{name} L={L}]", "dtype": args.dtype, "variant": args.h16_attn_variant, "bounded": bool(args.bounded), "ms": t * 1e3, "tflops": fl / t / 1e12,
                          "frac_of_2500TF": fl / t / 1e12 / PEAK})
     if args.only == "":
         x = torch.randn(TP, d, device=dev, generator=g); y = torch.empty(TP, d, device=dev, dtype=tdt)
@@ -111,6 +112,7 @@ def main():
     ap.add_argument("--dtype", default="float32", help="float32 | bfloat16 | float16 (16-bit: GEMM / attention / LN / qknorm twins)")
     ap.add_argument("--h16-gemm-variant", type=int, default=-1)
     ap.add_argument("--h16-attn-variant", type=int, default=-1, help="timing-only ablations of the 16-bit attention kernel")
+    ap.add_argument("--bounded", type=int, default=1, help="pass per-head logit bounds to the 16-bit attention (bounded-softmax v2, bf16)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()

@@ -194,15 +194,16 @@ def pack_qkv(q, k, v, dt, dev):
     return qk, vt.to(dev), nblk
 
 
-def run_attention_h(lib, dev, dt, q, k, v, cu):
+def run_attention_h(lib, dev, dt, q, k, v, cu, bound=None):
     H, TP, _ = q.shape
     qk, vt, nblk = pack_qkv(q, k, v, dt, dev)
     cu_d = cu.to(device=dev, dtype=torch.int32)
     nseg = cu.numel() - 1
     ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, nseg))
     out = torch.full((TP, H * 64), float("nan"), dtype=TORCH_DT[dt], device=dev)
-    rc = lib.rap_attention_h16(dt, _lib.ptr(qk), _lib.ptr(vt), nblk, _lib.ptr(cu_d), nseg, _lib.ptr(out), TP, H, _lib.ptr(ws),
-                               ws.numel(), stream(dev))
+    bound_d = None if bound is None else bound.to(device=dev, dtype=torch.float32)
+    rc = lib.rap_attention_h16(dt, _lib.ptr(qk), _lib.ptr(vt), nblk, _lib.ptr(cu_d), nseg, _lib.ptr(out), TP, H, _lib.ptr(bound_d),
+                               _lib.ptr(ws), ws.numel(), stream(dev))
     _lib.check(rc, "rap_attention_h16")
     torch.cuda.synchronize()
     return out.cpu()
@@ -222,9 +223,15 @@ def attention_ref64(q, k, v, cu, dt):
     return out
 
 
+def logit_bound(q, k):
+    """per-head bound on q.k/8 by Cauchy-Schwarz (what 8 max|gamma_q| max|gamma_k| is after qk-norm)"""
+    return q.norm(dim=-1).amax(dim=1) * k.norm(dim=-1).amax(dim=1) / 8.0 * 1.01
+
+
+@pytest.mark.parametrize("bounded", [False, True], ids=["online-max", "bounded"])
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("H", [1, 8])
-def test_attention_h16_ragged_segments(lib, dev, dt, H):
+def test_attention_h16_ragged_segments(lib, dev, dt, H, bounded):
     g = torch.Generator().manual_seed(11 + H)
     lens = [1, 63, 64, 65, 300, 0, 257, 1000, 31, 512]          # unaligned starts, empty segment, multi-block segments
     cu = torch.tensor([0] + lens).cumsum(0)
@@ -232,7 +239,7 @@ def test_attention_h16_ragged_segments(lib, dev, dt, H):
     q = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8 * (0.5 + torch.rand(H, 1, 64, generator=g))
     k = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8 * (0.5 + torch.rand(H, 1, 64, generator=g))
     v = torch.randn(H, TP, 64, generator=g)
-    out = run_attention_h(lib, dev, dt, q, k, v, cu)
+    out = run_attention_h(lib, dev, dt, q, k, v, cu, bound=logit_bound(q, k) if bounded else None)
     ref = attention_ref64(q, k, v, cu, dt)
     assert not torch.isnan(out.float()).any()
     err = (out.double() - ref).abs().max().item()
@@ -250,6 +257,8 @@ def test_attention_h16_single_token_segments_return_v(lib, dev, dt):
     out = run_attention_h(lib, dev, dt, q, k, v, torch.arange(TP + 1))
     want = to_h(v, dt).permute(1, 0, 2).reshape(TP, H * 64)
     assert torch.equal(out, want)        # softmax over one key is exactly 1
+    outb = run_attention_h(lib, dev, dt, q, k, v, torch.arange(TP + 1), bound=logit_bound(q, k))
+    assert (outb.float() - want.float()).abs().max().item() <= 2 * ULP[dt] * want.float().abs().max().item()
 
 
 @pytest.mark.parametrize("dt", [1, 2])
@@ -260,10 +269,11 @@ def test_attention_h16_sharp_softmax_and_late_maximum(lib, dev, dt):
     for spike_at in (L - 1, 0, 350):
         q = torch.randn(H, L, 64, generator=g); k = torch.randn(H, L, 64, generator=g) * 0.1; v = torch.randn(H, L, 64, generator=g)
         k[:, spike_at] = q[:, 5] * 4.0      # q5 . k_spike / 8 is huge for query 5, large for the others' projections
-        out = run_attention_h(lib, dev, dt, q, k, v, torch.tensor([0, L]))
         ref = attention_ref64(q, k, v, torch.tensor([0, L]), dt)
-        err = (out.double() - ref).abs().max().item()
-        assert err < 8 * ULP[dt], (spike_at, err)
+        for bound in (None, logit_bound(q, k).clamp(max=40.0)):
+            out = run_attention_h(lib, dev, dt, q, k, v, torch.tensor([0, L]), bound=bound)
+            err = (out.double() - ref).abs().max().item()
+            assert err < 8 * ULP[dt], (spike_at, bound is not None, err)
 
 
 @pytest.mark.parametrize("dt", [1, 2])
@@ -278,7 +288,7 @@ def test_attention_h16_full_size_agrees_with_fp32_kernel(lib, dev, dt):
     v = torch.randn(H, TP, 64, generator=g)
     for seg in (L, 2 * L):
         cu = torch.arange(0, TP + 1, seg)
-        out = run_attention_h(lib, dev, dt, q, k, v, cu)
+        out = run_attention_h(lib, dev, dt, q, k, v, cu, bound=torch.full((H,), 8.01))
         qkv32 = torch.stack([to_h(q, dt).float(), to_h(k, dt).float(), to_h(v, dt).float()]).contiguous().to(dev)
         o32 = torch.empty(TP, H * 64, device=dev)
         ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, cu.numel() - 1))
@@ -287,7 +297,7 @@ def test_attention_h16_full_size_agrees_with_fp32_kernel(lib, dev, dt):
         torch.cuda.synchronize()
         err = (out.float() - o32.cpu()).abs().max().item()
         assert err < 4 * ULP[dt], (seg, err)
-        ones = run_attention_h(lib, dev, dt, q, k, torch.ones_like(v), cu)
+        ones = run_attention_h(lib, dev, dt, q, k, torch.ones_like(v), cu, bound=torch.full((H,), 8.01))
         assert (ones.float() - 1.0).abs().max().item() <= 2 * ULP[dt]
 
 
@@ -450,3 +460,27 @@ def test_baseline_geometries_h16_agrees_with_fp32_path(label, batch, views, poin
     rig = rap_amd.rigidify_prediction_with_procrustes(a["end_point_trajectory"][-1], d["pointclouds"], inp["points_per_part"],
                                                       inp["cu_seqlens"])
     assert (a["trajectory"][-1] - rig).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("variant", [5, 11], ids=["online-softmax", "ping-pong"])
+def test_attention_h16_schedule_variants_agree(lib, dev, dt, variant):
+    """rap_set_tuning(3, .) selects alternative schedules of the 16-bit attention (online softmax even when logit bounds are
+    given; the ping-pong wave schedule): same function, results within rounding of the default."""
+    g = torch.Generator().manual_seed(31)
+    H = 4
+    cu = torch.tensor([0, 100, 164, 700, 1213, 1214, 2000])
+    TP = int(cu[-1])
+    q = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8
+    k = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8
+    v = torch.randn(H, TP, 64, generator=g)
+    bound = logit_bound(q, k)
+    base = run_attention_h(lib, dev, dt, q, k, v, cu, bound=bound)
+    assert lib.rap_set_tuning(3, variant) == 0
+    try:
+        alt = run_attention_h(lib, dev, dt, q, k, v, cu, bound=bound)
+    finally:
+        assert lib.rap_set_tuning(3, 0) == 0
+    ref = attention_ref64(q, k, v, cu, dt)
+    assert (alt.double() - ref).abs().max().item() < 8 * ULP[dt]
+    assert (alt.float() - base.float()).abs().max().item() < 4 * ULP[dt]
