@@ -49,7 +49,7 @@ SIGNATURES = {
                                _P, _P, c_int32, _P]),
     "rap_geglu_interleave": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P]),
     "rap_attention_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "rap_attention_f32": (c_int32, [_P, _P, c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
+    "rap_attention_f32": (c_int32, [_P, _P, c_int32, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "rap_layernorm_mod": (c_int32, [_P, _P, c_int64, c_int32, _P, c_int64, _P, _P]),
     "rap_layernorm_affine": (c_int32, [_P, _P, c_int64, c_int32, _P, _P, _P]),
     "rap_qknorm": (c_int32, [_P, c_int64, c_int32, _P, _P, _P]),

@@ -141,6 +141,8 @@ extern "C" int64_t rap_weight_count(const rap_model_desc* desc) {
   return n;
 }
 
+static int ensure_logit_bounds(rap_model* m, hipStream_t stream);
+
 extern "C" int rap_model_create(const rap_model_desc* desc, const float* d_weights, int64_t n_floats, void* stream_,
                                 rap_model** out) {
   if (!out) return RAP_ERR_INVALID;
@@ -226,6 +228,7 @@ extern "C" int rap_model_create(const rap_model_desc* desc, const float* d_weigh
   m->hW2 = take((size_t)(d / 2) * d); m->hb2 = take(d / 2);
   m->hW4 = take((size_t)3 * (d / 2));
   if ((int64_t)(p - m->raw) != n_floats || (size_t)(q - m->derived) != n_derived) return fail(RAP_ERR_INVALID);
+  if ((rc = ensure_logit_bounds(m, stream))) return fail(rc);
   *out = m;
   return RAP_OK;
 }
@@ -238,6 +241,25 @@ extern "C" void rap_model_destroy(rap_model* m) {
     if (m->half[i].blob) (void)hipFree(m->half[i].blob);
   if (m->logit_bound) (void)hipFree(m->logit_bound);
   delete m;
+}
+
+// Per-head bounds on the attention logits from the qk-norm gains (a property of the weights): (L, 2, H) floats on the
+// device; read back once (model creation may synchronise) to decide whether the bounded-softmax kernels are admissible.
+static int ensure_logit_bounds(rap_model* m, hipStream_t stream) {
+  if (m->logit_bound) return RAP_OK;
+  const int n = m->L * 2 * m->H;
+  if (hipMalloc((void**)&m->logit_bound, (size_t)n * sizeof(float)) != hipSuccess) { m->logit_bound = nullptr; return RAP_ERR_ALLOC; }
+  for (int i = 0; i < m->L; ++i)
+    for (int a = 0; a < 2; ++a) {
+      const int rc = launch_qk_logit_bound(stream, m->layers[i].gq[a], m->layers[i].gk[a], m->H, m->logit_bound + (size_t)(2 * i + a) * m->H);
+      if (rc) return rc;
+    }
+  std::vector<float> hb(n);
+  RAP_HIP_CHECK(hipMemcpyAsync(hb.data(), m->logit_bound, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream));
+  RAP_HIP_CHECK(hipStreamSynchronize(stream));
+  m->bounded_ok = true;
+  for (float b : hb) if (!(b <= RAP_MAX_LOGIT_BOUND)) m->bounded_ok = false;
+  return RAP_OK;
 }
 
 extern "C" int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* stream_) {
@@ -270,23 +292,7 @@ extern "C" int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* st
     }
     if (rc != RAP_OK) { (void)hipFree(hw.blob); hw.blob = nullptr; hw.layers.clear(); return rc; }
   }
-  if (!m->logit_bound) {
-    // logit bounds from the qk-norm gains (a property of the weights); model creation may synchronise, so read them
-    // back once to decide whether the bounded-softmax kernel is admissible for this checkpoint
-    hipStream_t stream = (hipStream_t)stream_;
-    const int n = m->L * 2 * m->H;
-    if (hipMalloc((void**)&m->logit_bound, (size_t)n * sizeof(float)) != hipSuccess) { m->logit_bound = nullptr; return RAP_ERR_ALLOC; }
-    for (int i = 0; i < m->L; ++i)
-      for (int a = 0; a < 2; ++a) {
-        const int rc = launch_qk_logit_bound(stream, m->layers[i].gq[a], m->layers[i].gk[a], m->H, m->logit_bound + (size_t)(2 * i + a) * m->H);
-        if (rc) return rc;
-      }
-    std::vector<float> hb(n);
-    RAP_HIP_CHECK(hipMemcpyAsync(hb.data(), m->logit_bound, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream));
-    RAP_HIP_CHECK(hipStreamSynchronize(stream));
-    m->bounded_ok = true;
-    for (float b : hb) if (!(b <= RAP_MAX_LOGIT_BOUND)) m->bounded_ok = false;
-  }
+  { const int rcb = ensure_logit_bounds(m, (hipStream_t)stream_); if (rcb) return rcb; }
   m->dtype = dtype;
   return RAP_OK;
 }
@@ -444,8 +450,9 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       if ((rc = launch_qknorm(stream, w.qkv, TP, H, lw.gq[a], lw.gk[a]))) return rc;
       {
         ProfScope ps(stream, a);
-        if (a == 0) rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_part, w.max_items_part);
-        else rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_batch, w.max_items_batch);
+        const float* bound = m->bounded_ok ? m->logit_bound + (size_t)j * H : nullptr;
+        if (a == 0) rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_part, w.max_items_part, bound);
+        else rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_batch, w.max_items_batch, bound);
       }
       if (rc) return rc;
       GemmParams o{};
@@ -652,14 +659,15 @@ extern "C" size_t rap_attention_workspace_bytes(int64_t TP, int32_t nseg) {
 }
 
 extern "C" int rap_attention_f32(const float* qkv_headmajor, const int32_t* cu_seqlens, int32_t nseg, float* out,
-                                 int64_t TP, int32_t heads, void* ws, size_t ws_bytes, void* stream_) {
+                                 int64_t TP, int32_t heads, const float* logit_bound, void* ws, size_t ws_bytes,
+                                 void* stream_) {
   if (!qkv_headmajor || !cu_seqlens || !out || nseg < 0 || TP < 0 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
   if (!ws || ws_bytes < rap_attention_workspace_bytes(TP, nseg)) return RAP_ERR_WORKSPACE;
   const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
   if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, 0))) return rc;
-  return launch_attention_f32(stream, qkv_headmajor, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items);
+  return launch_attention_f32(stream, qkv_headmajor, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound);
 }
 
 extern "C" int rap_layernorm_mod(const float* x, float* out, int64_t TP, int32_t d, const float* mod, int64_t mod_stride,

@@ -38,8 +38,9 @@ struct AttnWorkItem { int seg_start, seg_len, q0, pad; };
 // the 16-bit attention kernel always takes 256.
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,
                                int max_items, int block_queries);
+// bound: optional per-head upper bounds (device, H floats) on the logits q.k/8 -> bounded-softmax instantiation
 int launch_attention_f32(hipStream_t stream, const float* qkv_headmajor, float* out, int TP, int heads,
-                         const AttnWorkItem* items, int max_items);
+                         const AttnWorkItem* items, int max_items, const float* bound);
 
 // ---------------------------------------------------------------------------------------------
 // memory-bound ring

@@ -160,16 +160,17 @@ def main():
     qkv = torch.randn(3, H, TP, 64, device=dev, generator=g)
     qkv[:2] = torch.nn.functional.normalize(qkv[:2], dim=-1) * 8
     out = torch.empty(TP, d, device=dev)
+    bound32 = torch.full((H,), 8.01, device=dev) if args.bounded else None     # |q| = |k| = 8  ->  q.k/8 <= 8
     for name, L in (("per part", args.points), ("per sample", args.points * args.views)):
         cu = torch.arange(0, TP + 1, L, dtype=torch.int32, device=dev)
         nseg = cu.numel() - 1
         ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, nseg))
         def fn():
-            rc = lib.rap_attention_f32(_lib.ptr(qkv), _lib.ptr(cu), nseg, _lib.ptr(out), TP, H, _lib.ptr(ws), ws.numel(), st())
+            rc = lib.rap_attention_f32(_lib.ptr(qkv), _lib.ptr(cu), nseg, _lib.ptr(out), TP, H, _lib.ptr(bound32), _lib.ptr(ws), ws.numel(), st())
             assert rc == 0, rc
         t = timeit(fn, iters=1 if args.pmc else 3, warm=0 if args.pmc else 1)
         fl = 4.0 * H * 64 * L * TP
-        rows.append({"kernel": f"attention_f32[{name} L={L}]", "variant": args.attn_variant, "ms": t * 1e3, "tflops": fl / t / 1e12,
+        rows.append({"kernel": f"attention_f32[{name} L={L}]", "variant": args.attn_variant, "bounded": bool(args.bounded), "ms": t * 1e3, "tflops": fl / t / 1e12,
                      "frac_of_157.3TF": fl / t / 1e12 / 157.3})
 
     if args.only == "attention":

@@ -293,7 +293,7 @@ def test_attention_h16_full_size_agrees_with_fp32_kernel(lib, dev, dt):
         o32 = torch.empty(TP, H * 64, device=dev)
         ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, cu.numel() - 1))
         _lib.check(lib.rap_attention_f32(_lib.ptr(qkv32), _lib.ptr(cu.to(device=dev, dtype=torch.int32)), cu.numel() - 1, _lib.ptr(o32),
-                                         TP, H, _lib.ptr(ws), ws.numel(), stream(dev)), "attention_f32")
+                                         TP, H, _lib.ptr(None), _lib.ptr(ws), ws.numel(), stream(dev)), "attention_f32")
         torch.cuda.synchronize()
         err = (out.float() - o32.cpu()).abs().max().item()
         assert err < 4 * ULP[dt], (seg, err)

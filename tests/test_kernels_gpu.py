@@ -135,22 +135,24 @@ def test_gemm_full_size_linearity_property(lib, dev):
 # ---------------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------------
-def run_attention(lib, dev, qkv_thd, cu):
-    """qkv_thd: (T,3,H,64) fp32 CPU -> out (T,H,64) from the HIP kernel."""
+def run_attention(lib, dev, qkv_thd, cu, bound=None):
+    """qkv_thd: (T,3,H,64) fp32 CPU -> out (T,H,64) from the HIP kernel.  bound: optional (H,) logit bounds -> bounded softmax."""
     T, _, H, D = qkv_thd.shape
+    bound_d = None if bound is None else bound.to(device=dev, dtype=torch.float32)
     hm = qkv_thd.permute(1, 2, 0, 3).contiguous().to(dev)     # [3][H][T][64]
     cu_d = cu.to(torch.int32).to(dev)
     out = torch.full((T, H * 64), float("nan"), device=dev)
     nseg = cu.numel() - 1
     ws = workspace(dev, lib.rap_attention_workspace_bytes(T, nseg))
-    rc = lib.rap_attention_f32(_lib.ptr(hm), _lib.ptr(cu_d), nseg, _lib.ptr(out), T, H, _lib.ptr(ws), ws.numel(), stream(dev))
+    rc = lib.rap_attention_f32(_lib.ptr(hm), _lib.ptr(cu_d), nseg, _lib.ptr(out), T, H, _lib.ptr(bound_d), _lib.ptr(ws), ws.numel(), stream(dev))
     _lib.check(rc, "rap_attention_f32")
     torch.cuda.synchronize()
     return out.cpu().reshape(T, H, 64)
 
 
+@pytest.mark.parametrize("bounded", [False, True], ids=["online-max", "bounded"])
 @pytest.mark.parametrize("H", [1, 8])
-def test_attention_ragged_segments_match_fp64(lib, dev, H):
+def test_attention_ragged_segments_match_fp64(lib, dev, H, bounded):
     g = torch.Generator().manual_seed(11 + H)
     cu = torch.tensor([0, 1, 38, 38, 294, 600, 1624, 1657])     # lengths 1, 37, 0, 256, 306, 1024, 33
     T = int(cu[-1])
@@ -159,7 +161,8 @@ def test_attention_ragged_segments_match_fp64(lib, dev, H):
     qkv[:, 0] = F.normalize(qkv[:, 0], dim=-1) * 8
     qkv[:, 1] = F.normalize(qkv[:, 1], dim=-1) * 8
     ref = O.varlen_attention(qkv.double(), cu.to(torch.int32))
-    out = run_attention(lib, dev, qkv, cu)
+    # |q| = |k| = 8 -> q.k/8 <= 8: the bound the model derives from the qk-norm gains (bounded-softmax instantiation)
+    out = run_attention(lib, dev, qkv, cu, bound=torch.full((H,), 8.01) if bounded else None)
     assert not torch.isnan(out).any()
     err = (out.double() - ref).abs().max().item()
     assert err < 5e-6, err     # softmax-weighted mean of |v| <~ 4: fp32 round-off is ~1e-6
@@ -171,6 +174,9 @@ def test_attention_single_token_segments_return_v(lib, dev):
     cu = torch.tensor([0, 1, 2, 3, 4, 5])
     out = run_attention(lib, dev, qkv, cu)
     assert (out - qkv[:, 2]).abs().max().item() < 1e-6
+    bound = (qkv[:, 0].norm(dim=-1).amax(0) * qkv[:, 1].norm(dim=-1).amax(0) / 8.0) * 1.01
+    outb = run_attention(lib, dev, qkv, cu, bound=bound)
+    assert (outb - qkv[:, 2]).abs().max().item() < 2e-6
 
 
 def test_attention_sharp_softmax_and_late_maximum(lib, dev):
@@ -203,7 +209,7 @@ def test_attention_full_size_properties(lib, dev):
         ws = workspace(dev, lib.rap_attention_workspace_bytes(T, nseg))
         hm = torch.stack([q, k, v]).permute(0, 2, 1, 3).contiguous()     # [3][H][T][64]
         out = torch.empty((T, H * 64), device=dev)
-        _lib.check(lib.rap_attention_f32(_lib.ptr(hm), _lib.ptr(cu), nseg, _lib.ptr(out), T, H, _lib.ptr(ws), ws.numel(),
+        _lib.check(lib.rap_attention_f32(_lib.ptr(hm), _lib.ptr(cu), nseg, _lib.ptr(out), T, H, _lib.ptr(None), _lib.ptr(ws), ws.numel(),
                                          stream(dev)), "attn")
         ref = torch.empty((T, H, 64), device=dev)
         for s in range(nseg):
@@ -215,7 +221,7 @@ def test_attention_full_size_properties(lib, dev):
         print(f"full-size attention {cu_list}: max abs err vs fp64 SDPA {e_ref:.2e}")
         assert e_ref < 5e-6, e_ref
         hm1 = torch.stack([q, k, torch.ones_like(v)]).permute(0, 2, 1, 3).contiguous()
-        _lib.check(lib.rap_attention_f32(_lib.ptr(hm1), _lib.ptr(cu), nseg, _lib.ptr(out), T, H, _lib.ptr(ws), ws.numel(),
+        _lib.check(lib.rap_attention_f32(_lib.ptr(hm1), _lib.ptr(cu), nseg, _lib.ptr(out), T, H, _lib.ptr(None), _lib.ptr(ws), ws.numel(),
                                          stream(dev)), "attn")
         torch.cuda.synchronize()
         e_one = (out - 1.0).abs().max().item()
@@ -403,7 +409,7 @@ def test_attention_large_scan_geometry_one_head(lib, dev):
         nseg = len(cu_list) - 1
         ws = workspace(dev, lib.rap_attention_workspace_bytes(T, nseg))
         out = torch.empty((T, 64), device=dev)
-        _lib.check(lib.rap_attention_f32(_lib.ptr(hm), _lib.ptr(cu), nseg, _lib.ptr(out), T, H, _lib.ptr(ws), ws.numel(),
+        _lib.check(lib.rap_attention_f32(_lib.ptr(hm), _lib.ptr(cu), nseg, _lib.ptr(out), T, H, _lib.ptr(None), _lib.ptr(ws), ws.numel(),
                                          stream(dev)), "attn")
         torch.cuda.synchronize()
         worst = 0.0
