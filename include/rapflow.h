@@ -109,6 +109,27 @@ int rap_sample(const rap_model* m, const float* cond, const float* feat, const f
                int64_t TP, int32_t num_steps, int32_t rigidity_forcing, float* traj_x0, float* traj_xt, float* R_out,
                float* t_out, float* feats_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- generation selection by rigidity (the caller side of the path) ----
+ * Replaces compute_rigidity_rmse (reference eval/metrics.py:511-622): per sample, the RMS of |cond_p R_p^T + t_p - pred_p|
+ * over the points of all non-empty parts (average_per_part: mean over parts of the per-part RMS), inf for a sample
+ * without points, times scales[b] if scales != NULL.  out (B,).  ws >= rap_rigidity_workspace_bytes(B*P, steps, B). */
+size_t rap_rigidity_workspace_bytes(int32_t nparts, int32_t steps, int32_t B);
+int rap_rigidity_rmse(const float* cond, const float* pred, const float* R, const float* t, const int64_t* points_per_part,
+                      int32_t B, int32_t P, const float* scales, int32_t average_per_part, float* out, void* ws,
+                      size_t ws_bytes, void* stream);
+/* Replaces the use_average_rigidity_rmse loop of test_step (reference modeling.py:466-500): for every step of the
+ * end-point trajectory traj (steps,TP,3): R,t = fit_transformations(cond, traj[s]); rmse[s] = rigidity RMSE; mean_out (B,) =
+ * mean over steps.  per_step_out (steps,B) or NULL. */
+int rap_trajectory_rigidity_rmse(const float* cond, const float* traj, const int64_t* points_per_part, int32_t B, int32_t P,
+                                 int64_t TP, int32_t steps, const float* scales, float* mean_out, float* per_step_out, void* ws,
+                                 size_t ws_bytes, void* stream);
+/* Replaces the rigidity-selected generation pick (reference modeling.py:518, 560-592): best_out[b] = argmin_g rmse[g][b]
+ * (first minimum); if clouds != NULL also gathers cloud_out (TP,3), R_out (B,P,3,3), t_out (B,P,3) of the picked generation
+ * per sample from clouds (G,TP,3), R (G,B,P,3,3), t (G,B,P,3); cu_batch (B+1,) int32. */
+int rap_select_generation(const float* rmse, int32_t G, int32_t B, int32_t P, int64_t TP, const int32_t* cu_batch,
+                          const float* clouds, const float* R, const float* t, int32_t* best_out, float* cloud_out,
+                          float* R_out, float* t_out, void* stream);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels the calls above launch) ---- */
 /* C(M,N) = A(M,K) W(N,K)^T (+bias) (+resid) ; epilogue: 0 bias, 1 bias+resid, 2 bias+SiLU,
  * 3 GEGLU (W/bias must be value/gate interleaved by rap_geglu_interleave; C is (M,N/2)),

@@ -66,5 +66,39 @@ def main():
         print(name, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_selection_golden():
+    """Generation selection by rigidity: 3 generations of the l2_ragged_rigid case with
+    rigidity forcing OFF (so the trajectories are not rigid and the RMSEs differ), a sample with an empty part, averaged
+    over the trajectory steps and at the final step; reference = its own fit_transformations + compute_rigidity_rmse."""
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    sd = S.make_weights(cfg, 1)
+    inp = S.make_inputs([[70, 45, 0], [33, 90, 61], [128, 40]], seed=13)
+    cu_b, _ = O.prepare_cu_seqlens(inp)
+    trajs = []
+    for seed in (104, 109, 101):      # chosen so that the three objects pick three different generations
+        gen = torch.Generator().manual_seed(seed)
+        x_1 = torch.randn(inp["x_1"].shape, generator=gen)
+        inp_g = dict(inp); inp_g["x_1"] = x_1
+        trajs.append(ref_loader.reference_sample(cfg, sd, inp_g, 4, False)["end_point_trajectory"])
+    out = {"num_layers": np.int64(2), "weight_seed": np.int64(1), "num_steps": np.int64(4)}
+    for k, v in inp.items():
+        out["in_" + k] = v.numpy()
+    out["trajectories"] = torch.stack(trajs).numpy()
+    for tag, use_avg in (("avg", True), ("final", False)):
+        r = ref_loader.reference_generation_selection(inp["pointclouds"], trajs, inp["points_per_part"], cu_b.long(), inp["scales"],
+                                                      use_average=use_avg)
+        for k, v in r.items():
+            out[f"{tag}_{k}"] = v.numpy()
+    ref = ref_loader.load_reference()
+    Rf, tf = ref.fit_transformations(inp["pointclouds"], trajs[0][-1], inp["points_per_part"], cu_b.long())
+    out["per_part_rmse"] = ref.compute_rigidity_rmse(inp["pointclouds"], trajs[0][-1], Rf, tf, inp["points_per_part"], cu_b.long(),
+                                                     None, average_per_part=True).numpy()
+    path = os.path.join(GOLDEN_DIR, "selection_g3.npz")
+    np.savez_compressed(path, **out)
+    print("selection_g3", os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if "--selection-only" not in sys.argv:
+        main()
+    make_selection_golden()

@@ -330,6 +330,53 @@ def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.
 # ----------------------------------------------------------------------------
 # eval/metrics.py:284-294 -- the SE(3) error formulae used to report pose deviation
 # ----------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------
+# generation selection by rigidity
+# ---------------------------------------------------------------------------------------------
+def compute_rigidity_rmse(cond, pred, R, t, points_per_part, cu_seqlens_batch, scales=None, average_per_part=False):
+    """eval/metrics.py:511-622: per object RMS of |cond_p R_p^T + t_p - pred_p| over all points of its non-empty parts
+    (average_per_part: mean over parts of the per-part RMS); inf for an object without points; x scales."""
+    B, P = points_per_part.shape
+    parts_in = split_parts(cond, points_per_part, cu_seqlens_batch)
+    parts_pr = split_parts(pred, points_per_part, cu_seqlens_batch)
+    out = torch.zeros(B, dtype=cond.dtype)
+    for b in range(B):
+        sq, rm = [], []
+        for p in range(P):
+            if points_per_part[b, p] == 0:
+                continue                                                          # metrics.py:566-567 / 594-595
+            e = ((parts_in[b][p] @ R[b, p].T + t[b, p] - parts_pr[b][p]) ** 2).sum(dim=1)   # :577-581 / :605-609
+            sq.append(e); rm.append(torch.sqrt(e.mean()))
+        if not sq:
+            out[b] = float("inf")                                                 # :589 / :616
+        elif average_per_part:
+            out[b] = torch.stack(rm).mean()                                       # :587
+        else:
+            out[b] = torch.sqrt(torch.cat(sq).mean())                             # :613-614
+    return out * scales if scales is not None else out                            # :619-620
+
+
+def average_trajectory_rigidity_rmse(cond, trajectory, points_per_part, cu_seqlens_batch, scales=None):
+    """modeling.py:466-489: mean over trajectory steps of the rigidity RMSE of each step against its own Procrustes fit.
+    -> (mean (B,), per_step (S,B))"""
+    per_step = []
+    for s in range(trajectory.shape[0]):
+        R, t = fit_transformations(cond, trajectory[s], points_per_part, cu_seqlens_batch)          # :479-481
+        per_step.append(compute_rigidity_rmse(cond, trajectory[s], R, t, points_per_part, cu_seqlens_batch, scales))
+    per_step = torch.stack(per_step)
+    return per_step.mean(dim=0), per_step                                                          # :489
+
+
+def select_generations_by_rigidity(stacked_rigidity, final_clouds, rotations, translations, cu_seqlens_batch):
+    """modeling.py:518, 560-592: per object the generation of smallest rigidity RMSE; gather its cloud / R / t."""
+    best = torch.argmin(stacked_rigidity, dim=0)
+    B = best.shape[0]
+    cloud = torch.cat([final_clouds[int(best[b])][int(cu_seqlens_batch[b]):int(cu_seqlens_batch[b + 1])] for b in range(B)])
+    R = torch.stack([rotations[int(best[b])][b] for b in range(B)])
+    t = torch.stack([translations[int(best[b])][b] for b in range(B)])
+    return best, cloud, R, t
+
+
 def rotation_error_deg(R_a: torch.Tensor, R_b: torch.Tensor) -> torch.Tensor:
     """acos((trace(R_a^T R_b) - 1) / 2) in degrees, clamped (metrics.py:289-291)."""
     tr = torch.einsum("...ij,...ij->...", R_a, R_b)

@@ -153,6 +153,21 @@ def _install_stubs():
                             "diffusers.models.attention": da, "diffusers.models.embeddings": de})
 
 
+def _install_pytorch3d_import_stub():
+    """eval/metrics.py imports pytorch3d (0.7.8, install.sh:16) at module level for chamfer / ICP metrics that are NOT on
+    the path; compute_rigidity_rmse (metrics.py:511-622) does not touch it.  The stub only lets the unmodified module
+    import; calling the stubbed functions raises."""
+    if "pytorch3d" in sys.modules:
+        return
+    def _absent(*a, **k):
+        raise NotImplementedError("pytorch3d is not installed in this container (stub for import only)")
+    p3 = types.ModuleType("pytorch3d"); p3.__path__ = []
+    loss = types.ModuleType("pytorch3d.loss"); loss.__path__ = []
+    ch = types.ModuleType("pytorch3d.loss.chamfer"); ch.chamfer_distance = _absent
+    ops = types.ModuleType("pytorch3d.ops"); ops.iterative_closest_point = _absent
+    sys.modules.update({"pytorch3d": p3, "pytorch3d.loss": loss, "pytorch3d.loss.chamfer": ch, "pytorch3d.ops": ops})
+
+
 _LOADED = None
 
 
@@ -178,8 +193,46 @@ def load_reference():
     ns.get_sampler = ns.sampler.get_sampler
     ns.fit_transformations = ns.procrustes.fit_transformations
     ns.rigidify_prediction_with_procrustes = ns.procrustes.rigidify_prediction_with_procrustes
+    # generation selection: the reference's own compute_rigidity_rmse
+    _install_pytorch3d_import_stub()
+    evalp = types.ModuleType("rectified_point_flow.eval"); evalp.__path__ = [os.path.join(pkg_dir, "eval")]
+    sys.modules.setdefault("rectified_point_flow.eval", evalp)
+    ns.metrics = importlib.import_module("rectified_point_flow.eval.metrics")
+    ns.compute_rigidity_rmse = ns.metrics.compute_rigidity_rmse
     _LOADED = ns
     return ns
+
+
+def reference_generation_selection(cond, trajectories, points_per_part, cu_seqlens_batch, scales, use_average=True):
+    """The rigidity-selection block of the reference's test_step (modeling.py:456-592) driven with the reference's OWN
+    fit_transformations and compute_rigidity_rmse; the surrounding LightningModule bookkeeping (logging, evaluator) is not
+    importable here (lightning / hydra), so the ~25 lines of control flow are restated verbatim below.
+    trajectories: list over generations of (S,TP,3) end-point trajectories."""
+    ref = load_reference()
+    n_rot, n_trans, rig = [], [], []
+    with torch.inference_mode():
+        for trajs in trajectories:
+            R, t = ref.fit_transformations(cond, trajs[-1], points_per_part, cu_seqlens_batch)       # modeling.py:389-391
+            n_rot.append(R); n_trans.append(t)
+            if use_average:                                                                          # :466-500
+                step_rmses = []
+                for step_idx in range(trajs.shape[0]):
+                    Rs, ts = ref.fit_transformations(cond, trajs[step_idx], points_per_part, cu_seqlens_batch)
+                    step_rmses.append(ref.compute_rigidity_rmse(cond, trajs[step_idx], Rs, ts, points_per_part,
+                                                                cu_seqlens_batch, scales))
+                rig.append(torch.stack(step_rmses).mean(dim=0))
+            else:                                                                                    # :501-504
+                rig.append(ref.compute_rigidity_rmse(cond, trajs[-1], R, t, points_per_part, cu_seqlens_batch, scales))
+        stacked = torch.stack(rig)                                                                   # (G,B)
+        best = torch.argmin(stacked, dim=0)                                                          # :518
+        B = best.shape[0]
+        sel = [trajectories[int(best[b])][-1][cu_seqlens_batch[b]:cu_seqlens_batch[b + 1]] for b in range(B)]   # :560-573
+        R_sel = torch.zeros_like(n_rot[0]); t_sel = torch.zeros_like(n_trans[0])                                # :583-588
+        for b in range(B):
+            R_sel[b] = n_rot[int(best[b])][b]; t_sel[b] = n_trans[int(best[b])][b]
+    return {"rigidity_rmse": stacked, "best_gen_indices": best, "pointclouds_selected": torch.cat(sel, dim=0),
+            "rotations_selected": R_sel, "translations_selected": t_sel, "n_rotations": torch.stack(n_rot),
+            "n_translations": torch.stack(n_trans)}
 
 
 def build_reference_dit(cfg, state_dict, dtype=torch.float32):

@@ -744,3 +744,66 @@ extern "C" int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t h
   if (!qk || !gamma_q || !gamma_k) return RAP_ERR_INVALID;
   return launch_qknorm_h16((hipStream_t)stream, dtype, qk, (int)TP, heads, gamma_q, gamma_k);
 }
+
+// ---------------------------------------------------------------------------------------------
+// generation selection by rigidity
+// ---------------------------------------------------------------------------------------------
+struct RigWs { int32_t* off; double* partials; float* Rc; float* tc; float* per_step; size_t total; };
+static RigWs carve_rig(int nparts, int S, int B, char* basep) {
+  RigWs p; size_t off = 0;
+  auto take = [&](size_t bytes) { char* r = basep ? basep + off : nullptr; off += align_up(bytes, 256); return r; };
+  p.off = (int32_t*)take(((size_t)nparts + 1) * 4);
+  p.partials = (double*)take((size_t)nparts * RAP_PROC_CHUNKS * 16 * 8);
+  p.Rc = (float*)take((size_t)nparts * 9 * 4);
+  p.tc = (float*)take((size_t)nparts * 3 * 4);
+  p.per_step = (float*)take((size_t)(S > 0 ? S : 1) * B * 4);
+  p.total = off;
+  return p;
+}
+extern "C" size_t rap_rigidity_workspace_bytes(int32_t nparts, int32_t steps, int32_t B) {
+  return (nparts < 0 || steps < 0 || B < 0) ? 0 : carve_rig(nparts, steps, B, nullptr).total;
+}
+
+extern "C" int rap_rigidity_rmse(const float* cond, const float* pred, const float* R, const float* t,
+                                 const int64_t* points_per_part, int32_t B, int32_t P, const float* scales,
+                                 int32_t average_per_part, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  if (!cond || !pred || !R || !t || !points_per_part || !out || B <= 0 || P <= 0) return RAP_ERR_INVALID;
+  if ((int64_t)B * P > 65535) return RAP_ERR_INVALID;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  RigWs w = carve_rig(B * P, 0, B, (char*)ws);
+  if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  if ((rc = launch_part_offsets(stream, points_per_part, B * P, w.off))) return rc;
+  return launch_rigidity_rmse(stream, cond, pred, R, t, w.off, B, P, scales, average_per_part, out, w.partials);
+}
+
+extern "C" int rap_trajectory_rigidity_rmse(const float* cond, const float* traj, const int64_t* points_per_part, int32_t B,
+                                            int32_t P, int64_t TP, int32_t steps, const float* scales, float* mean_out,
+                                            float* per_step_out, void* ws, size_t ws_bytes, void* stream_) {
+  if (!cond || !traj || !points_per_part || !mean_out || B <= 0 || P <= 0 || TP <= 0 || steps <= 0) return RAP_ERR_INVALID;
+  if ((int64_t)B * P > 65535) return RAP_ERR_INVALID;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  RigWs w = carve_rig(B * P, steps, B, (char*)ws);
+  if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  float* per_step = per_step_out ? per_step_out : w.per_step;
+  int rc;
+  if ((rc = launch_part_offsets(stream, points_per_part, B * P, w.off))) return rc;
+  for (int s = 0; s < steps; ++s) {
+    const float* x0 = traj + (size_t)s * TP * 3;
+    if ((rc = launch_procrustes_fit(stream, cond, x0, w.off, B * P, w.Rc, w.tc, w.partials))) return rc;      // modeling.py:479-481
+    if ((rc = launch_rigidity_rmse(stream, cond, x0, w.Rc, w.tc, w.off, B, P, scales, 0, per_step + (size_t)s * B, w.partials)))
+      return rc;                                                                                              // :484-487
+  }
+  return launch_step_mean(stream, per_step, steps, B, mean_out);                                             // :489
+}
+
+extern "C" int rap_select_generation(const float* rmse, int32_t G, int32_t B, int32_t P, int64_t TP, const int32_t* cu_batch,
+                                     const float* clouds, const float* R, const float* t, int32_t* best_out, float* cloud_out,
+                                     float* R_out, float* t_out, void* stream) {
+  if (!rmse || !best_out || G <= 0 || B <= 0) return RAP_ERR_INVALID;
+  if (clouds && (!R || !t || !cu_batch || !cloud_out || !R_out || !t_out || P <= 0 || TP <= 0)) return RAP_ERR_INVALID;
+  return launch_select_generation((hipStream_t)stream, rmse, G, B, P, (long)TP, cu_batch, clouds, R, t, best_out, cloud_out,
+                                  R_out, t_out);
+}

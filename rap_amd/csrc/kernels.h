@@ -120,3 +120,14 @@ int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const float* x, u
                                 const float* gain, const float* shift);
 int launch_qknorm_h16(hipStream_t stream, int dtype, uint16_t* qk, int TP, int heads, const float* gamma_q,
                       const float* gamma_k);
+
+// ---------------------------------------------------------------------------------------------
+// generation selection by rigidity (rigidity.hip; reference modeling.py:456-592, eval/metrics.py:511-622)
+// ---------------------------------------------------------------------------------------------
+int launch_rigidity_rmse(hipStream_t stream, const float* src, const float* tgt, const float* R, const float* t,
+                         const int32_t* part_offsets, int B, int P, const float* scales, int average_per_part, float* out,
+                         double* partials);
+int launch_step_mean(hipStream_t stream, const float* per_step, int S, int B, float* out);
+int launch_select_generation(hipStream_t stream, const float* rmse, int G, int B, int P, long TP, const int32_t* cu_batch,
+                             const float* clouds, const float* R, const float* t, int32_t* best, float* cloud_out,
+                             float* R_out, float* t_out);

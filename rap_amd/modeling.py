@@ -99,4 +99,29 @@ class RectifiedPointFlow:
             return {"points": result["end_point_trajectory"][-1], "transformer_features": out["transformer_features"]}
         return result
 
+    @torch.inference_mode()
+    def sample_generations(self, data_dict: dict, x_1_list=None, use_average_rigidity_rmse: bool = True) -> dict:
+        """``n_generations`` sampling calls + the reference's rigidity-based selection (test_step, modeling.py:397-592):
+        per generation the trajectory, final cloud and poses; per object the generation whose rigidity RMSE is smallest --
+        averaged over all end-point trajectory steps (``use_average_rigidity_rmse``, modeling.py:466-500) or taken at the
+        final step (:501-504).  Everything stays on the device."""
+        from .selection import (average_trajectory_rigidity_rmse, compute_rigidity_rmse, select_generations_by_rigidity)
+        G = int(self.n_generations)
+        d = self._prepare_data(data_dict)
+        gens = []
+        for g in range(G):
+            x_1 = None if x_1_list is None else x_1_list[g]
+            gens.append(self.sample_and_register(data_dict, x_1=x_1))
+        cond, ppp, cu, scales = d["cond"], d["ppp"], d["cu_batch"], d["scales"]
+        if use_average_rigidity_rmse and self.return_end_point_trajectory:
+            rig = [average_trajectory_rigidity_rmse(cond, o["end_point_trajectory"], ppp, cu, scales) for o in gens]
+        else:
+            rig = [compute_rigidity_rmse(cond, o["end_point_trajectory"][-1], o["R"], o["t"], ppp, cu, scales) for o in gens]
+        stacked = torch.stack(rig)                                                          # (G,B)
+        finals = torch.stack([o["end_point_trajectory"][-1] for o in gens])
+        best, cloud, R, t = select_generations_by_rigidity(stacked, finals, torch.stack([o["R"] for o in gens]),
+                                                           torch.stack([o["t"] for o in gens]), cu)
+        return {"generations": gens, "rigidity_rmse": stacked, "best_gen_indices": best, "pointclouds_selected": cloud,
+                "rotations_selected": R, "translations_selected": t}
+
     sample = sample_rectified_flow   # the name BASELINE.json's north_star uses

@@ -108,3 +108,55 @@ def test_kat_timestep_sinusoid_layout():
     assert abs(ts[0, 0].item() - math.cos(0.5)) < 1e-6          # cos first (flip_sin_to_cos=True), w_0 = 1
     assert abs(ts[0, 128].item() - math.sin(0.5)) < 1e-6
     assert abs(ts[0, 127].item() - math.cos(0.5 * math.exp(-math.log(10000) * 127 / 128))) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# generation selection by rigidity
+# ---------------------------------------------------------------------------------------------
+def _selection_golden():
+    g, inp = load_golden("selection_g3")
+    cu_b, _ = O.prepare_cu_seqlens(inp)
+    return g, inp, cu_b.long(), torch.from_numpy(g["trajectories"])
+
+
+def test_oracle_selection_matches_reference_golden():
+    """oracle restatement of compute_rigidity_rmse / trajectory average / argmin-select vs the fixture produced by the
+    reference's own fit_transformations + compute_rigidity_rmse (oracle/make_golden.py::make_selection_golden)."""
+    g, inp, cu, trajs = _selection_golden()
+    cond, ppp, scales = inp["pointclouds"], inp["points_per_part"], inp["scales"]
+    G = trajs.shape[0]
+    for tag in ("avg", "final"):
+        rig, Rs, ts = [], [], []
+        for k in range(G):
+            R, t = O.fit_transformations(cond, trajs[k][-1], ppp, cu)
+            Rs.append(R); ts.append(t)
+            if tag == "avg":
+                rig.append(O.average_trajectory_rigidity_rmse(cond, trajs[k], ppp, cu, scales)[0])
+            else:
+                rig.append(O.compute_rigidity_rmse(cond, trajs[k][-1], R, t, ppp, cu, scales))
+        stacked = torch.stack(rig)
+        ref = torch.from_numpy(g[f"{tag}_rigidity_rmse"])
+        assert (stacked - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+        best, cloud, R, t = O.select_generations_by_rigidity(stacked, trajs[:, -1], torch.stack(Rs), torch.stack(ts), cu)
+        assert torch.equal(best, torch.from_numpy(g[f"{tag}_best_gen_indices"]))
+        assert (cloud - torch.from_numpy(g[f"{tag}_pointclouds_selected"])).abs().max().item() == 0.0
+        assert (R - torch.from_numpy(g[f"{tag}_rotations_selected"])).abs().max().item() < 1e-5
+    R0, t0 = O.fit_transformations(cond, trajs[0][-1], ppp, cu)
+    pp = O.compute_rigidity_rmse(cond, trajs[0][-1], R0, t0, ppp, cu, None, average_per_part=True)
+    assert (pp - torch.from_numpy(g["per_part_rmse"])).abs().max().item() < 2e-6
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
+def test_oracle_rigidity_matches_live_reference_function():
+    ref = ref_loader.load_reference()
+    inp = S.make_inputs([[50, 77, 0], [31, 64, 12]], seed=5)     # empty parts only as trailing padding: the reference's split_parts drops empty splits and mis-indexes otherwise
+    cu_b, _ = O.prepare_cu_seqlens(inp)
+    cu = cu_b.long()
+    g = torch.Generator().manual_seed(1)
+    pred = inp["pointclouds"] + 0.05 * torch.randn(inp["pointclouds"].shape, generator=g)
+    R, t = ref.fit_transformations(inp["pointclouds"], pred, inp["points_per_part"], cu)
+    for per_part in (False, True):
+        for scales in (None, inp["scales"]):
+            a = ref.compute_rigidity_rmse(inp["pointclouds"], pred, R, t, inp["points_per_part"], cu, scales, per_part)
+            b = O.compute_rigidity_rmse(inp["pointclouds"], pred, R, t, inp["points_per_part"], cu, scales, per_part)
+            assert (a - b).abs().max().item() < 1e-6

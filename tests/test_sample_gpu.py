@@ -180,3 +180,72 @@ def test_multiview_full_geometry_first_step_matches_oracle(dev):
     for k in ("end_point_trajectory", "trajectory"):
         err = (out[k][:1].cpu() - ref[k][:1]).abs().max().item()
         assert err < 5e-5, (k, err)
+
+
+# ---------------------------------------------------------------------------------------------
+# generation selection by rigidity
+# ---------------------------------------------------------------------------------------------
+def test_rigidity_rmse_and_selection_match_reference_golden(dev):
+    """compute_rigidity_rmse / trajectory average / argmin selection on device vs the fixture produced by the reference's own
+    fit_transformations + compute_rigidity_rmse (3 generations, an object with an empty part, both selection modes)."""
+    g, inp = load_golden("selection_g3")
+    cu = inp["cu_seqlens"]
+    cond, ppp, scales = inp["pointclouds"].to(dev), inp["points_per_part"], inp["scales"].to(dev)
+    trajs = torch.from_numpy(g["trajectories"]).to(dev)                       # (G,S,TP,3)
+    G = trajs.shape[0]
+    Rs, ts = zip(*[rap_amd.fit_transformations(cond, trajs[k][-1], ppp, cu) for k in range(G)])
+    for tag in ("avg", "final"):
+        if tag == "avg":
+            rig = [rap_amd.average_trajectory_rigidity_rmse(cond, trajs[k], ppp, cu, scales) for k in range(G)]
+        else:
+            rig = [rap_amd.compute_rigidity_rmse(cond, trajs[k][-1], Rs[k], ts[k], ppp, cu, scales) for k in range(G)]
+        stacked = torch.stack(rig)
+        ref = torch.from_numpy(g[f"{tag}_rigidity_rmse"])
+        rel = ((stacked.cpu() - ref).abs() / ref.abs()).max().item()
+        assert rel < 2e-6, (tag, rel)                                        # fp32 reference vs fp64-accumulated kernel
+        best, cloud, R, t = rap_amd.select_generations_by_rigidity(stacked, trajs[:, -1], torch.stack(Rs), torch.stack(ts), cu)
+        assert torch.equal(best.cpu(), torch.from_numpy(g[f"{tag}_best_gen_indices"]))
+        assert torch.equal(cloud.cpu(), torch.from_numpy(g[f"{tag}_pointclouds_selected"]))      # a gather: bit-exact
+        assert (R.cpu() - torch.from_numpy(g[f"{tag}_rotations_selected"])).abs().max().item() < 1e-5
+        assert (t.cpu() - torch.from_numpy(g[f"{tag}_translations_selected"])).abs().max().item() < 1e-5
+    pp = rap_amd.compute_rigidity_rmse(cond, trajs[0][-1], Rs[0], ts[0], ppp, cu, None, average_per_part=True)
+    assert (pp.cpu() - torch.from_numpy(g["per_part_rmse"])).abs().max().item() < 2e-6
+
+
+def test_rigidity_rmse_edge_cases_match_oracle(dev):
+    """object without points -> inf; exact rigid image -> 0; per-step output of the trajectory average vs the oracle."""
+    inp = S.make_inputs([[64, 31, 0], [200, 100, 50]], seed=8)
+    cu_b, _ = O.prepare_cu_seqlens(inp)
+    cond = inp["pointclouds"]
+    gen = torch.Generator().manual_seed(0)
+    traj = torch.stack([cond + 0.02 * (k + 1) * torch.randn(cond.shape, generator=gen) for k in range(3)])
+    mean_ref, per_ref = O.average_trajectory_rigidity_rmse(cond, traj, inp["points_per_part"], cu_b.long(), inp["scales"])
+    mean, per = rap_amd.average_trajectory_rigidity_rmse(cond.to(dev), traj.to(dev), inp["points_per_part"], inp["cu_seqlens"],
+                                                         inp["scales"].to(dev), return_per_step=True)
+    assert ((per.cpu() - per_ref).abs() / per_ref.abs()).max().item() < 5e-6
+    assert ((mean.cpu() - mean_ref).abs() / mean_ref.abs()).max().item() < 5e-6
+    # exact rigid image of cond -> RMSE ~ fp32 round-off of the coordinates
+    R, t = rap_amd.fit_transformations(cond.to(dev), cond.to(dev), inp["points_per_part"], inp["cu_seqlens"])
+    z = rap_amd.compute_rigidity_rmse(cond.to(dev), cond.to(dev), R, t, inp["points_per_part"], inp["cu_seqlens"])
+    assert z.max().item() < 1e-6
+    # an object whose parts are all empty
+    ppp = torch.tensor([[5, 3], [0, 0]]); cu = torch.tensor([0, 8, 8])
+    x = torch.randn(8, 3, generator=gen).to(dev)
+    R2, t2 = rap_amd.fit_transformations(x, x, ppp, cu)
+    r = rap_amd.compute_rigidity_rmse(x, x, R2, t2, ppp, cu)
+    assert torch.isinf(r[1]) and r[0].item() < 1e-6
+
+
+def test_sample_generations_selects_by_rigidity(dev):
+    """n_generations sampling calls + selection through the RectifiedPointFlow mirror equal the pieces run by hand."""
+    cfg, sd, model = get_model(2, 1, dev)
+    inp = S.make_inputs([[70, 45, 0], [33, 90, 61], [128, 40]], seed=13)
+    d = to_dev(inp, dev)
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=4, rigidity_forcing=False, n_generations=3)
+    x1s = [torch.randn(inp["x_1"].shape, generator=torch.Generator().manual_seed(s)).to(dev) for s in (104, 109, 101)]
+    out = flow.sample_generations(d, x_1_list=x1s)
+    g, _ = load_golden("selection_g3")
+    assert torch.equal(out["best_gen_indices"].cpu(), torch.from_numpy(g["avg_best_gen_indices"]))
+    ref = torch.from_numpy(g["avg_rigidity_rmse"])
+    assert ((out["rigidity_rmse"].cpu() - ref).abs() / ref).max().item() < 1e-4       # sampled on the GPU, not from the fixture
+    assert (out["pointclouds_selected"].cpu() - torch.from_numpy(g["avg_pointclouds_selected"])).abs().max().item() < 5e-5
