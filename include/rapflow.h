@@ -130,6 +130,15 @@ int rap_select_generation(const float* rmse, int32_t G, int32_t B, int32_t P, in
                           const float* clouds, const float* R, const float* t, int32_t* best_out, float* cloud_out,
                           float* R_out, float* t_out, void* stream);
 
+/* ---- output transforms (the data format after the path) ----
+ * Replaces the 4x4 computation of Evaluator._save_transformation_files (reference eval/evaluator.py:383-490): per (sample,
+ * part) the predicted pose relative to the ground-truth pose in metres, R_rel = R_pred R_gt^T, t_rel = s t_pred -
+ * (s t_gt) R_rel^T, times inv([R_global | t_global]) when the per-sample global frame (B,3,3)/(B,3) is given.
+ * out (B,P,4,4) row-major fp32; all-zero blocks for parts without points. */
+int rap_relative_transforms(const float* R_pred, const float* t_pred, const float* R_gt, const float* t_gt, const float* scales,
+                            const int64_t* points_per_part, int32_t B, int32_t P, const float* global_rotation,
+                            const float* global_translation, float* out, void* stream);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels the calls above launch) ---- */
 /* C(M,N) = A(M,K) W(N,K)^T (+bias) (+resid) ; epilogue: 0 bias, 1 bias+resid, 2 bias+SiLU,
  * 3 GEGLU (W/bias must be value/gate interleaved by rap_geglu_interleave; C is (M,N/2)),

@@ -98,7 +98,40 @@ def make_selection_golden():
     print("selection_g3", os.path.getsize(path) // 1024, "KiB")
 
 
+def make_transform_golden():
+    """Output transform files: the reference's own Evaluator._save_transformation_files on a
+    3-object batch (trailing empty part, random GT poses / scales / global frames), with and without the global frame;
+    the fixture keeps the inputs and the 4x4 matrices parsed back from the text files it wrote."""
+    import tempfile
+    from scipy.spatial.transform import Rotation
+    g = torch.Generator().manual_seed(77)
+    B, P = 3, 3
+    ppp = torch.tensor([[70, 45, 0], [33, 90, 61], [128, 40, 0]])
+    def rot(n):
+        q = torch.randn(n, 4, generator=g)
+        return torch.from_numpy(Rotation.from_quat(q.numpy()).as_matrix()).float()
+    data = {"rotations": rot(B * P).reshape(B, P, 3, 3), "translations": torch.randn(B, P, 3, generator=g) * 0.3,
+            "scales": torch.rand(B, generator=g) * 45 + 5, "points_per_part": ppp}
+    R_pred = rot(B * P).reshape(B, P, 3, 3); t_pred = torch.randn(B, P, 3, generator=g) * 0.3
+    G_R = rot(B); G_t = torch.randn(B, 3, generator=g) * 20
+    out = {"in_" + k: v.numpy() for k, v in data.items()}
+    out.update({"R_pred": R_pred.numpy(), "t_pred": t_pred.numpy(), "global_rotation": G_R.numpy(), "global_translation": G_t.numpy(),
+                "sample_indices": np.array([7, 8, 12])})
+    for tag, gr, gt in (("plain", None, None), ("global", G_R, G_t)):
+        with tempfile.TemporaryDirectory() as d:
+            files = ref_loader.reference_transformation_files(data, d, "synth", [7, 8, 12], "selected" if tag == "global" else 1,
+                                                              R_pred, t_pred, gr, gt)
+        out[f"{tag}_names"] = np.array(sorted(files))
+        out[f"{tag}_matrices"] = np.stack([files[k] for k in sorted(files)])
+    path = os.path.join(GOLDEN_DIR, "transform_files.npz")
+    np.savez_compressed(path, **out)
+    print("transform_files", os.path.getsize(path) // 1024, "KiB", len(out["plain_names"]), "files per mode")
+
+
 if __name__ == "__main__":
-    if "--selection-only" not in sys.argv:
+    if "--selection-only" not in sys.argv and "--transforms-only" not in sys.argv:
         main()
-    make_selection_golden()
+    if "--transforms-only" not in sys.argv:
+        make_selection_golden()
+    if "--selection-only" not in sys.argv:
+        make_transform_golden()

@@ -377,6 +377,32 @@ def select_generations_by_rigidity(stacked_rigidity, final_clouds, rotations, tr
     return best, cloud, R, t
 
 
+# ---------------------------------------------------------------------------------------------
+# output transforms
+# ---------------------------------------------------------------------------------------------
+def relative_transforms(R_pred, t_pred, R_gt, t_gt, scales, points_per_part, global_rotation=None, global_translation=None):
+    """eval/evaluator.py:436-474 for the whole batch -> (B,P,4,4) float32 (zero blocks for empty parts)."""
+    import numpy as np
+    B, P = points_per_part.shape
+    out = np.zeros((B, P, 4, 4), dtype=np.float32)
+    for b in range(B):
+        s = float(scales[b])
+        for p in range(P):
+            if points_per_part[b, p] == 0:
+                continue
+            Rp, Rg = R_pred[b, p].numpy().astype(float), R_gt[b, p].numpy().astype(float)
+            tp, tg = t_pred[b, p].numpy().astype(float) * s, t_gt[b, p].numpy().astype(float) * s        # :440-441
+            RrT = Rg @ Rp.T                                                                               # :448
+            M = np.eye(4, dtype=np.float32)
+            M[:3, :3] = RrT.T; M[:3, 3] = tp - tg @ RrT                                                   # :449-455
+            if global_rotation is not None and global_translation is not None:
+                Gm = np.eye(4, dtype=np.float32)
+                Gm[:3, :3] = global_rotation[b].numpy().astype(float); Gm[:3, 3] = global_translation[b].numpy().astype(float)
+                M = M @ np.linalg.inv(Gm)                                                                 # :474
+            out[b, p] = M
+    return torch.from_numpy(out)
+
+
 def rotation_error_deg(R_a: torch.Tensor, R_b: torch.Tensor) -> torch.Tensor:
     """acos((trace(R_a^T R_b) - 1) / 2) in degrees, clamped (metrics.py:289-291)."""
     tr = torch.einsum("...ij,...ij->...", R_a, R_b)

@@ -168,6 +168,47 @@ def _install_pytorch3d_import_stub():
     sys.modules.update({"pytorch3d": p3, "pytorch3d.loss": loss, "pytorch3d.loss.chamfer": ch, "pytorch3d.ops": ops})
 
 
+class _PermissiveModule(types.ModuleType):
+    """Import-only stand-in: any attribute is an empty class (for `from x import A, B, C` of render / Lightning helpers that
+    are never called on the path)."""
+    __path__: list = []
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return type(name, (), {})
+
+
+def load_reference_evaluator():
+    """The reference's unmodified eval/evaluator.py (for Evaluator._save_transformation_files, evaluator.py:383-490).  It
+    imports lightning (2.5.2) and, through utils/render.py, pytorch3d.structures / .renderer -- none of which the transform
+    writer touches; they are replaced by import-only stand-ins."""
+    ref = load_reference()
+    if getattr(ref, "evaluator", None) is None:
+        for n in ("pytorch3d.structures", "pytorch3d.renderer", "pytorch3d.renderer.points", "pytorch3d.renderer.cameras", "lightning"):
+            sys.modules.setdefault(n, _PermissiveModule(n))
+        ref.evaluator = importlib.import_module("rectified_point_flow.eval.evaluator")
+    return ref.evaluator
+
+
+def reference_transformation_files(data, sample_dir, dataset_name, sample_indices, generation_idx, rotations_pred, translations_pred,
+                                   global_rotation=None, global_translation=None):
+    """Run the reference's own Evaluator._save_transformation_files for every sample of the batch (as Evaluator.run does,
+    evaluator.py:370-381); returns {file name: 4x4 float64 array parsed back from the text it wrote}."""
+    import numpy as np
+    from pathlib import Path
+    ev = load_reference_evaluator()
+    sample_dir = Path(sample_dir); sample_dir.mkdir(parents=True, exist_ok=True)
+    fake_self = types.SimpleNamespace()
+    B = data["points_per_part"].shape[0]
+    for idx in range(B):
+        gr = None if global_rotation is None else global_rotation[idx]
+        gt = None if global_translation is None else global_translation[idx]
+        ev.Evaluator._save_transformation_files(fake_self, data, idx, sample_dir, dataset_name, int(sample_indices[idx]), generation_idx,
+                                                rotations_pred, translations_pred, gr, gt)
+    return {p.name: np.loadtxt(p) for p in sorted(sample_dir.glob("*_transform.txt"))}
+
+
 _LOADED = None
 
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "rap_rigidity_rmse": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _P, _P, c_size_t, _P]),
     "rap_trajectory_rigidity_rmse": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P]),
     "rap_select_generation": (c_int32, [_P, c_int32, c_int32, c_int32, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rap_relative_transforms": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),
     "rap_gemm_f32": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32,
                                _P, _P, c_int32, _P]),
     "rap_geglu_interleave": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P]),

@@ -807,3 +807,12 @@ extern "C" int rap_select_generation(const float* rmse, int32_t G, int32_t B, in
   return launch_select_generation((hipStream_t)stream, rmse, G, B, P, (long)TP, cu_batch, clouds, R, t, best_out, cloud_out,
                                   R_out, t_out);
 }
+
+extern "C" int rap_relative_transforms(const float* R_pred, const float* t_pred, const float* R_gt, const float* t_gt,
+                                       const float* scales, const int64_t* points_per_part, int32_t B, int32_t P,
+                                       const float* global_rotation, const float* global_translation, float* out, void* stream) {
+  if (!R_pred || !t_pred || !R_gt || !t_gt || !scales || !points_per_part || !out || B <= 0 || P <= 0) return RAP_ERR_INVALID;
+  if ((global_rotation == nullptr) != (global_translation == nullptr)) return RAP_ERR_INVALID;
+  return launch_relative_transforms((hipStream_t)stream, R_pred, t_pred, R_gt, t_gt, scales, points_per_part, B, P,
+                                    global_rotation, global_translation, out);
+}

@@ -131,3 +131,8 @@ int launch_step_mean(hipStream_t stream, const float* per_step, int S, int B, fl
 int launch_select_generation(hipStream_t stream, const float* rmse, int G, int B, int P, long TP, const int32_t* cu_batch,
                              const float* clouds, const float* R, const float* t, int32_t* best, float* cloud_out,
                              float* R_out, float* t_out);
+
+// output transforms (transforms.hip; reference eval/evaluator.py:383-490)
+int launch_relative_transforms(hipStream_t stream, const float* R_pred, const float* t_pred, const float* R_gt, const float* t_gt,
+                               const float* scales, const int64_t* ppp, int B, int P, const float* R_glob, const float* t_glob,
+                               float* out);

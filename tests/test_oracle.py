@@ -160,3 +160,29 @@ def test_oracle_rigidity_matches_live_reference_function():
             a = ref.compute_rigidity_rmse(inp["pointclouds"], pred, R, t, inp["points_per_part"], cu, scales, per_part)
             b = O.compute_rigidity_rmse(inp["pointclouds"], pred, R, t, inp["points_per_part"], cu, scales, per_part)
             assert (a - b).abs().max().item() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# output transform files
+# ---------------------------------------------------------------------------------------------
+def _transform_golden():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transform_files.npz"))
+    g = {k: z[k] for k in z.files}
+    T = lambda k: torch.from_numpy(g[k])
+    data = {"rotations": T("in_rotations"), "translations": T("in_translations"), "scales": T("in_scales"),
+            "points_per_part": T("in_points_per_part")}
+    return g, data, T
+
+
+def test_oracle_relative_transforms_match_reference_written_files():
+    """oracle restatement vs the matrices parsed back from the text files the reference's own
+    Evaluator._save_transformation_files wrote (oracle/make_golden.py::make_transform_golden); %12.8f => 1e-8 quantum."""
+    g, data, T = _transform_golden()
+    ppp = data["points_per_part"]
+    valid = [(b, p) for b in range(ppp.shape[0]) for p in range(ppp.shape[1]) if ppp[b, p] > 0]
+    for tag, gr, gt in (("plain", None, None), ("global", T("global_rotation"), T("global_translation"))):
+        M = O.relative_transforms(T("R_pred"), T("t_pred"), data["rotations"], data["translations"], data["scales"], ppp, gr, gt)
+        got = torch.stack([M[b, p] for b, p in valid]).double()
+        ref = torch.from_numpy(g[f"{tag}_matrices"])
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())

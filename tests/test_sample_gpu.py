@@ -249,3 +249,28 @@ def test_sample_generations_selects_by_rigidity(dev):
     ref = torch.from_numpy(g["avg_rigidity_rmse"])
     assert ((out["rigidity_rmse"].cpu() - ref).abs() / ref).max().item() < 1e-4       # sampled on the GPU, not from the fixture
     assert (out["pointclouds_selected"].cpu() - torch.from_numpy(g["avg_pointclouds_selected"])).abs().max().item() < 5e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# output transform files
+# ---------------------------------------------------------------------------------------------
+def test_transform_files_match_reference_written_files(dev, tmp_path):
+    """Same file names, same 4 x `%12.8f` layout, same numbers (to the fp32 rounding of the stored 4x4) as the files written
+    by the reference's own Evaluator._save_transformation_files -- with and without the global frame."""
+    import numpy as np
+    import os
+    from rap_amd.evaluator import save_transformation_files
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transform_files.npz"))
+    T = lambda k: torch.from_numpy(z[k])
+    data = {"rotations": T("in_rotations"), "translations": T("in_translations"), "scales": T("in_scales"),
+            "points_per_part": T("in_points_per_part")}
+    for tag, gen, gr, gt in (("plain", 1, None, None), ("global", "selected", T("global_rotation"), T("global_translation"))):
+        d = tmp_path / tag
+        paths = save_transformation_files(data, d, "synth", z["sample_indices"].tolist(), gen, T("R_pred").to(dev), T("t_pred").to(dev),
+                                          gr, gt)
+        assert sorted(p.name for p in paths) == list(z[f"{tag}_names"])
+        for name, ref in zip(z[f"{tag}_names"], z[f"{tag}_matrices"]):
+            text = (d / str(name)).read_text().splitlines()
+            assert len(text) == 4 and all(len(line) == 4 * 12 + 3 for line in text)          # 4 x %12.8f joined by blanks
+            got = np.loadtxt(d / str(name))
+            assert np.abs(got - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), name
