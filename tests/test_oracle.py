@@ -1,6 +1,7 @@
 """CPU: the oracle (oracle/rap_oracle.py) against the golden vectors produced by the reference's own
 modules, against the live reference when it is mounted, and against analytic known-answer tests."""
 import math
+import os
 
 import numpy as np
 import pytest
