@@ -124,11 +124,19 @@ int rap_trajectory_rigidity_rmse(const float* cond, const float* traj, const int
                                  int64_t TP, int32_t steps, const float* scales, float* mean_out, float* per_step_out, void* ws,
                                  size_t ws_bytes, void* stream);
 /* Replaces the rigidity-selected generation pick (reference modeling.py:518, 560-592): best_out[b] = argmin_g rmse[g][b]
- * (first minimum); if clouds != NULL also gathers cloud_out (TP,3), R_out (B,P,3,3), t_out (B,P,3) of the picked generation
+ * (first minimum), or with pick_largest != 0 the overlap-ratio pick argmax_g (modeling.py:601); if clouds != NULL also gathers cloud_out (TP,3), R_out (B,P,3,3), t_out (B,P,3) of the picked generation
  * per sample from clouds (G,TP,3), R (G,B,P,3,3), t (G,B,P,3); cu_batch (B+1,) int32. */
 int rap_select_generation(const float* rmse, int32_t G, int32_t B, int32_t P, int64_t TP, const int32_t* cu_batch,
-                          const float* clouds, const float* R, const float* t, int32_t* best_out, float* cloud_out,
-                          float* R_out, float* t_out, void* stream);
+                          const float* clouds, const float* R, const float* t, int32_t pick_largest, int32_t* best_out,
+                          float* cloud_out, float* R_out, float* t_out, void* stream);
+/* Replaces compute_overlap_ratio (reference eval/metrics.py:625-691): per sample the fraction of points that have a point of
+ * a DIFFERENT part of the same sample within distance tau, for n_taus (<= 8) thresholds given as a HOST array.
+ * ratios_out (n_taus, B) device; min_dist_out (TP,) device or NULL (distance to the nearest other-part point, inf if none).
+ * 0 for samples with <= 1 point or fewer than two non-empty parts.  ws >= rap_overlap_workspace_bytes(TP, B, P). */
+size_t rap_overlap_workspace_bytes(int64_t TP, int32_t B, int32_t P);
+int rap_overlap_ratio(const float* pointclouds_pred, const int64_t* points_per_part, const int32_t* cu_batch, int32_t B, int32_t P,
+                      int64_t TP, const float* h_taus, int32_t n_taus, float* ratios_out, float* min_dist_out, void* ws,
+                      size_t ws_bytes, void* stream);
 
 /* ---- output transforms (the data format after the path) ----
  * Replaces the 4x4 computation of Evaluator._save_transformation_files (reference eval/evaluator.py:383-490): per (sample,

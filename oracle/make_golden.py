@@ -98,6 +98,29 @@ def make_selection_golden():
     print("selection_g3", os.path.getsize(path) // 1024, "KiB")
 
 
+def make_overlap_golden():
+    """Cross-part overlap ratio: the reference's own compute_overlap_ratio on 4 objects (two
+    overlapping views of one surface, a single-part object -> 0, a trailing empty part, a 1-point part), thresholds chosen
+    inside the distance distribution so that the ratios are neither 0 nor 1."""
+    g = torch.Generator().manual_seed(5)
+    ppp = torch.tensor([[400, 300, 0], [500, 0, 0], [257, 1, 130], [64, 64, 64]])
+    clouds = []
+    for b in range(ppp.shape[0]):
+        surf = torch.rand(2000, 3, generator=g); surf[:, 2] = 0.2 * torch.sin(3 * surf[:, 0])       # one shared surface per object
+        for p in range(ppp.shape[1]):
+            idx = torch.randint(0, 2000, (int(ppp[b, p]),), generator=g)
+            clouds.append(surf[idx] + 0.002 * torch.randn(int(ppp[b, p]), 3, generator=g))
+    pred = torch.cat(clouds)
+    cu = torch.cat([torch.zeros(1, dtype=torch.long), ppp.sum(1).cumsum(0)])
+    taus = [0.005, 0.01, 0.02]
+    ref = ref_loader.load_reference()
+    ratios = ref.compute_overlap_ratio(pred, ppp, cu, taus)
+    path = os.path.join(GOLDEN_DIR, "overlap_ratio.npz")
+    np.savez_compressed(path, pred=pred.numpy(), points_per_part=ppp.numpy(), cu_seqlens=cu.numpy(), taus=np.array(taus),
+                        ratios=ratios.numpy())
+    print("overlap_ratio", os.path.getsize(path) // 1024, "KiB", ratios)
+
+
 def make_transform_golden():
     """Output transform files: the reference's own Evaluator._save_transformation_files on a
     3-object batch (trailing empty part, random GT poses / scales / global frames), with and without the global frame;
@@ -129,9 +152,12 @@ def make_transform_golden():
 
 
 if __name__ == "__main__":
-    if "--selection-only" not in sys.argv and "--transforms-only" not in sys.argv:
+    only = [a for a in sys.argv[1:] if a.endswith("-only")]     # e.g. --overlap-only regenerates one fixture
+    if not only:
         main()
-    if "--transforms-only" not in sys.argv:
+    if not only or "--selection-only" in only:
         make_selection_golden()
-    if "--selection-only" not in sys.argv:
+    if not only or "--transforms-only" in only:
         make_transform_golden()
+    if not only or "--overlap-only" in only:
+        make_overlap_golden()

@@ -377,6 +377,29 @@ def select_generations_by_rigidity(stacked_rigidity, final_clouds, rotations, tr
     return best, cloud, R, t
 
 
+def compute_overlap_ratio(pred, points_per_part, cu_seqlens_batch, taus=(0.005, 0.01, 0.02)):
+    """eval/metrics.py:625-691 with exact fp64 pairwise distances (the reference's fp32 torch.cdist may use the
+    |a|^2+|b|^2-2ab expansion, ~1e-7 absolute in d^2): -> (ratios (T,B), min_other_dist (TP,) fp64, inf where no other part)."""
+    B, P = points_per_part.shape
+    ratios = torch.zeros(len(taus), B, dtype=torch.float64)
+    min_d = torch.full((pred.shape[0],), float("inf"), dtype=torch.float64)
+    for b in range(B):
+        a, e = int(cu_seqlens_batch[b]), int(cu_seqlens_batch[b + 1])
+        if e <= a:
+            continue
+        pts = pred[a:e].double()
+        pid = torch.repeat_interleave(torch.arange(P), points_per_part[b])                     # ppp_to_ids, point_clouds.py:86-91
+        if e - a <= 1 or pid.unique().numel() <= 1:
+            continue                                                                            # metrics.py:667-668
+        d = torch.cdist(pts, pts, p=2, compute_mode="donot_use_mm_for_euclid_dist")
+        d[pid[:, None] == pid[None, :]] = float("inf")                                          # :673-676
+        m = d.min(dim=1).values
+        min_d[a:e] = m
+        for ti, tau in enumerate(taus):
+            ratios[ti, b] = (m <= float(tau)).double().mean()                                   # :681-683
+    return ratios, min_d
+
+
 # ---------------------------------------------------------------------------------------------
 # output transforms (SURVEY.md section 8f row 3)
 # ---------------------------------------------------------------------------------------------

@@ -240,6 +240,7 @@ def load_reference():
     sys.modules.setdefault("rectified_point_flow.eval", evalp)
     ns.metrics = importlib.import_module("rectified_point_flow.eval.metrics")
     ns.compute_rigidity_rmse = ns.metrics.compute_rigidity_rmse
+    ns.compute_overlap_ratio = ns.metrics.compute_overlap_ratio
     _LOADED = ns
     return ns
 

@@ -48,7 +48,9 @@ SIGNATURES = {
     "rap_rigidity_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "rap_rigidity_rmse": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _P, _P, c_size_t, _P]),
     "rap_trajectory_rigidity_rmse": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P]),
-    "rap_select_generation": (c_int32, [_P, c_int32, c_int32, c_int32, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rap_select_generation": (c_int32, [_P, c_int32, c_int32, c_int32, c_int64, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
+    "rap_overlap_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "rap_overlap_ratio": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, _P, c_int32, _P, _P, _P, c_size_t, _P]),
     "rap_relative_transforms": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),
     "rap_gemm_f32": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32,
                                _P, _P, c_int32, _P]),

@@ -800,12 +800,12 @@ extern "C" int rap_trajectory_rigidity_rmse(const float* cond, const float* traj
 }
 
 extern "C" int rap_select_generation(const float* rmse, int32_t G, int32_t B, int32_t P, int64_t TP, const int32_t* cu_batch,
-                                     const float* clouds, const float* R, const float* t, int32_t* best_out, float* cloud_out,
-                                     float* R_out, float* t_out, void* stream) {
+                                     const float* clouds, const float* R, const float* t, int32_t pick_largest,
+                                     int32_t* best_out, float* cloud_out, float* R_out, float* t_out, void* stream) {
   if (!rmse || !best_out || G <= 0 || B <= 0) return RAP_ERR_INVALID;
   if (clouds && (!R || !t || !cu_batch || !cloud_out || !R_out || !t_out || P <= 0 || TP <= 0)) return RAP_ERR_INVALID;
-  return launch_select_generation((hipStream_t)stream, rmse, G, B, P, (long)TP, cu_batch, clouds, R, t, best_out, cloud_out,
-                                  R_out, t_out);
+  return launch_select_generation((hipStream_t)stream, rmse, G, B, P, (long)TP, cu_batch, clouds, R, t, pick_largest, best_out,
+                                  cloud_out, R_out, t_out);
 }
 
 extern "C" int rap_relative_transforms(const float* R_pred, const float* t_pred, const float* R_gt, const float* t_gt,
@@ -815,4 +815,36 @@ extern "C" int rap_relative_transforms(const float* R_pred, const float* t_pred,
   if ((global_rotation == nullptr) != (global_translation == nullptr)) return RAP_ERR_INVALID;
   return launch_relative_transforms((hipStream_t)stream, R_pred, t_pred, R_gt, t_gt, scales, points_per_part, B, P,
                                     global_rotation, global_translation, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cross-part overlap ratio
+// ---------------------------------------------------------------------------------------------
+struct OvWs { int32_t* off; int32_t* pid; float* min_dist; void* items; size_t total; };
+static OvWs carve_ov(int64_t TP, int B, int P, char* basep) {
+  OvWs w; size_t off = 0;
+  auto take = [&](size_t bytes) { char* r = basep ? basep + off : nullptr; off += align_up(bytes, 256); return r; };
+  w.off = (int32_t*)take(((size_t)B * P + 1) * 4);
+  w.pid = (int32_t*)take((size_t)TP * 4);
+  w.min_dist = (float*)take((size_t)TP * 4);
+  w.items = take(overlap_max_items((long)TP, B) * 16);
+  w.total = off;
+  return w;
+}
+extern "C" size_t rap_overlap_workspace_bytes(int64_t TP, int32_t B, int32_t P) {
+  return (TP < 0 || B < 0 || P < 0) ? 0 : carve_ov(TP, B, P, nullptr).total;
+}
+extern "C" int rap_overlap_ratio(const float* pointclouds_pred, const int64_t* points_per_part, const int32_t* cu_batch, int32_t B,
+                                 int32_t P, int64_t TP, const float* h_taus, int32_t n_taus, float* ratios_out, float* min_dist_out,
+                                 void* ws, size_t ws_bytes, void* stream_) {
+  if (!pointclouds_pred || !points_per_part || !cu_batch || !h_taus || !ratios_out || B <= 0 || P <= 0 || TP <= 0) return RAP_ERR_INVALID;
+  if ((int64_t)B * P > 65535 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  OvWs w = carve_ov(TP, B, P, (char*)ws);
+  if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  if ((rc = launch_part_offsets(stream, points_per_part, B * P, w.off))) return rc;
+  return launch_overlap_ratio(stream, pointclouds_pred, cu_batch, w.off, B, P, (long)TP, h_taus, n_taus, ratios_out,
+                              min_dist_out ? min_dist_out : w.min_dist, w.pid, w.items);
 }

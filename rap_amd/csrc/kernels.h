@@ -129,10 +129,15 @@ int launch_rigidity_rmse(hipStream_t stream, const float* src, const float* tgt,
                          double* partials);
 int launch_step_mean(hipStream_t stream, const float* per_step, int S, int B, float* out);
 int launch_select_generation(hipStream_t stream, const float* rmse, int G, int B, int P, long TP, const int32_t* cu_batch,
-                             const float* clouds, const float* R, const float* t, int32_t* best, float* cloud_out,
+                             const float* clouds, const float* R, const float* t, int largest, int32_t* best, float* cloud_out,
                              float* R_out, float* t_out);
 
 // output transforms (transforms.hip; reference eval/evaluator.py:383-490)
 int launch_relative_transforms(hipStream_t stream, const float* R_pred, const float* t_pred, const float* R_gt, const float* t_gt,
                                const float* scales, const int64_t* ppp, int B, int P, const float* R_glob, const float* t_glob,
                                float* out);
+
+// cross-part overlap ratio (overlap.hip; reference eval/metrics.py:625-691)
+size_t overlap_max_items(long TP, int B);
+int launch_overlap_ratio(hipStream_t stream, const float* pts, const int32_t* cu_batch, const int32_t* part_off, int B, int P,
+                         long TP, const float* h_taus, int n_taus, float* ratios, float* min_dist, int32_t* pid, void* items_ws);

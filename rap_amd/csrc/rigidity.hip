@@ -79,15 +79,17 @@ __global__ __launch_bounds__(64) void step_mean_kernel(const float* __restrict__
   out[b] = (float)(s / (double)S);
 }
 
-// best[b] = first index of the minimum over generations (torch.argmin, modeling.py:518)
-__global__ __launch_bounds__(64) void argmin_generation_kernel(const float* __restrict__ rmse, int G, int B, int32_t* __restrict__ best) {
+// best[b] = first index of the minimum (torch.argmin, modeling.py:518: rigidity) or of the maximum (torch.argmax, :601: overlap
+// ratio) over generations
+__global__ __launch_bounds__(64) void argmin_generation_kernel(const float* __restrict__ rmse, int G, int B, int largest,
+                                                               int32_t* __restrict__ best) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   int bi = 0;
   float bv = rmse[b];
   for (int g = 1; g < G; ++g) {
     const float v = rmse[(size_t)g * B + b];
-    if (v < bv) { bv = v; bi = g; }
+    if (largest ? (v > bv) : (v < bv)) { bv = v; bi = g; }
   }
   best[b] = bi;
 }
@@ -126,9 +128,9 @@ int launch_step_mean(hipStream_t stream, const float* per_step, int S, int B, fl
   return RAP_OK;
 }
 int launch_select_generation(hipStream_t stream, const float* rmse, int G, int B, int P, long TP, const int32_t* cu_batch,
-                             const float* clouds, const float* R, const float* t, int32_t* best, float* cloud_out,
+                             const float* clouds, const float* R, const float* t, int largest, int32_t* best, float* cloud_out,
                              float* R_out, float* t_out) {
-  hipLaunchKernelGGL(argmin_generation_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, rmse, G, B, best);
+  hipLaunchKernelGGL(argmin_generation_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, rmse, G, B, largest, best);
   RAP_LAUNCH_CHECK();
   if (clouds && cloud_out) {
     hipLaunchKernelGGL(gather_generation_kernel, dim3(16, B), dim3(256), 0, stream, clouds, R, t, best, cu_batch, B, P, TP,

@@ -68,7 +68,46 @@ def average_trajectory_rigidity_rmse(condition, trajectory, points_per_part, cu_
     return (mean, per_step) if return_per_step else mean
 
 
-def select_generations_by_rigidity(stacked_rigidity, final_clouds, rotations, translations, cu_seqlens_batch):
+def compute_overlap_ratio(pointclouds_pred, points_per_part, cu_seqlens_batch=None, taus=(0.005, 0.01, 0.02),
+                          return_min_distances: bool = False):
+    """Reference signature (eval/metrics.py:625-631) -> (T,B) overlap ratios: the fraction of an object's points that have a
+    point of a DIFFERENT part within ``tau`` [, (TP,) distance to the nearest other-part point]."""
+    pts = _check_packed(pointclouds_pred, points_per_part, cu_seqlens_batch)
+    _require_cuda(pts, "pointclouds_pred")
+    device = pts.device
+    B, P = points_per_part.shape
+    pts = _f32c(pts)
+    TP = pts.shape[0]
+    ppp = points_per_part.to(device=device, dtype=torch.int64).contiguous()
+    if cu_seqlens_batch is None:     # fixed batching (B,N,3): every object has N points
+        cu = torch.arange(0, TP + 1, TP // B, dtype=torch.int32, device=device)
+    else:
+        cu = cu_seqlens_batch.to(device=device, dtype=torch.int32).contiguous()
+    tau_list = [float(taus)] if isinstance(taus, (float, int)) else [float(t) for t in taus]     # metrics.py:648-651
+    if not 1 <= len(tau_list) <= 8:
+        raise ValueError("between 1 and 8 thresholds are supported")
+    import ctypes
+    h_taus = (ctypes.c_float * len(tau_list))(*tau_list)
+    lib = _lib.load()
+    ratios = torch.empty((len(tau_list), B), dtype=torch.float32, device=device)
+    min_d = torch.empty((TP,), dtype=torch.float32, device=device) if return_min_distances else None
+    ws = workspace(device, lib.rap_overlap_workspace_bytes(TP, B, P))
+    with torch.cuda.device(device):
+        rc = lib.rap_overlap_ratio(_lib.ptr(pts), _lib.ptr(ppp), _lib.ptr(cu), B, P, TP, ctypes.cast(h_taus, ctypes.c_void_p),
+                                   len(tau_list), _lib.ptr(ratios), _lib.ptr(min_d), _lib.ptr(ws), ws.numel(),
+                                   _lib.current_stream(device))
+    _lib.check(rc, "rap_overlap_ratio")
+    return (ratios, min_d) if return_min_distances else ratios
+
+
+def select_generations_by_overlap(stacked_overlap_ratios, final_clouds, rotations, translations, cu_seqlens_batch):
+    """Per object the generation with the LARGEST overlap ratio (modeling.py:597-601) -> (best, cloud, R, t)."""
+    return select_generations_by_rigidity(stacked_overlap_ratios, final_clouds, rotations, translations, cu_seqlens_batch,
+                                          _pick_largest=True)
+
+
+def select_generations_by_rigidity(stacked_rigidity, final_clouds, rotations, translations, cu_seqlens_batch,
+                                   _pick_largest: bool = False):
     """stacked_rigidity (G,B); final_clouds (G,TP,3); rotations (G,B,P,3,3); translations (G,B,P,3) ->
     (best_gen_indices (B,) int64, cloud (TP,3), R (B,P,3,3), t (B,P,3)) of the generation with the smallest rigidity
     RMSE per object (modeling.py:518, 560-592)."""
@@ -89,7 +128,7 @@ def select_generations_by_rigidity(stacked_rigidity, final_clouds, rotations, tr
     t_out = torch.empty((B, P, 3), dtype=torch.float32, device=device)
     with torch.cuda.device(device):
         rc = lib.rap_select_generation(_lib.ptr(rm), G, B, P, TP, _lib.ptr(cu), _lib.ptr(clouds), _lib.ptr(R), _lib.ptr(t),
-                                       _lib.ptr(best), _lib.ptr(cloud_out), _lib.ptr(R_out), _lib.ptr(t_out),
+                                       1 if _pick_largest else 0, _lib.ptr(best), _lib.ptr(cloud_out), _lib.ptr(R_out), _lib.ptr(t_out),
                                        _lib.current_stream(device))
     _lib.check(rc, "rap_select_generation")
     return best.to(torch.int64), cloud_out, R_out, t_out

@@ -274,3 +274,46 @@ def test_transform_files_match_reference_written_files(dev, tmp_path):
             assert len(text) == 4 and all(len(line) == 4 * 12 + 3 for line in text)          # 4 x %12.8f joined by blanks
             got = np.loadtxt(d / str(name))
             assert np.abs(got - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), name
+
+
+# ---------------------------------------------------------------------------------------------
+# cross-part overlap ratio
+# ---------------------------------------------------------------------------------------------
+def test_overlap_ratio_matches_reference_golden_and_oracle(dev):
+    import numpy as np
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "overlap_ratio.npz"))
+    pred, ppp, cu = torch.from_numpy(z["pred"]), torch.from_numpy(z["points_per_part"]), torch.from_numpy(z["cu_seqlens"])
+    taus = z["taus"].tolist()
+    ratios, min_d = rap_amd.compute_overlap_ratio(pred.to(dev), ppp, cu, taus, return_min_distances=True)
+    ref_ratios, ref_min = O.compute_overlap_ratio(pred, ppp, cu, taus)
+    finite = torch.isfinite(ref_min)
+    assert torch.equal(torch.isfinite(min_d.cpu()), finite)
+    assert (min_d.cpu()[finite].double() - ref_min[finite]).abs().max().item() < 1e-6       # fp32 direct differences vs fp64
+    n = (cu[1:] - cu[:-1]).double()
+    assert ((ratios.cpu().double() - ref_ratios).abs() * n[None, :]).max().item() <= 1.0 + 1e-6            # vs the fp64 oracle
+    assert ((ratios.cpu().double() - torch.from_numpy(z["ratios"]).double()).abs() * n[None, :]).max().item() <= 2.0 + 1e-6
+    assert ratios[:, 1].abs().max().item() == 0.0
+
+
+def test_overlap_ratio_full_geometry_properties_and_selection(dev):
+    """BASELINE geometry (4 objects x 2 views x 4096 points): two identical views -> every point has a zero-distance
+    neighbour in the other part (ratio 1); far-apart views -> 0; the argmax pick over generations gathers the right one."""
+    g = torch.Generator().manual_seed(3)
+    B, N = 4, 4096
+    base = torch.rand(B, N, 3, generator=g)
+    ppp = torch.full((B, 2), N, dtype=torch.int64)
+    cu = torch.arange(0, B * 2 * N + 1, 2 * N)
+    same = torch.cat([torch.cat([base[b], base[b]]) for b in range(B)]).to(dev)
+    far = torch.cat([torch.cat([base[b], base[b] + 10.0]) for b in range(B)]).to(dev)
+    r_same = rap_amd.compute_overlap_ratio(same, ppp, cu, [0.01])
+    r_far = rap_amd.compute_overlap_ratio(far, ppp, cu, [0.01])
+    assert torch.equal(r_same.cpu(), torch.ones(1, B)) and torch.equal(r_far.cpu(), torch.zeros(1, B))
+    mixed = far.clone(); mixed[: 2 * N] = same[: 2 * N]           # generation 1: object 0 overlaps, the others do not
+    stacked = torch.cat([r_far, rap_amd.compute_overlap_ratio(mixed, ppp, cu, [0.01])])       # (G=2, B)
+    R = torch.zeros(2, B, 2, 3, 3, device=dev); R[1] += 1.0
+    t = torch.zeros(2, B, 2, 3, device=dev); t[1] += 2.0
+    best, cloud, Rs, ts = rap_amd.select_generations_by_overlap(stacked, torch.stack([far, mixed]), R, t, cu)
+    assert best.tolist() == [1, 0, 0, 0]                          # argmax; ties -> first
+    assert torch.equal(cloud[: 2 * N], mixed[: 2 * N]) and torch.equal(cloud[2 * N:], far[2 * N:])
+    assert Rs[0].min().item() == 1.0 and Rs[1:].abs().max().item() == 0.0 and ts[0].min().item() == 2.0
