@@ -202,7 +202,18 @@ def main():
                                                                                  _lib.ptr(R), _lib.ptr(tt), _lib.ptr(wsp), wsp.numel(), st()), TP * 24)
     mem_case("rigidify+blend (fit + apply)", lambda: lib.rap_rigidify_blend(_lib.ptr(v3), _lib.ptr(x3), _lib.ptr(ppp), args.batch, args.views, _lib.ptr(x0),
                                                                             0.6, 0.4, _lib.ptr(xn), _lib.ptr(wsp), wsp.numel(), st()), TP * (24 + 36))
-    y2 = torch.randn(TP, 256, device=dev, generator=g); W4 = torch.randn(3, 256, device=dev, generator=g); vo = torch.empty(TP, 3, device=dev)
+    # caller-side rows: generation selection criteria on a 20-step trajectory of the same batch
+    import rap_amd
+    cond = torch.rand(TP, 3, device=dev, generator=g) - 0.5
+    traj = cond[None] + 0.01 * torch.randn(20, TP, 3, device=dev, generator=g)
+    cu = torch.arange(0, TP + 1, args.views * args.points, dtype=torch.int32, device=dev)
+    sc = torch.ones(args.batch, device=dev)
+    mem_case("trajectory rigidity RMSE (20 x [Procrustes fit + RMSE])",
+             lambda: rap_amd.average_trajectory_rigidity_rmse(cond, traj, ppp, cu, sc), 20 * TP * 48)
+    t_ov = timeit(lambda: rap_amd.compute_overlap_ratio(cond, ppp, cu, [0.005, 0.01, 0.02]), iters=5, warm=1)
+    pairs = args.batch * float(args.views * args.points) ** 2
+    rows.append({"kernel": "overlap ratio (cross-part nearest neighbour, N^2 in LDS)", "ms": t_ov * 1e3, "pair_distances": pairs,
+                 "Gpairs_per_s": pairs / t_ov / 1e9})
     for r in rows:
         print(json.dumps(r))
 
