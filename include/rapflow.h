@@ -147,10 +147,27 @@ int rap_relative_transforms(const float* R_pred, const float* t_pred, const floa
                             const int64_t* points_per_part, int32_t B, int32_t P, const float* global_rotation,
                             const float* global_translation, float* out, void* stream);
 
+/* ---- MiniSpinNet local feature extractor (the step before the path) ----
+ * Replaces MiniSpinNet.forward (reference dataset_process/utils/spinnet/patch_embedder.py:49-183 with patchnet.py:16-84 and
+ * utils/common.py) as extract_sample_features.py:151-220 / demo.py:959-988 call it: global-z alignment, 512 points per patch,
+ * 3 x 7 x 20 voxels x 10 samples, delta 0.8 -- the only configuration the reference ships.  Weight blob = the float tensors
+ * of MiniSpinNet.state_dict() in registration order (pnt_layer, pool_layer, conv_net; num_batches_tracked skipped), eval mode.
+ * rap_spinnet_describe: pts (N,3) raw cloud, perm (N,) int32 or NULL = the shuffle select_patches applies before the ball
+ * query (patch_embedder.py:99-100; the ball query keeps the first 512 in-radius points IN THAT ORDER), kpts (K,3), des_r;
+ * desc_out (K,32) unit-norm descriptors = the `features` of the sampling path.  Keypoints are processed in chunks of
+ * keypoints_per_chunk; ws >= rap_spinnet_workspace_bytes(keypoints_per_chunk) (about 0.8 MB per keypoint). */
+typedef struct rap_spinnet rap_spinnet;
+int64_t rap_spinnet_weight_count(void);
+int rap_spinnet_create(const float* d_weights, int64_t n_floats, void* stream, rap_spinnet** out);
+void rap_spinnet_destroy(rap_spinnet* m);
+size_t rap_spinnet_workspace_bytes(int32_t keypoints_per_chunk);
+int rap_spinnet_describe(const rap_spinnet* m, const float* pts, const int32_t* perm, int64_t N, const float* kpts, int32_t K,
+                         float des_r, float* desc_out, int32_t keypoints_per_chunk, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels the calls above launch) ---- */
 /* C(M,N) = A(M,K) W(N,K)^T (+bias) (+resid) ; epilogue: 0 bias, 1 bias+resid, 2 bias+SiLU,
  * 3 GEGLU (W/bias must be value/gate interleaved by rap_geglu_interleave; C is (M,N/2)),
- * 4 head-major qkv scatter ([3][H][M][64]), 5 bias + anchor embedding select. */
+ * 4 head-major qkv scatter ([3][H][M][64]), 5 bias + anchor embedding select, 6 bias+ReLU. */
 int rap_gemm_f32(int32_t epilogue, const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc,
                  int32_t M, int32_t N, int32_t K, const float* bias, const float* resid, int32_t ldr,
                  const uint8_t* anchor, const float* anchor_emb, int32_t heads, void* stream);

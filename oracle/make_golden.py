@@ -121,6 +121,28 @@ def make_overlap_golden():
     print("overlap_ratio", os.path.getsize(path) // 1024, "KiB", ratios)
 
 
+def make_spinnet_golden():
+    """MiniSpinNet descriptors: the reference's unmodified module (ball_query restated, see
+    ref_loader.reference_spinnet_forward) on a 3000-point surface, 16 keypoints whose balls hold both fewer and more than 512
+    points (so both the keypoint fill and the 512-cap / last-slot centring are exercised), seeded synthetic weights."""
+    from rap_amd.spinnet import make_spinnet_weights
+    from oracle import spinnet_oracle as SO
+    sd = make_spinnet_weights(0)
+    g = torch.Generator().manual_seed(1)
+    pts = torch.rand(3000, 3, generator=g)
+    pts[:, 2] = 0.3 * torch.sin(4 * pts[:, 0]) + 0.05 * torch.rand(3000, generator=g)
+    kpts = pts[torch.randperm(3000, generator=g)[:16]].clone()
+    kpts[0] = torch.tensor([5.0, 5.0, 5.0])                 # a keypoint with an empty ball: the patch is 512 copies of it
+    des_r, seed = 0.3, 5
+    ref = ref_loader.reference_spinnet_forward(sd, pts, kpts, des_r, seed)
+    counts = (((kpts[:, None] - pts[None]) ** 2).sum(-1) < des_r ** 2).sum(1)
+    path = os.path.join(GOLDEN_DIR, "spinnet_k16.npz")
+    np.savez_compressed(path, pts=pts.numpy(), kpts=kpts.numpy(), perm=ref["perm"], des_r=np.float64(des_r), weight_seed=np.int64(0),
+                        desc=ref["desc"].numpy(), patches_first=ref["patches"][:, :4].numpy(), patches_last=ref["patches"][:, -1].numpy(),
+                        ball_counts=counts.numpy())
+    print("spinnet_k16", os.path.getsize(path) // 1024, "KiB; points per ball:", counts.tolist())
+
+
 def make_transform_golden():
     """Output transform files: the reference's own Evaluator._save_transformation_files on a
     3-object batch (trailing empty part, random GT poses / scales / global frames), with and without the global frame;
@@ -161,3 +183,5 @@ if __name__ == "__main__":
         make_transform_golden()
     if not only or "--overlap-only" in only:
         make_overlap_golden()
+    if not only or "--spinnet-only" in only:
+        make_spinnet_golden()

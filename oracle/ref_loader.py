@@ -209,6 +209,46 @@ def reference_transformation_files(data, sample_dir, dataset_name, sample_indice
     return {p.name: np.loadtxt(p) for p in sorted(sample_dir.glob("*_transform.txt"))}
 
 
+def reference_spinnet_forward(sd, pts, kpts, des_r, perm_seed):
+    """Run the reference's UNMODIFIED MiniSpinNet (dataset_process/utils/spinnet/*) on CPU.  Test-only shims: pytorch3d.ops.
+    ball_query is the restatement of oracle/spinnet_oracle.py (the wheel is absent); `Tensor.cuda` is a no-op for the duration
+    of the call (SPT hard-codes `.cuda()`, patch_embedder.py:176); numpy's global RNG is seeded so that the shuffle of
+    select_patches (:99) is reproducible -- the permutation it draws is returned."""
+    import numpy as np
+    from oracle import spinnet_oracle as SO
+    _install_pytorch3d_import_stub()
+
+    def ball_query(p1, p2, K, radius, return_nn=True, **kw):
+        idx, nn = zip(*[SO.ball_query_first_k(p1[b], p2[b], K, radius) for b in range(p1.shape[0])])
+        idx = torch.stack(idx); nn = torch.stack(nn)
+        d2 = ((p1[:, :, None, :] - nn) ** 2).sum(-1) * (idx >= 0)
+        return d2, idx, nn
+    sys.modules["pytorch3d.ops"].ball_query = ball_query
+    for name, path in (("dataset_process", "dataset_process"), ("dataset_process.utils", "dataset_process/utils"),
+                       ("dataset_process.utils.spinnet", "dataset_process/utils/spinnet"),
+                       ("dataset_process.utils.spinnet.utils", "dataset_process/utils/spinnet/utils")):
+        if name not in sys.modules:
+            m = types.ModuleType(name); m.__path__ = [os.path.join(REFERENCE_ROOT, path)]
+            sys.modules[name] = m
+    pe = importlib.import_module("dataset_process.utils.spinnet.patch_embedder")
+    common = importlib.import_module("dataset_process.utils.spinnet.utils.common")
+    pe.ball_query = ball_query; common.ball_query = ball_query          # both modules did `from pytorch3d.ops import ball_query`
+    net = pe.MiniSpinNet(des_r=des_r)
+    net.load_state_dict(sd, strict=False)                               # num_batches_tracked buffers are not in the blob
+    net.eval()
+    np.random.seed(perm_seed)
+    perm = np.random.choice(pts.shape[0], pts.shape[0], replace=False)
+    np.random.seed(perm_seed)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            out = net(pts[None], kpts[None], des_r, True)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    return {"desc": out["desc"], "patches": out["patches"], "perm": perm}
+
+
 _LOADED = None
 
 

@@ -52,6 +52,11 @@ SIGNATURES = {
     "rap_overlap_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "rap_overlap_ratio": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, _P, c_int32, _P, _P, _P, c_size_t, _P]),
     "rap_relative_transforms": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),
+    "rap_spinnet_weight_count": (c_int64, []),
+    "rap_spinnet_create": (c_int32, [_P, c_int64, _P, ctypes.POINTER(_P)]),
+    "rap_spinnet_destroy": (None, [_P]),
+    "rap_spinnet_workspace_bytes": (c_size_t, [c_int32]),
+    "rap_spinnet_describe": (c_int32, [_P, _P, _P, c_int64, _P, c_int32, c_float, _P, c_int32, _P, c_size_t, _P]),
     "rap_gemm_f32": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32,
                                _P, _P, c_int32, _P]),
     "rap_geglu_interleave": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P]),

@@ -848,3 +848,158 @@ extern "C" int rap_overlap_ratio(const float* pointclouds_pred, const int64_t* p
   return launch_overlap_ratio(stream, pointclouds_pred, cu_batch, w.off, B, P, (long)TP, h_taus, n_taus, ratios_out,
                               min_dist_out ? min_dist_out : w.min_dist, w.pid, w.items);
 }
+
+// ---------------------------------------------------------------------------------------------
+// MiniSpinNet local feature extractor
+// ---------------------------------------------------------------------------------------------
+#include <cmath>
+struct SpinLayer { int Cin, Cout, Kd, ldw; bool bn_relu; const float* W; const float* b; };
+struct rap_spinnet {
+  float* raw = nullptr;       // the caller's blob (MiniSpinNet.state_dict() float tensors, registration order)
+  float* derived = nullptr;   // folded + padded conv weights / biases, voxel table, pool weights
+  float h_w1[48], h_b1[16];   // point MLP with BatchNorm folded (kernel argument)
+  const float* vox;           // (420,3)
+  const void* pool_w;         // SpinPoolW on the device
+  SpinLayer layers[8];
+};
+static const int kSpinCin[8] = {16, 64, 64, 128, 128, 64, 64, 32};
+static const int kSpinCout[8] = {64, 64, 128, 128, 64, 64, 32, 32};
+
+extern "C" int64_t rap_spinnet_weight_count(void) {
+  int64_t n = 48 + 16 * 5 + (512 + 16 * 5 + 16 + 5);
+  for (int i = 0; i < 8; ++i) {
+    const int64_t kd = (int64_t)kSpinCin[i] * (i == 0 ? 27 : 9);
+    n += kSpinCout[i] * kd + kSpinCout[i] + (i < 7 ? 2 * kSpinCout[i] : 0);
+  }
+  return n;
+}
+
+extern "C" void rap_spinnet_destroy(rap_spinnet* m) {
+  if (!m) return;
+  if (m->raw) (void)hipFree(m->raw);
+  if (m->derived) (void)hipFree(m->derived);
+  delete m;
+}
+
+extern "C" int rap_spinnet_create(const float* d_weights, int64_t n_floats, void* stream_, rap_spinnet** out) {
+  if (!out) return RAP_ERR_INVALID;
+  *out = nullptr;
+  if (!d_weights || n_floats != rap_spinnet_weight_count()) return RAP_ERR_INVALID;
+  hipStream_t stream = (hipStream_t)stream_;
+  rap_spinnet* m = new (std::nothrow) rap_spinnet();
+  if (!m) return RAP_ERR_ALLOC;
+  auto fail = [&](int code) { rap_spinnet_destroy(m); return code; };
+  if (hipMalloc((void**)&m->raw, (size_t)n_floats * 4) != hipSuccess) { delete m; return RAP_ERR_ALLOC; }
+  size_t n_der = 420 * 3 + 1024;      // voxel table + pool struct (613 floats used)
+  for (int i = 0; i < 8; ++i) n_der += (size_t)128 * (i == 0 ? 448 : kSpinCin[i] * 9) + 128;
+  if (hipMalloc((void**)&m->derived, n_der * 4) != hipSuccess) return fail(RAP_ERR_ALLOC);
+  if (hipMemcpyAsync(m->raw, d_weights, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail(RAP_ERR_HIP);
+  // ---- small heads on the host: point MLP (128 floats) and attention pool (613 floats)
+  std::vector<float> h(128 + 613);
+  if (hipMemcpyAsync(h.data(), m->raw, h.size() * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return fail(RAP_ERR_HIP);
+  if (hipStreamSynchronize(stream) != hipSuccess) return fail(RAP_ERR_HIP);
+  {
+    const float *W = &h[0], *b = &h[48], *g = &h[64], *be = &h[80], *rm = &h[96], *rv = &h[112];
+    for (int c = 0; c < 16; ++c) {
+      const float s = g[c] / std::sqrt(rv[c] + 1e-5f);
+      for (int d = 0; d < 3; ++d) m->h_w1[c * 3 + d] = W[c * 3 + d] * s;
+      m->h_b1[c] = (b[c] - rm[c]) * s + be[c];
+    }
+  }
+  std::vector<float> pool(16 * 32 + 16 + 16 + 1);
+  {
+    const float* p0 = &h[128];
+    const float *W1 = p0, *b1 = p0 + 512, *g1 = p0 + 528, *be1 = p0 + 544, *rm1 = p0 + 560, *rv1 = p0 + 576;
+    const float *W2 = p0 + 592, *b2 = p0 + 608, *g2 = p0 + 609, *be2 = p0 + 610, *rm2 = p0 + 611, *rv2 = p0 + 612;
+    for (int j = 0; j < 16; ++j) {
+      const float s = g1[j] / std::sqrt(rv1[j] + 1e-5f);
+      for (int c = 0; c < 32; ++c) pool[j * 32 + c] = W1[j * 32 + c] * s;
+      pool[512 + j] = (b1[j] - rm1[j]) * s + be1[j];
+    }
+    const float s2 = g2[0] / std::sqrt(rv2[0] + 1e-5f);
+    for (int j = 0; j < 16; ++j) pool[528 + j] = W2[j] * s2;
+    pool[544] = (b2[0] - rm2[0]) * s2 + be2[0];
+  }
+  // ---- voxel centres: get_voxel_coordinate(radius 1, rad_n 3, azi_n 20, ele_n 7)  (utils/common.py:213-225, 338-372, 387-393)
+  std::vector<float> vox(420 * 3);
+  for (int r = 0; r < 3; ++r)
+    for (int e = 0; e < 7; ++e)
+      for (int a = 0; a < 20; ++a) {
+        const double beta = M_PI * e / 7.0 + M_PI / 7.0 / 2.0, alpha = 2.0 * M_PI * a / 20.0 + M_PI / 20.0;
+        const double sc = (double)r / 3.0 + 1.0 / 6.0;
+        float* v = &vox[((r * 7 + e) * 20 + a) * 3];
+        v[0] = (float)(sc * std::sin(beta) * std::cos(alpha));
+        v[1] = (float)(sc * std::sin(beta) * std::sin(alpha));
+        v[2] = (float)(sc * std::cos(beta));
+      }
+  float* q = m->derived;
+  if (hipMemcpyAsync(q, vox.data(), vox.size() * 4, hipMemcpyHostToDevice, stream) != hipSuccess) return fail(RAP_ERR_HIP);
+  m->vox = q; q += 420 * 3;
+  if (hipMemcpyAsync(q, pool.data(), pool.size() * 4, hipMemcpyHostToDevice, stream) != hipSuccess) return fail(RAP_ERR_HIP);
+  m->pool_w = q; q += 1024;
+  if (hipStreamSynchronize(stream) != hipSuccess) return fail(RAP_ERR_HIP);   // vox / pool are stack-backed host vectors
+  // ---- conv stack: fold BatchNorm (affine=False) and pad to 128 output columns / 32-multiple k
+  const float* p = m->raw + 128 + 613;
+  for (int i = 0; i < 8; ++i) {
+    SpinLayer& L = m->layers[i];
+    L.Cin = kSpinCin[i]; L.Cout = kSpinCout[i]; L.Kd = L.Cin * (i == 0 ? 27 : 9); L.ldw = i == 0 ? 448 : L.Kd; L.bn_relu = i < 7;
+    const float* W = p; p += (size_t)L.Cout * L.Kd;
+    const float* b = p; p += L.Cout;
+    const float *rm = nullptr, *rv = nullptr;
+    if (L.bn_relu) { rm = p; p += L.Cout; rv = p; p += L.Cout; }
+    float* Wd = q; q += (size_t)128 * L.ldw;
+    float* bd = q; q += 128;
+    int rc;
+    if ((rc = launch_spin_fold(stream, W, b, nullptr, nullptr, rm, rv, L.Cout, L.Kd, Wd, L.ldw, 128, bd))) return fail(rc);
+    L.W = Wd; L.b = bd;
+  }
+  if ((int64_t)(p - m->raw) != n_floats) return fail(RAP_ERR_INVALID);
+  *out = m;
+  return RAP_OK;
+}
+
+struct SpinWs { float *x0, *A, *Y0, *Y1; size_t total; };
+static SpinWs carve_spin(int Kc, char* basep) {
+  SpinWs w; size_t off = 0;
+  auto take = [&](size_t bytes) { char* r = basep ? basep + off : nullptr; off += align_up(bytes, 256); return r; };
+  w.x0 = (float*)take((size_t)Kc * 420 * 16 * 4);
+  w.A = (float*)take((size_t)Kc * 140 * 1152 * 4);
+  w.Y0 = (float*)take((size_t)Kc * 140 * 128 * 4);
+  w.Y1 = (float*)take((size_t)Kc * 140 * 128 * 4);
+  w.total = off;
+  return w;
+}
+extern "C" size_t rap_spinnet_workspace_bytes(int32_t keypoints_per_chunk) {
+  return keypoints_per_chunk <= 0 ? 0 : carve_spin(keypoints_per_chunk, nullptr).total;
+}
+
+extern "C" int rap_spinnet_describe(const rap_spinnet* m, const float* pts, const int32_t* perm, int64_t N, const float* kpts,
+                                    int32_t K, float des_r, float* desc_out, int32_t keypoints_per_chunk, void* ws, size_t ws_bytes,
+                                    void* stream_) {
+  if (!m || !pts || !kpts || !desc_out || N <= 0 || K < 0 || !(des_r > 0.f) || keypoints_per_chunk <= 0) return RAP_ERR_INVALID;
+  if (K == 0) return RAP_OK;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  SpinWs w = carve_spin(keypoints_per_chunk, (char*)ws);
+  if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  for (int k0 = 0; k0 < K; k0 += keypoints_per_chunk) {
+    const int Kc = K - k0 < keypoints_per_chunk ? K - k0 : keypoints_per_chunk;
+    const int M = Kc * 140;
+    if ((rc = launch_spin_patch(stream, pts, perm, (long)N, kpts + (size_t)k0 * 3, Kc, des_r, m->vox, m->h_w1, m->h_b1, w.x0))) return rc;
+    float* yin = nullptr;
+    float* yout = w.Y0;
+    for (int i = 0; i < 8; ++i) {
+      const SpinLayer& L = m->layers[i];
+      if (i == 0) rc = launch_spin_im2col3d(stream, w.x0, Kc, w.A, L.ldw);
+      else rc = launch_spin_im2col2d(stream, yin, 128, L.Cin, Kc, w.A);
+      if (rc) return rc;
+      GemmParams g{};
+      g.A = w.A; g.lda = L.ldw; g.W = L.W; g.ldw = L.ldw; g.C = yout; g.ldc = 128; g.M = M; g.N = 128; g.K = L.ldw; g.bias = L.b;
+      if ((rc = launch_gemm_f32(stream, L.bn_relu ? EPI_BIAS_RELU : EPI_BIAS, g))) return rc;
+      yin = yout; yout = (yout == w.Y0) ? w.Y1 : w.Y0;
+    }
+    if ((rc = launch_spin_pool(stream, yin, 128, Kc, m->pool_w, desc_out + (size_t)k0 * 32))) return rc;
+  }
+  return RAP_OK;
+}

@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
           p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
         } else if (EPI == EPI_BIAS_SILU) {
           p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
+        } else if (EPI == EPI_BIAS_RELU) {
+          p.C[(size_t)m * p.ldc + n] = fmaxf(v, 0.f);
         } else if (EPI == EPI_BIAS_ANCHOR) {
           const int sel = p.anchor[m] ? 1 : 0;
           p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
@@ -382,6 +384,8 @@ __global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 2 : (WNT == 2 ? 2 : 1))) voi
           p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
         } else if (EPI == EPI_BIAS_SILU) {
           p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
+        } else if (EPI == EPI_BIAS_RELU) {
+          p.C[(size_t)m * p.ldc + n] = fmaxf(v, 0.f);
         } else if (EPI == EPI_BIAS_ANCHOR) {
           const int sel = p.anchor[m] ? 1 : 0;
           p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
@@ -564,6 +568,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
           p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
         } else if (EPI == EPI_BIAS_SILU) {
           p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
+        } else if (EPI == EPI_BIAS_RELU) {
+          p.C[(size_t)m * p.ldc + n] = fmaxf(v, 0.f);
         } else if (EPI == EPI_BIAS_ANCHOR) {
           const int sel = p.anchor[m] ? 1 : 0;
           p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
@@ -616,6 +622,7 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p) {
       launch_gemm_variant<EPI_QKV_HEADMAJOR>(stream, p, v);
       break;
     case EPI_BIAS_ANCHOR: launch_gemm_variant<EPI_BIAS_ANCHOR>(stream, p, v); break;
+    case EPI_BIAS_RELU: launch_gemm_variant<EPI_BIAS_RELU>(stream, p, v); break;
     default: return RAP_ERR_INVALID;
   }
   RAP_LAUNCH_CHECK();

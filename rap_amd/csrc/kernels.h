@@ -14,6 +14,7 @@ enum GemmEpilogue {
   EPI_GEGLU = 3,         // W rows pre-interleaved [32 value | 32 gate]: C(M,N/2) = (h + bh) * gelu_erf(g + bg)
   EPI_QKV_HEADMAJOR = 4, // N = 3*H*64: scatter to [3][H][M][64]
   EPI_BIAS_ANCHOR = 5,   // C = acc + bias[n] + anchor_emb[anchor[m] ? 1 : 0][n]
+  EPI_BIAS_RELU = 6,     // C = max(acc + bias[n], 0)      (MiniSpinNet convolutions with folded BatchNorm)
 };
 
 struct GemmParams {
@@ -141,3 +142,12 @@ int launch_relative_transforms(hipStream_t stream, const float* R_pred, const fl
 size_t overlap_max_items(long TP, int B);
 int launch_overlap_ratio(hipStream_t stream, const float* pts, const int32_t* cu_batch, const int32_t* part_off, int B, int P,
                          long TP, const float* h_taus, int n_taus, float* ratios, float* min_dist, int32_t* pid, void* items_ws);
+
+// MiniSpinNet local feature extractor (spinnet.hip; reference dataset_process/utils/spinnet/*)
+int launch_spin_fold(hipStream_t stream, const float* W, const float* b, const float* gamma, const float* beta, const float* rm,
+                     const float* rv, int Cout, int Kd, float* Wout, int ldw, int Npad, float* bout);
+int launch_spin_patch(hipStream_t stream, const float* pts, const int32_t* perm, long N, const float* kpts, int K, float des_r,
+                      const float* vox, const float* h_w1, const float* h_b1, float* x0);
+int launch_spin_im2col3d(hipStream_t stream, const float* x0, int K, float* A, int ldA);
+int launch_spin_im2col2d(hipStream_t stream, const float* y, int ldy, int Cin, int K, float* A);
+int launch_spin_pool(hipStream_t stream, const float* x, int ldx, int K, const void* d_pool_w, float* desc);

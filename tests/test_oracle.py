@@ -207,3 +207,37 @@ def test_oracle_overlap_ratio_matches_reference_golden():
     assert ((ratios - torch.from_numpy(g["ratios"]).double()).abs() * n[None, :]).max().item() <= 2.0 + 1e-6
     assert ratios[:, 1].abs().max().item() == 0.0            # single-part object
     assert torch.isinf(min_d[int(cu[1]):int(cu[2])]).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# MiniSpinNet local feature extractor
+# ---------------------------------------------------------------------------------------------
+def _spinnet_golden():
+    from rap_amd.spinnet import make_spinnet_weights
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spinnet_k16.npz"))
+    return z, make_spinnet_weights(int(z["weight_seed"]))
+
+
+def test_spinnet_oracle_matches_reference_golden():
+    from oracle import spinnet_oracle as SO
+    z, sd = _spinnet_golden()
+    out = SO.forward(sd, torch.from_numpy(z["pts"]), torch.from_numpy(z["kpts"]), float(z["des_r"]), torch.from_numpy(z["perm"]))
+    assert (out["patches"][:, :4] - torch.from_numpy(z["patches_first"])).abs().max().item() == 0.0
+    assert (out["patches"][:, -1] - torch.from_numpy(z["patches_last"])).abs().max().item() == 0.0
+    assert (out["desc"] - torch.from_numpy(z["desc"])).abs().max().item() < 2e-6
+    counts = z["ball_counts"]
+    assert counts.min() == 0 and (counts < 512).any() and (counts > 512).any()      # the fixture exercises fill and cap
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
+def test_spinnet_oracle_matches_live_reference():
+    from oracle import spinnet_oracle as SO
+    from rap_amd.spinnet import make_spinnet_weights
+    sd = make_spinnet_weights(3)
+    g = torch.Generator().manual_seed(9)
+    pts = torch.randn(1200, 3, generator=g) * torch.tensor([1.0, 1.0, 0.15])
+    kpts = pts[:6].clone()
+    ref = ref_loader.reference_spinnet_forward(sd, pts, kpts, 0.6, 11)
+    out = SO.forward(sd, pts, kpts, 0.6, torch.as_tensor(ref["perm"]))
+    assert (out["patches"] - ref["patches"]).abs().max().item() == 0.0
+    assert (out["desc"] - ref["desc"]).abs().max().item() < 2e-6
