@@ -214,6 +214,16 @@ def main():
     pairs = args.batch * float(args.views * args.points) ** 2
     rows.append({"kernel": "overlap ratio (cross-part nearest neighbour, N^2 in LDS)", "ms": t_ov * 1e3, "pair_distances": pairs,
                  "Gpairs_per_s": pairs / t_ov / 1e9})
+    # the step before the path: MiniSpinNet descriptors for 4096 keypoints of a 65536-point cloud
+    from rap_amd.spinnet import MiniSpinNet, make_spinnet_weights
+    net = MiniSpinNet(des_r=0.2); net.load_state_dict(make_spinnet_weights(0)); net.to(dev)
+    cloud = torch.rand(65536, 3, device=dev, generator=g) * torch.tensor([4.0, 4.0, 0.3], device=dev)
+    kp = cloud[:4096].clone()
+    import numpy as np
+    perm = np.random.RandomState(0).permutation(65536)
+    t_sp = timeit(lambda: net(cloud[None], kp[None], 0.2, True, perm=perm), iters=3, warm=1)
+    rows.append({"kernel": "MiniSpinNet descriptors (65536 pts, 4096 keypoints)", "ms": t_sp * 1e3, "keypoints_per_s": 4096 / t_sp,
+                 "algorithmic_TFLOPs": 4096 * 119e6 / t_sp / 1e12})
     for r in rows:
         print(json.dumps(r))
 
