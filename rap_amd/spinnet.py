@@ -42,7 +42,7 @@ def make_spinnet_weights(seed: int = 0) -> dict:
     biases that keep the ReLUs of the attention pool active so that descriptors are not degenerate."""
     sd = {}
     for name, shape in spinnet_weight_spec():
-        g = torch.Generator().manual_seed(seed * 7919 + (hash(name) & 0xFFFF) * 0 + sum(ord(c) for c in name))
+        g = torch.Generator().manual_seed(seed * 7919 + sum(ord(c) for c in name))     # per tensor, by name
         if name.endswith("running_var"):
             t = torch.rand(shape, generator=g) * 0.8 + 0.4
         elif name.endswith("running_mean"):
