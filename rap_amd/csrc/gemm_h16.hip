@@ -36,154 +36,16 @@ __device__ __forceinline__ float gelu_erf_fast(float g) {
   return g < 0.f ? 0.5f * g * q : g * (1.0f - 0.5f * q);
 }
 
-template <int EPI, int DT, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16_kernel(GemmParamsH p) {
-  typedef typename H16<DT>::T8 T8;
-  constexpr int NT = 64 * WM * WN;
-  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;   // 16-byte chunks per thread per k-tile
-  constexpr int ABYTES = BM * 128, BBYTES = BN * 128;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [A0 A1 B0 B1]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-  const int wm = wave / WN, wn = wave % WN;
-
-  const int nt = p.N / BN;
-  const int mt = (p.M + BM - 1) / BM;
-  const int logical = xcd_remap(blockIdx.x, mt * nt);
-  const int m0 = (logical / nt) * BM;
-  const int n0 = (logical % nt) * BN;
-
-  // DMA sources: chunk id = i*NT + tid -> (row = id >> 3, physical slot = id & 7) holds logical slot (slot ^ swz(row))
-  const u16* a_src[CA];
-  const u16* w_src[CB];
-#pragma unroll
-  for (int i = 0; i < CA; ++i) {
-    const int id = i * NT + tid;
-    const int row = id >> 3;
-    const int lslot = (id & 7) ^ ((row >> 1) & 7);
-    int r = m0 + row;
-    r = r < p.M ? r : p.M - 1;
-    a_src[i] = p.A + (size_t)r * p.lda + 8 * lslot;
-  }
-#pragma unroll
-  for (int i = 0; i < CB; ++i) {
-    const int id = i * NT + tid;
-    const int row = id >> 3;
-    const int lslot = (id & 7) ^ ((row >> 1) & 7);
-    w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + 8 * lslot;
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / 64;
-  const int sw = (l31 >> 1) & 7;
-  const int a_row = (wm * TM * 32 + l31) * 128;                       // byte offsets inside one A / B buffer
-  const int b_row = (wn * TN * 32 + l31) * 128;
-
-  // The DMA is issued from inline asm (see gemm_f32.hip: through the builtin hipcc drains it before the first
-  // fragment read of the same iteration).  m0 carries the wave-uniform LDS byte address of the 1 KiB piece.
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-#define HG_DMA1(GSRC, LDSB)                                                                                   \
-  {                                                                                                           \
-    unsigned keep_;                                                                                           \
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                 : "=&s"(keep_) : "v"(GSRC), "s"(LDSB) : "memory");                                           \
-  }
-#define HG_DMA(KT, BUF)                                                                                       \
-  _Pragma("unroll") for (int i = 0; i < CA; ++i)                                                              \
-    HG_DMA1(a_src[i] + (size_t)(KT) * 64, lds_wave + (unsigned)((BUF) * ABYTES + i * NT * 16))                \
-  _Pragma("unroll") for (int i = 0; i < CB; ++i)                                                              \
-    HG_DMA1(w_src[i] + (size_t)(KT) * 64, lds_wave + (unsigned)(2 * ABYTES + (BUF) * BBYTES + i * NT * 16))
-#define HG_SYNC asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
-#define HG_FENCE __builtin_amdgcn_sched_barrier(0);
-
-  struct Frag { uint4 a[TM]; uint4 b[TN]; };
-  Frag f0, f1;
-  auto read_frag = [&](Frag& f, int buf, int g) {
-    const int co = ((2 * g + hi) ^ sw) * 16;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-      f.a[i] = *reinterpret_cast<const uint4*>(smem + buf * ABYTES + a_row + i * 32 * 128 + co);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-      f.b[j] = *reinterpret_cast<const uint4*>(smem + 2 * ABYTES + buf * BBYTES + b_row + j * 32 * 128 + co);
-  };
-  auto mma = [&](const Frag& f) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, f.a[i]), __builtin_bit_cast(T8, f.b[j]), acc[i][j]);
-  };
-
-  HG_DMA(0, 0)
-  HG_SYNC
-  read_frag(f0, 0, 0);
-
-  int kt = 0;
-  for (; kt + 1 < nk; ++kt) {
-    const int cur = kt & 1;
-    HG_DMA(kt + 1, cur ^ 1)                 // spare buffer: every wave finished reading it before the last barrier
-    read_frag(f1, cur, 1);
-    HG_FENCE
-    mma(f0);
-    HG_FENCE
-    read_frag(f0, cur, 2);
-    HG_FENCE
-    mma(f1);
-    HG_FENCE
-    read_frag(f1, cur, 3);
-    HG_FENCE
-    mma(f0);
-    HG_FENCE
-    HG_SYNC                                 // tile kt+1 landed (vmcnt(0)) and visible; reads of tile kt complete
-    read_frag(f0, cur ^ 1, 0);
-    HG_FENCE
-    mma(f1);
-    HG_FENCE
-  }
-  {
-    const int cur = kt & 1;
-    read_frag(f1, cur, 1);
-    HG_FENCE
-    mma(f0);
-    HG_FENCE
-    read_frag(f0, cur, 2);
-    HG_FENCE
-    mma(f1);
-    HG_FENCE
-    read_frag(f1, cur, 3);
-    HG_FENCE
-    mma(f0);
-    HG_FENCE
-    mma(f1);
-  }
-
-  // ---------------- epilogue ----------------
-  // acc[i][j][r] = C[mw + 32 i + crow(r, hi)][nw + 32 j + l31]: a lane owns ONE column, so direct stores would be
-  // 2- or 4-byte scatters (measured: the out-projection ran at 147 TF, 4x its HBM floor).  Every wave therefore
-  // transposes its tile through a private LDS slab (the operand buffers are dead by now) and writes whole rows with
-  // 16-byte stores; the fp32 residual is read the same way.
-  static_assert(TN == 2, "wave tiles are 64 columns wide: one head / one GEGLU value+gate group");
-  constexpr int STG_BYTES = 64 * 144;            // largest slab: the V^T image of 64 tokens (64 d rows of 144 bytes)
-  static_assert(64 * WM * WN / 64 * STG_BYTES <= 2 * (BM + BN) * 128, "staging slabs must fit the operand buffers");
-  __syncthreads();
-  unsigned char* stg = smem + wave * STG_BYTES;
-  const int mw = m0 + wm * TM * 32;
-  const int nw = n0 + wn * 64;
-
+// ---------------- epilogue (shared by the kernels below) ----------------
+// acc[i][j][r] = C[mw + 32 i + crow(r, hi)][nw + 32 j + l31]: a lane owns ONE column, so direct stores would be
+// 2- or 4-byte scatters (measured: the out-projection ran at 147 TF, 4x its HBM floor).  Every wave therefore
+// transposes its tile through a private LDS slab `stg` (the operand buffers are dead by now; the caller has
+// synchronised the block) and writes whole rows with 16-byte stores; the fp32 residual is read the same way.
+#define H16_STG_BYTES (64 * 144)   // largest slab: the V^T image of 64 tokens (64 d rows of 144 bytes)
+template <int EPI, int DT, int TM>
+__device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (&acc)[TM][2], unsigned char* stg, int mw, int nw,
+                                                  int lane) {
+  const int hi = lane >> 5, l31 = lane & 31;
   if constexpr (EPI == EPI_H_GEGLU) {
     u16* C = reinterpret_cast<u16*>(p.C);
     u16* sh = reinterpret_cast<u16*>(stg);       // [32 rows][32 outputs]
@@ -302,9 +164,289 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
   }
 }
 
+template <int EPI, int DT, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16_kernel(GemmParamsH p) {
+  typedef typename H16<DT>::T8 T8;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;   // 16-byte chunks per thread per k-tile
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [A0 A1 B0 B1]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nt = p.N / BN;
+  const int mt = (p.M + BM - 1) / BM;
+  const int logical = xcd_remap(blockIdx.x, mt * nt);
+  const int m0 = (logical / nt) * BM;
+  const int n0 = (logical % nt) * BN;
+
+  // DMA sources: chunk id = i*NT + tid -> (row = id >> 3, physical slot = id & 7) holds logical slot (slot ^ swz(row))
+  const u16* a_src[CA];
+  const u16* w_src[CB];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 3;
+    const int lslot = (id & 7) ^ ((row >> 1) & 7);
+    int r = m0 + row;
+    r = r < p.M ? r : p.M - 1;
+    a_src[i] = p.A + (size_t)r * p.lda + 8 * lslot;
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 3;
+    const int lslot = (id & 7) ^ ((row >> 1) & 7);
+    w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + 8 * lslot;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / 64;
+  const int sw = (l31 >> 1) & 7;
+  const int a_row = (wm * TM * 32 + l31) * 128;                       // byte offsets inside one A / B buffer
+  const int b_row = (wn * TN * 32 + l31) * 128;
+
+  // The DMA is issued from inline asm (see gemm_f32.hip: through the builtin hipcc drains it before the first
+  // fragment read of the same iteration).  m0 carries the wave-uniform LDS byte address of the 1 KiB piece.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+#define HG_DMA1(GSRC, LDSB)                                                                                   \
+  {                                                                                                           \
+    unsigned keep_;                                                                                           \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(GSRC), "s"(LDSB) : "memory");                                           \
+  }
+#define HG_DMA(KT, BUF)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < CA; ++i)                                                              \
+    HG_DMA1(a_src[i] + (size_t)(KT) * 64, lds_wave + (unsigned)((BUF) * ABYTES + i * NT * 16))                \
+  _Pragma("unroll") for (int i = 0; i < CB; ++i)                                                              \
+    HG_DMA1(w_src[i] + (size_t)(KT) * 64, lds_wave + (unsigned)(2 * ABYTES + (BUF) * BBYTES + i * NT * 16))
+#define HG_SYNC asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+#define HG_FENCE __builtin_amdgcn_sched_barrier(0);
+
+  struct Frag { uint4 a[TM]; uint4 b[TN]; };
+  Frag f0, f1;
+  auto read_frag = [&](Frag& f, int buf, int g) {
+    const int co = ((2 * g + hi) ^ sw) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      f.a[i] = *reinterpret_cast<const uint4*>(smem + buf * ABYTES + a_row + i * 32 * 128 + co);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      f.b[j] = *reinterpret_cast<const uint4*>(smem + 2 * ABYTES + buf * BBYTES + b_row + j * 32 * 128 + co);
+  };
+  auto mma = [&](const Frag& f) {
+    if (p.ablate & 2) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, f.a[i]), __builtin_bit_cast(T8, f.b[j]), acc[i][j]);
+  };
+
+  HG_DMA(0, 0)
+  HG_SYNC
+  read_frag(f0, 0, 0);
+
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {
+    const int cur = kt & 1;
+    if (!(p.ablate & 1)) { HG_DMA(kt + 1, cur ^ 1) }   // spare buffer: every wave finished reading it before the last barrier
+    read_frag(f1, cur, 1);
+    HG_FENCE
+    mma(f0);
+    HG_FENCE
+    read_frag(f0, cur, 2);
+    HG_FENCE
+    mma(f1);
+    HG_FENCE
+    read_frag(f1, cur, 3);
+    HG_FENCE
+    mma(f0);
+    HG_FENCE
+    HG_SYNC                                 // tile kt+1 landed (vmcnt(0)) and visible; reads of tile kt complete
+    read_frag(f0, cur ^ 1, 0);
+    HG_FENCE
+    mma(f1);
+    HG_FENCE
+  }
+  {
+    const int cur = kt & 1;
+    read_frag(f1, cur, 1);
+    HG_FENCE
+    mma(f0);
+    HG_FENCE
+    read_frag(f0, cur, 2);
+    HG_FENCE
+    mma(f1);
+    HG_FENCE
+    read_frag(f1, cur, 3);
+    HG_FENCE
+    mma(f0);
+    HG_FENCE
+    mma(f1);
+  }
+
+  // ---------------- epilogue ----------------
+  static_assert(TN == 2, "wave tiles are 64 columns wide: one head / one GEGLU value+gate group");
+  static_assert(WM * WN * H16_STG_BYTES <= 2 * (BM + BN) * 128, "staging slabs must fit the operand buffers");
+  __syncthreads();
+  gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ring variants (rap_set_tuning(2, 3 | 4); NOT the default): BK = 32 slices in an LDS ring with NSTAGE - 1 slices in flight
+// (counted s_waitcnt vmcnt, never 0 in the steady state) -- 256x256 / 8 waves / four 32 KB stages, or 256x128 / 4 waves /
+// three 24 KB stages at TWO blocks per CU.
+//
+// Two hypotheses about the two-stage kernel's 28 % of peak on the K = 512 shapes, both measured and rejected on MI355X
+// (profiles/r01_run24-27_gemm_h16_experiments.jsonl): (a) "one 64 KB transfer in flight per CU cannot hide the LDS-DMA latency"
+// -- three slices in flight: 676 vs 727 TF on the qkv shape; (b) "with one block per CU the store-bound epilogue (0.25 of the
+// 0.6 ms: ablation with neither DMA nor MFMA) never overlaps a k-loop" -- two blocks per CU: 642 TF (50 % more operand traffic
+// at the smaller tile eats the overlap).  PMC on the default kernel: waves spend 37 % parked on s_waitcnt / barriers, 42 % on
+// MFMA issue stalls, LDS bank conflicts 2 %.  Kept selectable, tested, as the A/B evidence.  64-byte LDS rows: bank conflicts of
+// the fragment reads are removed by slot' = slot ^ ((row >> 2) & 3), applied to the DMA source address and the ds_read_b128 address.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int DT, int WM, int WN, int TM, int NSTAGE>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_h16_ring_kernel(GemmParamsH p) {
+  typedef typename H16<DT>::T8 T8;
+  constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 64 * WN, TN = 2;
+  constexpr int CA = BM * 4 / NT, CB = BN * 4 / NT;      // 16-byte chunks per thread per k-slice (64-byte rows)
+  constexpr int STAGE = (BM + BN) * 64;                  // bytes: [A BM x 64 B][B BN x 64 B]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nt = p.N / BN;
+  const int mt = (p.M + BM - 1) / BM;
+  const int logical = xcd_remap(blockIdx.x, mt * nt);
+  const int m0 = (logical / nt) * BM;
+  const int n0 = (logical % nt) * BN;
+
+  // DMA sources: chunk id = i*NT + tid -> (row = id >> 2, physical slot = id & 3) holds logical slot (slot ^ ((row >> 2) & 3))
+  const u16* a_src[CA];
+  const u16* w_src[CB];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 2;
+    int r = m0 + row;
+    r = r < p.M ? r : p.M - 1;
+    a_src[i] = p.A + (size_t)r * p.lda + 8 * ((id & 3) ^ ((row >> 2) & 3));
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 2;
+    w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + 8 * ((id & 3) ^ ((row >> 2) & 3));
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / 32;
+  const int sw = (l31 >> 2) & 3;
+  const int a_row = (wm * TM * 32 + l31) * 64;
+  const int b_row = BM * 64 + (wn * TN * 32 + l31) * 64;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+#define HR_DMA(KT, SLOT)                                                                                      \
+  {                                                                                                           \
+    const unsigned sb_ = lds_wave + (unsigned)((SLOT) * STAGE);                                               \
+    _Pragma("unroll") for (int i = 0; i < CA; ++i) HG_DMA1(a_src[i] + (size_t)(KT) * 32, sb_ + (unsigned)(i * NT * 16))          \
+    _Pragma("unroll") for (int i = 0; i < CB; ++i) HG_DMA1(w_src[i] + (size_t)(KT) * 32, sb_ + (unsigned)(BM * 64 + i * NT * 16)) \
+  }
+  // "at most D younger slices outstanding": D * (CA + CB) transfers
+#define HR_WAIT(D)                                                                                            \
+  if constexpr ((D) * (CA + CB) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+  else if constexpr ((D) * (CA + CB) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   \
+  else if constexpr ((D) * (CA + CB) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                   \
+  else if constexpr ((D) * (CA + CB) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                   \
+  else if constexpr ((D) * (CA + CB) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 \
+  else static_assert((D) * (CA + CB) == 0, "add the vmcnt literal");
+
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+    if (s0 < nk) HR_DMA(s0, s0)
+
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // slice kt has landed once at most the transfers of the younger in-flight slices are outstanding
+    const int younger = nk - 1 - kt < NSTAGE - 2 ? nk - 1 - kt : NSTAGE - 2;
+    if (younger >= 2) { HR_WAIT(NSTAGE >= 4 ? 2 : 0) }
+    else if (younger == 1) { HR_WAIT(NSTAGE >= 3 ? 1 : 0) }
+    else { HR_WAIT(0) }
+    __syncthreads();                         // slice kt visible to every wave; every wave is done with slice kt-1 -> its stage is free
+    int free_slot = slot - 1; free_slot = free_slot < 0 ? NSTAGE - 1 : free_slot;
+    if (kt + NSTAGE - 1 < nk) HR_DMA(kt + NSTAGE - 1, free_slot)
+    const unsigned char* st = smem + slot * STAGE;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int co = ((2 * g + hi) ^ sw) * 16;
+      uint4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(st + a_row + i * 32 * 64 + co);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(st + b_row + j * 32 * 64 + co);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, fa[i]), __builtin_bit_cast(T8, fb[j]), acc[i][j]);
+    }
+    slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+  }
+  static_assert(WM * WN * H16_STG_BYTES <= NSTAGE * STAGE, "staging slabs must fit the operand ring");
+  __syncthreads();
+  gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
+}
+
 // tuning knob (rap_set_tuning key 2): 0 = 128x128 tile, 4 waves, two blocks per CU; 1 = 256x256 tile, 8 waves
-// (wave tile 128x64), one block per CU; 2 = 256x128 tile, 8 waves (wave tile 64x64).
+// (wave tile 128x64), two 64 KB stages (the default); 2 = 256x128 tile, 8 waves (wave tile 64x64); 3 = 256x256 ring of four 32 KB stages,
+// one block per CU; 4 = 256x128 ring (4 waves of 128x64, three 24 KB stages, TWO blocks per CU: one block's epilogue and
+// barrier stalls are covered by the other's k-loop).
 int g_rap_gemm_h16_variant = 1;
+
+template <int EPI, int DT, int WM, int WN, int TM, int NSTAGE>
+static int launch_ring(hipStream_t stream, const GemmParamsH& p) {
+  constexpr int BM = 32 * TM * WM, BN = 64 * WN;
+  constexpr int LDS = NSTAGE * (BM + BN) * 64;
+  static bool attr_done = false;
+  auto kern = gemm_h16_ring_kernel<EPI, DT, WM, WN, TM, NSTAGE>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      rap_set_last_hip_error((int)hipGetLastError());
+      return RAP_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(((p.M + BM - 1) / BM) * (p.N / BN)), dim3(64 * WM * WN), LDS, stream, p);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
 
 template <int EPI, int DT, int WM, int WN, int TM, int TN>
 static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
@@ -328,7 +470,9 @@ static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
 template <int EPI, int DT>
 static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
   const int v = g_rap_gemm_h16_variant;
-  if (v == 1 && p.N % 256 == 0) return launch_cfg<EPI, DT, 2, 4, 4, 2>(stream, p);
+  if (v == 4) return launch_ring<EPI, DT, 2, 2, 4, 3>(stream, p);
+  if (v == 3 && p.N % 256 == 0) return launch_ring<EPI, DT, 2, 4, 4, 4>(stream, p);
+  if ((v == 1 || v == 3) && p.N % 256 == 0) return launch_cfg<EPI, DT, 2, 4, 4, 2>(stream, p);
   if (v == 2) return launch_cfg<EPI, DT, 4, 2, 2, 2>(stream, p);
   return launch_cfg<EPI, DT, 2, 2, 2, 2>(stream, p);
 }
@@ -348,7 +492,7 @@ static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
 
 int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p) {
   if (p.M <= 0) return RAP_OK;
-  if (p.N % 128 != 0 || p.K % 64 != 0 || p.K <= 0) return RAP_ERR_INVALID;
+  if (p.N % 128 != 0 || p.K % 64 != 0 || p.K <= 0) return RAP_ERR_INVALID;      // K % 64: two 32-wide ring slices / one 64-wide tile
   if ((p.lda & 7) || (p.ldw & 7)) return RAP_ERR_INVALID;
   if (dtype == RAP_DT_BF16) return launch_dt<RAP_DT_BF16>(stream, epilogue, p);
   if (dtype == RAP_DT_F16) return launch_dt<RAP_DT_F16>(stream, epilogue, p);
