@@ -147,6 +147,19 @@ int rap_relative_transforms(const float* R_pred, const float* t_pred, const floa
                             const int64_t* points_per_part, int32_t B, int32_t P, const float* global_rotation,
                             const float* global_translation, float* out, void* stream);
 
+/* Nearest-neighbour metrics of the same evaluator.  ws >= rap_nn_metrics_workspace_bytes(points, B).
+ * rap_chamfer_rmse replaces compute_cd (reference eval/metrics.py:14-48): per object sqrt(0.5 (mean_i min_j |gt_i - pred_j|^2 +
+ * mean_j min_i |pred_j - gt_i|^2)); gt, pred (TP,3) packed by cu_batch (B+1,) int32; out (B,).
+ * rap_correspondence_rmse replaces compute_correspondence_rmse (:386-469) for ONE scan pair: nearest target_gt point of every
+ * source_gt point; pairs within distance_threshold are correspondences; out3 = {RMS of |source_pred_i - target_pred_nn(i)| over
+ * them (inf if none), their number, number / n_source} (device, 3 floats). */
+size_t rap_nn_metrics_workspace_bytes(int64_t n_points, int32_t B);
+int rap_chamfer_rmse(const float* pointclouds_gt, const float* pointclouds_pred, const int32_t* cu_batch, int32_t B, int64_t TP,
+                     float* out, void* ws, size_t ws_bytes, void* stream);
+int rap_correspondence_rmse(const float* source_gt, const float* target_gt, const float* source_pred, const float* target_pred,
+                            int32_t n_source, int32_t n_target, float distance_threshold, float* out3, void* ws, size_t ws_bytes,
+                            void* stream);
+
 /* ---- MiniSpinNet local feature extractor (the step before the path) ----
  * Replaces MiniSpinNet.forward (reference dataset_process/utils/spinnet/patch_embedder.py:49-183 with patchnet.py:16-84 and
  * utils/common.py) as extract_sample_features.py:151-220 / demo.py:959-988 call it: global-z alignment, 512 points per patch,

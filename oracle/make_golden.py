@@ -143,6 +143,30 @@ def make_spinnet_golden():
     print("spinnet_k16", os.path.getsize(path) // 1024, "KiB; points per ball:", counts.tolist())
 
 
+def make_nn_metrics_golden():
+    """Nearest-neighbour metrics: the reference's own compute_correspondence_rmse on a scan pair
+    (overlapping views of one surface, a slightly wrong predicted pose); chamfer RMSE from the oracle restatement (pytorch3d's
+    chamfer_distance is absent) on a 3-object batch."""
+    g = torch.Generator().manual_seed(17)
+    surf = torch.rand(6000, 3, generator=g); surf[:, 2] = 0.25 * torch.cos(3 * surf[:, 1])
+    sg = surf[torch.randint(0, 6000, (900,), generator=g)] + 0.003 * torch.randn(900, 3, generator=g)
+    tg = surf[torch.randint(0, 6000, (1100,), generator=g)] + 0.003 * torch.randn(1100, 3, generator=g)
+    sp = sg + torch.tensor([0.01, -0.02, 0.005]); tp = tg + 0.002 * torch.randn(1100, 3, generator=g)
+    ref = ref_loader.load_reference()
+    out = {"source_gt": sg.numpy(), "target_gt": tg.numpy(), "source_pred": sp.numpy(), "target_pred": tp.numpy()}
+    for thr in (0.02, 0.05):
+        rmse, n, ratio = ref.compute_correspondence_rmse(sg, tg, sp, tp, distance_threshold=thr)
+        out[f"corr_{thr}"] = np.array([float(rmse), n, ratio])
+    rmse0, n0, r0 = ref.compute_correspondence_rmse(sg, tg + 10.0, sp, tp, distance_threshold=0.05)
+    out["corr_none"] = np.array([float(rmse0), n0, r0])
+    cu = torch.tensor([0, 700, 1500, 1501])
+    gt = torch.rand(1501, 3, generator=g); pred = gt + 0.01 * torch.randn(1501, 3, generator=g)
+    out.update({"cd_gt": gt.numpy(), "cd_pred": pred.numpy(), "cd_cu": cu.numpy(), "cd": O.compute_cd(gt, pred, cu).numpy()})
+    path = os.path.join(GOLDEN_DIR, "nn_metrics.npz")
+    np.savez_compressed(path, **out)
+    print("nn_metrics", os.path.getsize(path) // 1024, "KiB", out["corr_0.02"], out["corr_0.05"], out["corr_none"], out["cd"])
+
+
 def make_transform_golden():
     """Output transform files: the reference's own Evaluator._save_transformation_files on a
     3-object batch (trailing empty part, random GT poses / scales / global frames), with and without the global frame;
@@ -185,3 +209,5 @@ if __name__ == "__main__":
         make_overlap_golden()
     if not only or "--spinnet-only" in only:
         make_spinnet_golden()
+    if not only or "--nn-only" in only:
+        make_nn_metrics_golden()

@@ -400,6 +400,30 @@ def compute_overlap_ratio(pred, points_per_part, cu_seqlens_batch, taus=(0.005, 
     return ratios, min_d
 
 
+def compute_cd(gt, pred, cu_seqlens_batch):
+    """eval/metrics.py:14-48.  pytorch3d 0.7.8 chamfer_distance(x, y, single_directional=False, norm=2, point_reduction="mean")
+    is absent: its documented result is mean_i min_j |x_i - y_j|^2 + mean_j min_i |y_j - x_i|^2 (parity unpinned for that call);
+    the reference then takes sqrt(0.5 * cd).  fp64 pairwise distances."""
+    out = []
+    for a, e in zip(cu_seqlens_batch[:-1].tolist(), cu_seqlens_batch[1:].tolist()):
+        d = torch.cdist(gt[a:e].double(), pred[a:e].double(), p=2, compute_mode="donot_use_mm_for_euclid_dist") ** 2
+        cd = d.min(dim=1).values.mean() + d.min(dim=0).values.mean()
+        out.append((0.5 * cd).sqrt())
+    return torch.stack(out)
+
+
+def compute_correspondence_rmse(source_gt, target_gt, source_pred, target_pred, distance_threshold=0.1):
+    """eval/metrics.py:386-469 with fp64 distances -> (rmse, num_correspondences, ratio, nearest indices)"""
+    d = torch.cdist(source_gt.double(), target_gt.double(), p=2, compute_mode="donot_use_mm_for_euclid_dist")
+    mind, nn = d.min(dim=1)
+    valid = mind <= distance_threshold
+    n = int(valid.sum())
+    if n == 0:
+        return torch.tensor(float("inf")), 0, 0.0, nn
+    se = ((source_pred[valid].double() - target_pred[nn[valid]].double()) ** 2).sum(dim=1)
+    return torch.sqrt(se.mean()), n, n / source_gt.shape[0], nn
+
+
 # ---------------------------------------------------------------------------------------------
 # output transforms (SURVEY.md section 8f row 3)
 # ---------------------------------------------------------------------------------------------

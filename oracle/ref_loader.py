@@ -281,6 +281,7 @@ def load_reference():
     ns.metrics = importlib.import_module("rectified_point_flow.eval.metrics")
     ns.compute_rigidity_rmse = ns.metrics.compute_rigidity_rmse
     ns.compute_overlap_ratio = ns.metrics.compute_overlap_ratio
+    ns.compute_correspondence_rmse = ns.metrics.compute_correspondence_rmse
     _LOADED = ns
     return ns
 

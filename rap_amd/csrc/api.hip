@@ -1006,3 +1006,39 @@ extern "C" int rap_spinnet_describe(const rap_spinnet* m, const float* pts, cons
   }
   return RAP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// nearest-neighbour registration metrics
+// ---------------------------------------------------------------------------------------------
+struct NnWs { float* d2a; float* d2b; int32_t* nn; NnWork* items; size_t total; };
+static NnWs carve_nn(int64_t n, int B, char* basep) {
+  NnWs w; size_t off = 0;
+  auto take = [&](size_t bytes) { char* r = basep ? basep + off : nullptr; off += align_up(bytes, 256); return r; };
+  w.d2a = (float*)take((size_t)n * 4);
+  w.d2b = (float*)take((size_t)n * 4);
+  w.nn = (int32_t*)take((size_t)n * 4);
+  w.items = (NnWork*)take(nn_max_items((long)n, B) * sizeof(NnWork));
+  w.total = off;
+  return w;
+}
+extern "C" size_t rap_nn_metrics_workspace_bytes(int64_t n_points, int32_t B) {
+  return (n_points < 0 || B < 0) ? 0 : carve_nn(n_points, B, nullptr).total;
+}
+extern "C" int rap_chamfer_rmse(const float* pointclouds_gt, const float* pointclouds_pred, const int32_t* cu_batch, int32_t B,
+                                int64_t TP, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!pointclouds_gt || !pointclouds_pred || !cu_batch || !out || B <= 0 || TP <= 0 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  NnWs w = carve_nn(TP, B, (char*)ws);
+  if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  return launch_chamfer_rmse((hipStream_t)stream, pointclouds_gt, pointclouds_pred, cu_batch, B, (long)TP, out, w.d2a, w.d2b, w.items);
+}
+extern "C" int rap_correspondence_rmse(const float* source_gt, const float* target_gt, const float* source_pred,
+                                       const float* target_pred, int32_t n_source, int32_t n_target, float distance_threshold,
+                                       float* out3, void* ws, size_t ws_bytes, void* stream) {
+  if (!source_gt || !target_gt || !source_pred || !target_pred || !out3 || n_source <= 0 || n_target <= 0) return RAP_ERR_INVALID;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  NnWs w = carve_nn(n_source, 1, (char*)ws);
+  if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  return launch_correspondence_rmse((hipStream_t)stream, source_gt, target_gt, source_pred, target_pred, n_source, n_target,
+                                    distance_threshold, out3, w.d2a, w.nn, w.items);
+}

@@ -152,3 +152,11 @@ int launch_spin_patch(hipStream_t stream, const float* pts, const int32_t* perm,
 int launch_spin_im2col3d(hipStream_t stream, const float* x0, int K, float* A, int ldA);
 int launch_spin_im2col2d(hipStream_t stream, const float* y, int ldy, int Cin, int K, float* A);
 int launch_spin_pool(hipStream_t stream, const float* x, int ldx, int K, const void* d_pool_w, float* desc);
+
+// nearest-neighbour metrics (nn_metrics.hip; reference eval/metrics.py:14-48, 386-469)
+struct NnWork { int x_start, x_len, q0, y_start, y_len, pad0, pad1, pad2; };
+size_t nn_max_items(long n, int B);
+int launch_chamfer_rmse(hipStream_t stream, const float* gt, const float* pred, const int32_t* cu_batch, int B, long TP, float* out,
+                        float* d2a, float* d2b, NnWork* items);
+int launch_correspondence_rmse(hipStream_t stream, const float* source_gt, const float* target_gt, const float* source_pred,
+                               const float* target_pred, int Ns, int Nt, float thr, float* out3, float* d2, int32_t* nn, NnWork* items);

@@ -241,3 +241,17 @@ def test_spinnet_oracle_matches_live_reference():
     out = SO.forward(sd, pts, kpts, 0.6, torch.as_tensor(ref["perm"]))
     assert (out["patches"] - ref["patches"]).abs().max().item() == 0.0
     assert (out["desc"] - ref["desc"]).abs().max().item() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# nearest-neighbour metrics
+# ---------------------------------------------------------------------------------------------
+def test_oracle_correspondence_rmse_matches_reference_golden():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nn_metrics.npz"))
+    T = lambda k: torch.from_numpy(z[k])
+    for thr in (0.02, 0.05):
+        rmse, n, ratio, _ = O.compute_correspondence_rmse(T("source_gt"), T("target_gt"), T("source_pred"), T("target_pred"), thr)
+        ref = z[f"corr_{thr}"]
+        assert abs(n - ref[1]) <= 1 and abs(float(rmse) - ref[0]) < 1e-4 * ref[0] + 1e-6       # fp32 cdist vs fp64 at the threshold
+    rmse, n, ratio, _ = O.compute_correspondence_rmse(T("source_gt"), T("target_gt") + 10.0, T("source_pred"), T("target_pred"), 0.05)
+    assert n == 0 and np.isinf(float(rmse)) and np.isinf(z["corr_none"][0])

@@ -317,3 +317,45 @@ def test_overlap_ratio_full_geometry_properties_and_selection(dev):
     assert best.tolist() == [1, 0, 0, 0]                          # argmax; ties -> first
     assert torch.equal(cloud[: 2 * N], mixed[: 2 * N]) and torch.equal(cloud[2 * N:], far[2 * N:])
     assert Rs[0].min().item() == 1.0 and Rs[1:].abs().max().item() == 0.0 and ts[0].min().item() == 2.0
+
+
+# ---------------------------------------------------------------------------------------------
+# nearest-neighbour metrics
+# ---------------------------------------------------------------------------------------------
+def test_chamfer_and_correspondence_rmse_match_golden_and_oracle(dev):
+    import numpy as np
+    import os
+    from rap_amd.metrics import compute_cd, compute_correspondence_rmse
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nn_metrics.npz"))
+    T = lambda k: torch.from_numpy(z[k])
+    # correspondence RMSE vs the reference's own function (fixture) and the fp64 oracle
+    sg, tg, sp, tp = (T(k).to(dev) for k in ("source_gt", "target_gt", "source_pred", "target_pred"))
+    for thr in (0.02, 0.05):
+        rmse, n, ratio = compute_correspondence_rmse(sg, tg, sp, tp, distance_threshold=thr)
+        o_rmse, o_n, o_ratio, _ = O.compute_correspondence_rmse(T("source_gt"), T("target_gt"), T("source_pred"), T("target_pred"), thr)
+        assert n == o_n and abs(float(rmse) - float(o_rmse)) < 2e-6 * float(o_rmse) + 1e-7, (thr, n, o_n)
+        ref = z[f"corr_{thr}"]
+        assert abs(n - ref[1]) <= 1 and abs(float(rmse) - ref[0]) < 1e-4 * ref[0] + 1e-6 and abs(ratio - ref[2]) < 2e-3
+    rmse, n, ratio = compute_correspondence_rmse(sg, tg + 10.0, sp, tp, distance_threshold=0.05)
+    assert n == 0 and ratio == 0.0 and torch.isinf(rmse)
+    with pytest.raises(ValueError):
+        compute_correspondence_rmse(sg, tg, sp[:-1], tp)
+    # chamfer RMSE per object (incl. a 1-point object) vs the oracle restatement
+    cd = compute_cd(T("cd_gt").to(dev), T("cd_pred").to(dev), T("cd_cu"))
+    assert (cd.cpu().double() - torch.from_numpy(z["cd"])).abs().max().item() < 2e-6
+
+
+def test_chamfer_full_geometry_properties(dev):
+    """BASELINE geometry (8 objects x 8192 points): identical clouds -> 0; a pure shuffle of the points -> 0 (set distance);
+    a rigid shift by d of a cloud whose spacing is >> d -> exactly d."""
+    from rap_amd.metrics import compute_cd
+    g = torch.Generator().manual_seed(4)
+    B, N = 8, 8192
+    grid = torch.stack(torch.meshgrid(torch.arange(32.), torch.arange(16.), torch.arange(16.), indexing="ij"), -1).reshape(-1, 3)
+    gt = torch.cat([grid + b for b in range(B)]).to(dev)
+    cu = torch.arange(0, B * N + 1, N)
+    assert compute_cd(gt, gt.clone(), cu).abs().max().item() == 0.0
+    perm = torch.cat([torch.randperm(N, generator=g) + b * N for b in range(B)]).to(dev)
+    assert compute_cd(gt, gt[perm], cu).abs().max().item() == 0.0
+    shifted = gt + torch.tensor([0.25, 0.0, 0.0], device=dev)
+    assert (compute_cd(gt, shifted, cu) - 0.25).abs().max().item() < 1e-6
