@@ -162,10 +162,14 @@ def main():
         if profile:
             lib.rap_profile_reset(); lib.rap_profile_enable(1)
         t0 = time.perf_counter()
+        enqueue = 0.0
         for _ in range(steps):
+            te = time.perf_counter()
             gathered, last = one_step()
+            enqueue += time.perf_counter() - te      # host time to ENQUEUE one sample call (nothing in it synchronises)
         barrier()
         elapsed = time.perf_counter() - t0
+        run_mode.host_enqueue_ms = 1e3 * enqueue / steps
         prof_ms = (ctypes.c_float * 3)(); prof_n = (ctypes.c_int64 * 3)()
         if profile:
             lib.rap_profile_enable(0)
@@ -205,6 +209,7 @@ def main():
         }
 
     elapsed, prof, last = run_mode(args.dtype, args.steps, args.warmup)
+    host_enqueue_ms = run_mode.host_enqueue_ms
     secondary = None
     if args.dtype == "float32" and not args.no_secondary:
         # the same workload with bf16 MFMA blocks (BASELINE configs[2]'s per-GPU shard), reported beside the fp32 headline
@@ -212,6 +217,7 @@ def main():
         a, b = l2["end_point_trajectory"][-1], last["end_point_trajectory"][-1]
         secondary = {
             "dtype": "bf16", "value": pts_per_rank * world * args.steps / e2, "unit": "points/s", "ms_per_step": 1e3 * e2 / args.steps,
+            "host_enqueue_ms_per_step": run_mode.host_enqueue_ms,
             "workload": "same batch, bf16 MFMA transformer blocks (fp32 accumulate / residual / LN / softmax / head)",
             "roofline": roofline_of("bfloat16", p2, e2),
             "deviation_from_fp32_path": {"final_cloud_max_abs": float((a - b).abs().max()),
@@ -236,6 +242,7 @@ def main():
                        "flow_steps": args.flow_steps, "num_layers": args.layers, "rigidity_forcing": bool(args.rigidity),
                        "sharding": f"independent pairs, {world} rank(s), one RCCL all-gather of clouds+poses per step"},
         }
+        result["host_enqueue_ms_per_step"] = host_enqueue_ms      # ~3 300 launches of one sample call; the GPU time is ms_per_step
         roof = roofline_of(args.dtype, prof, elapsed)
         if roof:
             result["roofline"] = roof

@@ -359,3 +359,21 @@ def test_chamfer_full_geometry_properties(dev):
     assert compute_cd(gt, gt[perm], cu).abs().max().item() == 0.0
     shifted = gt + torch.tensor([0.25, 0.0, 0.0], device=dev)
     assert (compute_cd(gt, shifted, cu) - 0.25).abs().max().item() < 1e-6
+
+
+def test_config0_demo_pair_full_run_matches_oracle(dev):
+    """BASELINE configs[0] in full: one pair, 2 views x 1024 points, rap_12, all 10 Euler steps with the reference's default
+    rigidity forcing, against the CPU oracle (the reference's own CPU-runnable case; ~30 s of host time)."""
+    cfg, sd, model = get_model(12, 0, dev)
+    inp = S.make_uniform_inputs(1, 2, 1024, seed=2024)
+    steps = 10
+    ref = O.sample(sd, cfg, inp, steps, True)
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=steps, rigidity_forcing=True)
+    out = flow.sample_and_register(to_dev(inp, dev), x_1=inp["x_1"].to(dev))
+    e0 = (out["end_point_trajectory"].cpu() - ref["end_point_trajectory"]).abs().max().item()
+    e1 = (out["trajectory"].cpu() - ref["trajectory"]).abs().max().item()
+    eR = torch.linalg.matrix_norm(out["R"].cpu() - ref["R"]).max().item()
+    et = (out["t"].cpu() - ref["t"]).abs().max().item()
+    print(f"configs[0] full run: x0 {e0:.2e} xt {e1:.2e} |dR|_F {eR:.2e} dt {et:.2e}")
+    assert e0 <= 5e-4 and e1 <= 5e-4 and eR <= 1e-3 and et <= 1e-3, (e0, e1, eR, et)          # the stated tolerance
+    assert e0 < 5e-5 and e1 < 5e-5 and eR < 5e-5 and et < 5e-5, (e0, e1, eR, et)              # what exact fp32 achieves
