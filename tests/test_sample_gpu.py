@@ -377,3 +377,23 @@ def test_config0_demo_pair_full_run_matches_oracle(dev):
     print(f"configs[0] full run: x0 {e0:.2e} xt {e1:.2e} |dR|_F {eR:.2e} dt {et:.2e}")
     assert e0 <= 5e-4 and e1 <= 5e-4 and eR <= 1e-3 and et <= 1e-3, (e0, e1, eR, et)          # the stated tolerance
     assert e0 < 5e-5 and e1 < 5e-5 and eR < 5e-5 and et < 5e-5, (e0, e1, eR, et)              # what exact fp32 achieves
+
+
+def test_large_qk_gains_fall_back_to_the_online_softmax(dev):
+    """The bounded-softmax kernels are used only when every logit bound 8 max|gamma_q| max|gamma_k| is <= 40; a checkpoint with
+    larger qk-norm gains must take the online-softmax instantiation and still match the oracle (logits up to ~128 here)."""
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    sd = S.make_weights(cfg, 6)
+    for k in list(sd):
+        if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma"):
+            sd[k] = sd[k] * 3.0                      # bounds up to 8 * 4.5 * 4.5 = 162 > 40
+    inp = S.make_inputs([[130, 77], [64, 200, 33]], seed=15)
+    ref = O.sample(sd, cfg, inp, 3, True)
+    for cdt, tol in (("float32", 2e-4), ("bfloat16", 5e-2)):
+        m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=2, num_heads=8, local_feat_dim=32, compute_dtype=cdt)
+        m.load_state_dict(sd); m.to(dev)
+        flow = rap_amd.RectifiedPointFlow(flow_model=m, inference_sampling_steps=3, rigidity_forcing=True)
+        out = flow.sample_and_register(to_dev(inp, dev), x_1=inp["x_1"].to(dev))
+        err = (out["end_point_trajectory"].cpu() - ref["end_point_trajectory"]).abs().max().item()
+        print(f"large-gain fallback {cdt}: x0 err {err:.2e}")
+        assert torch.isfinite(out["end_point_trajectory"]).all() and err < tol, (cdt, err)
