@@ -118,13 +118,11 @@ static bool desc_ok(const rap_model_desc* d) {
 extern int g_rap_gemm_variant;   // gemm_f32.hip
 extern int g_rap_attn_variant;   // attn_f32.hip
 extern int g_rap_gemm_h16_variant;   // gemm_h16.hip
-static int g_rap_gemm_h16_ablate = 0;   // rap_set_tuning key 4: timing-only ablations of rap_gemm_h16
 extern int g_rap_attn_h16_variant;   // attn_h16.hip
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16)) { g_rap_gemm_variant = value; return RAP_OK; }
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
   if (key == 2 && value >= 0 && value <= 4) { g_rap_gemm_h16_variant = value; return RAP_OK; }
-  if (key == 4 && value >= 0 && value <= 3) { g_rap_gemm_h16_ablate = value; return RAP_OK; }
   if (key == 3 && value >= 0 && value <= 11) { g_rap_attn_h16_variant = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
@@ -718,7 +716,6 @@ extern "C" int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, 
   GemmParamsH g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias;
   g.resid = resid; g.ldr = ldr; g.heads = heads; g.vt = vt; g.vt_nblk = vt_nblk;
-  g.ablate = g_rap_gemm_h16_ablate;
   return launch_gemm_h16((hipStream_t)stream, dtype, epilogue, g);
 }
 extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk,

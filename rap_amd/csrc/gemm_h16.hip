@@ -249,7 +249,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
       f.b[j] = *reinterpret_cast<const uint4*>(smem + 2 * ABYTES + buf * BBYTES + b_row + j * 32 * 128 + co);
   };
   auto mma = [&](const Frag& f) {
-    if (p.ablate & 2) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
   int kt = 0;
   for (; kt + 1 < nk; ++kt) {
     const int cur = kt & 1;
-    if (!(p.ablate & 1)) { HG_DMA(kt + 1, cur ^ 1) }   // spare buffer: every wave finished reading it before the last barrier
+    HG_DMA(kt + 1, cur ^ 1)                 // spare buffer: every wave finished reading it before the last barrier
     read_frag(f1, cur, 1);
     HG_FENCE
     mma(f0);
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
 // Two hypotheses about the two-stage kernel's 28 % of peak on the K = 512 shapes, both measured and rejected on MI355X
 // (profiles/r01_run24-27_gemm_h16_experiments.jsonl): (a) "one 64 KB transfer in flight per CU cannot hide the LDS-DMA latency"
 // -- three slices in flight: 676 vs 727 TF on the qkv shape; (b) "with one block per CU the store-bound epilogue (0.25 of the
-// 0.6 ms: ablation with neither DMA nor MFMA) never overlaps a k-loop" -- two blocks per CU: 642 TF (50 % more operand traffic
+// 0.6 ms: a timing-only build with neither DMA nor MFMA, since removed) never overlaps a k-loop" -- two blocks per CU: 642 TF (50 % more operand traffic
 // at the smaller tile eats the overlap).  PMC on the default kernel: waves spend 37 % parked on s_waitcnt / barriers, 42 % on
 // MFMA issue stalls, LDS bank conflicts 2 %.  Kept selectable, tested, as the A/B evidence.  64-byte LDS rows: bank conflicts of
 // the fragment reads are removed by slot' = slot ^ ((row >> 2) & 3), applied to the DMA source address and the ds_read_b128 address.

@@ -105,7 +105,6 @@ struct GemmParamsH {
   const float* resid; int ldr;
   int heads;
   uint16_t* vt; int vt_nblk;
-  int ablate;   // timing-only (scripts/kernel_bench.py): bit 0 = no operand streaming after the first k-tile, bit 1 = no MFMAs
 };
 int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p);
 int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t* dst, size_t n);

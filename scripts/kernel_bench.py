@@ -41,8 +41,6 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
         assert lib.rap_set_tuning(2, args.h16_gemm_variant) == 0
     if args.h16_attn_variant >= 0:
         assert lib.rap_set_tuning(3, args.h16_attn_variant) == 0
-    if args.h16_gemm_ablate:
-        assert lib.rap_set_tuning(4, args.h16_gemm_ablate) == 0
     nblk = (TP + 255) // 256 * 256 // 64
 
     def gemm_case(name, epi, N, K, out_half, Cw=None, heads=0):
@@ -59,7 +57,7 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
             assert rc == 0, rc
         t = timeit(fn)
         fl = 2.0 * TP * N * K
-        rows.append({"kernel": f"gemm_h16[{name}]", "dtype": args.dtype, "variant": args.h16_gemm_variant, "ablate": args.h16_gemm_ablate, "M": TP, "N": N, "K": K,
+        rows.append({"kernel": f"gemm_h16[{name}]", "dtype": args.dtype, "variant": args.h16_gemm_variant, "M": TP, "N": N, "K": K,
                      "ms": t * 1e3, "tflops": fl / t / 1e12, "frac_of_2500TF": fl / t / 1e12 / PEAK})
 
     if args.only in ("", "gemm"):
@@ -114,7 +112,6 @@ def main():
     ap.add_argument("--dtype", default="float32", help="float32 | bfloat16 | float16 (16-bit: GEMM / attention / LN / qknorm twins)")
     ap.add_argument("--h16-gemm-variant", type=int, default=-1)
     ap.add_argument("--h16-attn-variant", type=int, default=-1, help="timing-only ablations of the 16-bit attention kernel")
-    ap.add_argument("--h16-gemm-ablate", type=int, default=0, help="timing-only: 1 no operand streaming, 2 no MFMAs, 3 both")
     ap.add_argument("--bounded", type=int, default=1, help="pass per-head logit bounds to the 16-bit attention (bounded-softmax v2, bf16)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
