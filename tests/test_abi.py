@@ -77,3 +77,29 @@ def test_product_does_not_import_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "oracle/" not in text or f == "synthetic.py", f
+
+
+def test_new_entry_points_validate_arguments_without_a_gpu():
+    """Every caller-side entry point rejects NULL / non-positive arguments with RAP_ERR_INVALID (-1) before touching the device,
+    and the workspace queries are pure host arithmetic."""
+    import ctypes
+    from rap_amd import _lib
+    lib = _lib.load()
+    N = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(1)      # non-NULL sentinel; the calls below must fail on another argument first
+    assert lib.rap_rigidity_rmse(N, N, N, N, N, 1, 1, N, 0, N, N, 0, N) == -1
+    assert lib.rap_trajectory_rigidity_rmse(N, N, N, 1, 1, 10, 2, N, N, N, N, 0, N) == -1
+    assert lib.rap_select_generation(N, 1, 1, 1, 1, N, N, N, N, 0, N, N, N, N, N) == -1
+    assert lib.rap_overlap_ratio(N, N, N, 1, 1, 10, N, 1, N, N, N, 0, N) == -1
+    assert lib.rap_relative_transforms(N, N, N, N, N, N, 1, 1, N, N, N, N) == -1
+    assert lib.rap_chamfer_rmse(N, N, N, 1, 10, N, N, 0, N) == -1
+    assert lib.rap_correspondence_rmse(N, N, N, N, 1, 1, 0.1, N, N, 0, N) == -1
+    assert lib.rap_spinnet_describe(N, N, N, 10, N, 1, 0.5, N, 16, N, 0, N) == -1
+    assert lib.rap_spinnet_create(N, 0, N, ctypes.byref(ctypes.c_void_p(0))) == -1
+    assert lib.rap_model_set_compute_dtype(N, 1, N) == -1
+    assert lib.rap_spinnet_weight_count() == 426341
+    assert lib.rap_rigidity_workspace_bytes(64, 20, 32) > 0 and lib.rap_rigidity_workspace_bytes(-1, 0, 0) == 0
+    assert lib.rap_overlap_workspace_bytes(262144, 32, 2) > 262144 * 8
+    assert lib.rap_nn_metrics_workspace_bytes(262144, 32) > 262144 * 12
+    assert lib.rap_spinnet_workspace_bytes(2048) > 2048 * 140 * 1152 * 4 and lib.rap_spinnet_workspace_bytes(0) == 0
+    del one

@@ -87,3 +87,25 @@ def test_weights_are_a_pure_function_of_name_and_seed():
     c = S.make_weights(cfg, 1)
     assert not torch.equal(a["final_mlp.4.weight"], c["final_mlp.4.weight"])
     assert [n for n, _ in S.weight_spec(cfg)] == list(a.keys())
+
+
+def test_checkpoint_loader_edits_keys_like_the_reference(tmp_path):
+    """utils/checkpoint.py:13-61: keep + strip `prefix_to_remove`, substitute, add, then load_state_dict(strict)."""
+    import torch
+    from rap_amd.checkpoint import load_checkpoint_for_module, load_spinnet_checkpoint
+
+    class Sink:
+        def load_state_dict(self, sd, strict=True):
+            self.sd, self.strict = sd, strict
+            return "ok"
+
+    ck = {"state_dict": {"flow_model.a.weight": torch.ones(2), "flow_model.b.bias": torch.zeros(1), "encoder.x": torch.ones(1)}}
+    torch.save(ck, tmp_path / "m.ckpt")
+    s = Sink()
+    assert load_checkpoint_for_module(s, str(tmp_path / "m.ckpt"), prefix_to_remove="flow_model.") == "ok"
+    assert sorted(s.sd) == ["a.weight", "b.bias"] and s.strict is False
+    load_checkpoint_for_module(s, str(tmp_path / "m.ckpt"), keys_to_substitute={"encoder.": "feat."}, prefix_to_add="p.", strict=True)
+    assert "p.feat.x" in s.sd and "p.flow_model.a.weight" in s.sd and s.strict is True
+    torch.save({"Desc.pnt_layer.0.weight": torch.ones(1), "Other.k": torch.ones(1)}, tmp_path / "d.pth")
+    load_spinnet_checkpoint(s, str(tmp_path / "d.pth"))
+    assert list(s.sd) == ["pnt_layer.0.weight"] and s.strict is False
