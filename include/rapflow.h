@@ -177,6 +177,16 @@ size_t rap_spinnet_workspace_bytes(int32_t keypoints_per_chunk);
 int rap_spinnet_describe(const rap_spinnet* m, const float* pts, const int32_t* perm, int64_t N, const float* kpts, int32_t K,
                          float des_r, float* desc_out, int32_t keypoints_per_chunk, void* ws, size_t ws_bytes, void* stream);
 
+/* Farthest point sampling, the keypoint selection in front of MiniSpinNet (reference dataset_process/utils/
+ * point_sampling_utils.py:263-305 -> pytorch3d.ops.sample_farthest_points with lengths, per-cloud K and a random start):
+ * points (T,3) holds the clouds: cloud c = rows [cloud_start[c], cloud_start[c] + cloud_len[c]) (packed or zero-padded batches
+ * alike); k_per_cloud / start_idx (n_clouds,) int32 (the caller draws the start indices, as pytorch3d does with torch.randint);
+ * indices_out (n_clouds, k_max) int32, cloud-local, -1 padded past min(K, length); dist_ws: T floats of scratch.  Ties go to the
+ * lowest index (torch.argmax). */
+int rap_farthest_point_sampling(const float* points, const int32_t* cloud_start, const int32_t* cloud_len, const int32_t* k_per_cloud,
+                                const int32_t* start_idx, int32_t n_clouds, int32_t k_max, int32_t* indices_out, float* dist_ws,
+                                void* stream);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels the calls above launch) ---- */
 /* C(M,N) = A(M,K) W(N,K)^T (+bias) (+resid) ; epilogue: 0 bias, 1 bias+resid, 2 bias+SiLU,
  * 3 GEGLU (W/bias must be value/gate interleaved by rap_geglu_interleave; C is (M,N/2)),

@@ -424,6 +424,24 @@ def compute_correspondence_rmse(source_gt, target_gt, source_pred, target_pred, 
     return torch.sqrt(se.mean()), n, n / source_gt.shape[0], nn
 
 
+def farthest_point_sampling(points, length, K, start):
+    """pytorch3d 0.7.8 sample_farthest_points for ONE cloud (absent wheel; its published algorithm -- parity unpinned):
+    selected[0] = start; repeat: closest_dists = min(closest_dists, |p - p_last|^2); next = argmax (first maximum).
+    points (P,3) -> idx (min(K, length),) long.  fp32 distances like the kernel and pytorch3d."""
+    p = points[:length].float()
+    K = min(int(K), int(length))
+    idx = torch.empty(K, dtype=torch.long)
+    d = torch.full((length,), float("inf"))
+    last = int(start)
+    idx[0] = last
+    for k in range(1, K):
+        diff = p - p[last]
+        d = torch.minimum(d, (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2])
+        last = int(torch.argmax(d))
+        idx[k] = last
+    return idx
+
+
 # ---------------------------------------------------------------------------------------------
 # output transforms (SURVEY.md section 8f row 3)
 # ---------------------------------------------------------------------------------------------

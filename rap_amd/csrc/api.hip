@@ -1039,3 +1039,11 @@ extern "C" int rap_correspondence_rmse(const float* source_gt, const float* targ
   return launch_correspondence_rmse((hipStream_t)stream, source_gt, target_gt, source_pred, target_pred, n_source, n_target,
                                     distance_threshold, out3, w.d2a, w.nn, w.items);
 }
+
+extern "C" int rap_farthest_point_sampling(const float* points, const int32_t* cloud_start, const int32_t* cloud_len,
+                                           const int32_t* k_per_cloud, const int32_t* start_idx, int32_t n_clouds, int32_t k_max,
+                                           int32_t* indices_out, float* dist_ws, void* stream) {
+  if (!points || !cloud_start || !cloud_len || !k_per_cloud || !start_idx || !indices_out || !dist_ws || n_clouds <= 0 || k_max <= 0)
+    return RAP_ERR_INVALID;
+  return launch_fps((hipStream_t)stream, points, cloud_start, cloud_len, k_per_cloud, start_idx, n_clouds, k_max, dist_ws, indices_out);
+}

@@ -159,3 +159,8 @@ int launch_chamfer_rmse(hipStream_t stream, const float* gt, const float* pred, 
                         float* d2a, float* d2b, NnWork* items);
 int launch_correspondence_rmse(hipStream_t stream, const float* source_gt, const float* target_gt, const float* source_pred,
                                const float* target_pred, int Ns, int Nt, float thr, float* out3, float* d2, int32_t* nn, NnWork* items);
+
+// farthest point sampling (fps.hip; reference dataset_process/utils/point_sampling_utils.py:263-305)
+int launch_fps(hipStream_t stream, const float* pts, const int32_t* cloud_start, const int32_t* cloud_len, const int32_t* Ks,
+               const int32_t* starts, int C, int Kmax,
+               float* dist, int32_t* out);

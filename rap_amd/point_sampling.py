@@ -1,0 +1,52 @@
+"""Host-side mirror of the reference's batched farthest point sampling (preprocessing in front of
+MiniSpinNet): ``apply_batched_fps`` of ``dataset_process/utils/point_sampling_utils.py:263-305``, i.e.
+``pytorch3d.ops.sample_farthest_points(points, lengths=..., K=..., random_start_point=True)`` after ``torch.manual_seed``.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .flow_model import _f32c, _require_cuda
+
+
+def sample_farthest_points(points: torch.Tensor, lengths: torch.Tensor | None = None, K=50, random_start_point: bool = False,
+                           start_idx: torch.Tensor | None = None):
+    """pytorch3d signature: points (N,P,3) zero-padded, lengths (N,), K int or (N,) -> (sampled (N,Kmax,3), idx (N,Kmax) int64),
+    padded with 0 / -1 past min(K_n, length_n).  The random start (one ``torch.randint(high=length_n)`` per cloud, in cloud order,
+    as pytorch3d draws it) can be overridden with ``start_idx``."""
+    _require_cuda(points, "points")
+    device = points.device
+    N, P, _ = points.shape
+    lengths = torch.full((N,), P, dtype=torch.int64) if lengths is None else lengths.to("cpu", torch.int64)
+    Ks = torch.full((N,), int(K), dtype=torch.int64) if isinstance(K, int) else K.to("cpu", torch.int64)
+    Kmax = int(Ks.max())
+    if start_idx is None:
+        if random_start_point:
+            start_idx = torch.tensor([int(torch.randint(high=int(lengths[n]), size=(1,)).item()) for n in range(N)])
+        else:
+            start_idx = torch.zeros(N, dtype=torch.int64)
+    pts = _f32c(points)                                  # padded layout: cloud n occupies rows [n*P, n*P + length_n)
+    i32 = lambda t: t.to(device=device, dtype=torch.int32).contiguous()
+    cloud_start = i32(torch.arange(N, dtype=torch.int64) * P)
+    idx_out = torch.empty((N, Kmax), dtype=torch.int32, device=device)
+    dist = torch.empty((N * P,), dtype=torch.float32, device=device)
+    lib = _lib.load()
+    len_d, k_d, st_d = i32(lengths), i32(Ks), i32(start_idx)      # named: a temporary's memory is recycled by the next allocation
+    with torch.cuda.device(device):
+        rc = lib.rap_farthest_point_sampling(_lib.ptr(pts), _lib.ptr(cloud_start), _lib.ptr(len_d), _lib.ptr(k_d), _lib.ptr(st_d), N,
+                                             Kmax, _lib.ptr(idx_out), _lib.ptr(dist), _lib.current_stream(device))
+    _lib.check(rc, "rap_farthest_point_sampling")
+    idx = idx_out.to(torch.int64)
+    gathered = torch.gather(pts, 1, idx.clamp_min(0)[..., None].expand(-1, -1, 3))         # data movement only
+    sampled = torch.where((idx >= 0)[..., None], gathered, torch.zeros_like(gathered))
+    return sampled, idx
+
+
+def apply_batched_fps(batch_augmented_tensor, batch_lengths_tensor, batch_k_tensor, global_seed: int, device):
+    """point_sampling_utils.py:263-305 -> (list of sampled parts (K_i,3), indices (N,Kmax))."""
+    torch.manual_seed(global_seed)
+    batch = batch_augmented_tensor.contiguous().to(device)
+    _, idx = sample_farthest_points(batch, lengths=batch_lengths_tensor, K=batch_k_tensor, random_start_point=True)
+    parts = [batch[i][idx[i][: int(k)]] for i, k in enumerate(batch_k_tensor)]
+    return parts, idx

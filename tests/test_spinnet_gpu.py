@@ -73,3 +73,34 @@ def test_spinnet_descriptor_is_invariant_to_yaw_about_the_keypoint_frame_origin(
     # points within 1e-6 of a voxel / ball boundary may flip under the fp32 rotation: compare in the bulk
     close = ((d0 - d1).abs().max(dim=1).values < 5e-3).float().mean().item()
     assert close > 0.9, close
+
+
+def test_farthest_point_sampling_matches_oracle(dev):
+    """Batched, ragged FPS (zero-padded batch, per-cloud K, given start indices) vs the sequential oracle; K > length clamps;
+    the index list is a prefix-greedy maximin set (each pick is the farthest remaining point)."""
+    from oracle import rap_oracle as O
+    from rap_amd.point_sampling import apply_batched_fps, sample_farthest_points
+    g = torch.Generator().manual_seed(8)
+    lengths = torch.tensor([3000, 1, 257, 1500])
+    P = int(lengths.max())
+    batch = torch.zeros(4, P, 3)
+    for n, L in enumerate(lengths.tolist()):
+        batch[n, :L] = torch.randn(L, 3, generator=g) * torch.tensor([2.0, 1.0, 0.3])
+    Ks = torch.tensor([64, 5, 300, 200])
+    starts = torch.tensor([17, 0, 256, 3])
+    sampled, idx = sample_farthest_points(batch.to(dev), lengths=lengths, K=Ks, start_idx=starts)
+    assert idx.shape == (4, 300)
+    for n in range(4):
+        ref = O.farthest_point_sampling(batch[n], int(lengths[n]), int(Ks[n]), int(starts[n]))
+        k = ref.numel()
+        assert torch.equal(idx[n, :k].cpu(), ref), n
+        assert (idx[n, k:] == -1).all()
+        assert torch.equal(sampled[n, :k].cpu(), batch[n][ref])
+    # the reference wrapper: seeds torch, draws the starts like pytorch3d (one randint per cloud), returns the sampled parts
+    parts, idx2 = apply_batched_fps(batch, lengths, Ks, global_seed=42, device=dev)
+    torch.manual_seed(42)
+    st = [int(torch.randint(high=int(L), size=(1,)).item()) for L in lengths.tolist()]
+    for n in range(4):
+        ref = O.farthest_point_sampling(batch[n], int(lengths[n]), int(Ks[n]), st[n])
+        assert torch.equal(idx2[n, :ref.numel()].cpu(), ref)
+        assert parts[n].shape[0] == int(Ks[n]) or int(Ks[n]) > int(lengths[n])
