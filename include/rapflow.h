@@ -187,6 +187,20 @@ int rap_farthest_point_sampling(const float* points, const int32_t* cloud_start,
                                 const int32_t* start_idx, int32_t n_clouds, int32_t k_max, int32_t* indices_out, float* dist_ws,
                                 void* stream);
 
+/* Voxel down-sampling, the first preprocessing step of the same script (reference dataset_process/utils/dataset_utils.py:279-322,
+ * voxel_down_sample_torch): per occupied voxel the point closest to the voxel centre (distance quantised to 1000 levels, ties to the
+ * lowest index), indices returned in ascending voxel-key order.  Two steps because the dense key table is sized from the data:
+ *   rap_voxel_bounds    -> bounds6_out (device, 6 int64: per-axis min then max of floor(p / voxel_size)), dist_max_out (device float);
+ *   the caller copies both to the host (the reference synchronises at the same point), then
+ *   rap_voxel_downsample(points, N, voxel_size, h_bounds6 (HOST), dist_max, indices_out (device, >= min(N, slots) int64),
+ *                        count_out (device int32: number of kept points), ws >= rap_voxel_workspace_bytes(h_bounds6)).
+ * rap_voxel_table_slots returns the table size (8 bytes per slot), or -1 when the grid needs more than 2^33 slots. */
+int rap_voxel_bounds(const float* points, int64_t N, float voxel_size, int64_t* bounds6_out, float* dist_max_out, void* stream);
+int64_t rap_voxel_table_slots(const int64_t* h_bounds6);
+size_t rap_voxel_workspace_bytes(const int64_t* h_bounds6);
+int rap_voxel_downsample(const float* points, int64_t N, float voxel_size, const int64_t* h_bounds6, float dist_max,
+                         int64_t* indices_out, int32_t* count_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels the calls above launch) ---- */
 /* C(M,N) = A(M,K) W(N,K)^T (+bias) (+resid) ; epilogue: 0 bias, 1 bias+resid, 2 bias+SiLU,
  * 3 GEGLU (W/bias must be value/gate interleaved by rap_geglu_interleave; C is (M,N/2)),

@@ -167,6 +167,21 @@ def make_nn_metrics_golden():
     print("nn_metrics", os.path.getsize(path) // 1024, "KiB", out["corr_0.02"], out["corr_0.05"], out["corr_none"], out["cd"])
 
 
+def make_voxel_golden():
+    """Voxel down-sampling (preprocessing): the reference's own voxel_down_sample_torch on a
+    40k-point scan-like cloud (negative coordinates, anisotropic extent) at two voxel sizes; the fixture keeps the seed, not the
+    points (regenerated by the test with the same generator calls)."""
+    du = ref_loader.load_reference_dataset_utils()
+    g = torch.Generator().manual_seed(23)
+    p = (torch.rand(40000, 3, generator=g) - 0.4) * torch.tensor([30.0, 22.0, 4.0])
+    out = {"seed": np.int64(23), "n": np.int64(40000), "scale": np.array([30.0, 22.0, 4.0], np.float32)}
+    for vs in (0.25, 1.0):
+        out[f"idx_{vs}"] = du.voxel_down_sample_torch(p, vs).numpy()
+    path = os.path.join(GOLDEN_DIR, "voxel_downsample.npz")
+    np.savez_compressed(path, **out)
+    print("voxel_downsample", os.path.getsize(path) // 1024, "KiB", {k: v.shape for k, v in out.items() if k.startswith("idx")})
+
+
 def make_transform_golden():
     """Output transform files: the reference's own Evaluator._save_transformation_files on a
     3-object batch (trailing empty part, random GT poses / scales / global frames), with and without the global frame;
@@ -211,3 +226,5 @@ if __name__ == "__main__":
         make_spinnet_golden()
     if not only or "--nn-only" in only:
         make_nn_metrics_golden()
+    if not only or "--voxel-only" in only:
+        make_voxel_golden()

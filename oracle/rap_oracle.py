@@ -472,3 +472,29 @@ def rotation_error_deg(R_a: torch.Tensor, R_b: torch.Tensor) -> torch.Tensor:
     """acos((trace(R_a^T R_b) - 1) / 2) in degrees, clamped (metrics.py:289-291)."""
     tr = torch.einsum("...ij,...ij->...", R_a, R_b)
     return torch.rad2deg(torch.acos(((tr - 1) / 2).clamp(-1, 1)))
+
+
+def voxel_down_sample(points, voxel_size):
+    """dataset_process/utils/dataset_utils.py:279-322 (voxel_down_sample_torch) restated with explicit loops over voxels:
+    per occupied voxel (key = gx + gy v + gz v^2, v = largest grid coordinate -- :301-303, wrap-around collisions included) the
+    point with the smallest (quantised centre distance, index) pair (:296-299, :306-316), in ascending key order (:305).
+    fp32 arithmetic in the reference's order."""
+    import numpy as np
+    p = np.asarray(points, dtype=np.float32)
+    vs = np.float32(voxel_size)
+    grid = np.floor(p / vs)                                              # :294
+    center = (grid + np.float32(0.5)) * vs                               # :295
+    d = p - center
+    sq = d * d
+    dist = np.sqrt((sq[:, 0] + sq[:, 1]) + sq[:, 2])                     # :296
+    level = (dist / dist.max() * np.float32(999)).astype(np.int64)       # :297-299
+    g = grid.astype(np.int64)
+    g = g - g.min(axis=0)                                                # :293, :301 (floor is monotonic: floor(min) = min(floor))
+    v = int(g.max())                                                     # :302
+    key = g[:, 0] + g[:, 1] * v + g[:, 2] * v * v                        # :303
+    best = {}
+    for i in range(p.shape[0]):
+        k = int(key[i]); cand = (int(level[i]), i)
+        if k not in best or cand < best[k]:
+            best[k] = cand
+    return np.array([best[k][1] for k in sorted(best)], dtype=np.int64)

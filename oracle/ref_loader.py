@@ -249,6 +249,21 @@ def reference_spinnet_forward(sd, pts, kpts, des_r, perm_seed):
     return {"desc": out["desc"], "patches": out["patches"], "perm": perm}
 
 
+def load_reference_dataset_utils():
+    """The reference's UNMODIFIED dataset_process/utils/dataset_utils.py (voxel_down_sample_torch, :279-322).  Test-only shim:
+    `open3d` and `h5py` (absent wheels) are import-only stubs -- the functions used from this module are pure torch."""
+    if not reference_available():
+        raise RuntimeError(f"reference not mounted at {REFERENCE_ROOT}")
+    for absent in ("open3d", "h5py"):                     # io_utils imports h5py at module level
+        if absent not in sys.modules:
+            sys.modules[absent] = types.ModuleType(absent)
+    for name, path in (("dataset_process", "dataset_process"), ("dataset_process.utils", "dataset_process/utils")):
+        if name not in sys.modules:
+            m = types.ModuleType(name); m.__path__ = [os.path.join(REFERENCE_ROOT, path)]
+            sys.modules[name] = m
+    return importlib.import_module("dataset_process.utils.dataset_utils")
+
+
 _LOADED = None
 
 

@@ -55,6 +55,10 @@ SIGNATURES = {
     "rap_nn_metrics_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "rap_chamfer_rmse": (c_int32, [_P, _P, _P, c_int32, c_int64, _P, _P, c_size_t, _P]),
     "rap_correspondence_rmse": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_float, _P, _P, c_size_t, _P]),
+    "rap_voxel_bounds": (c_int32, [_P, c_int64, c_float, _P, _P, _P]),
+    "rap_voxel_table_slots": (c_int64, [_P]),
+    "rap_voxel_workspace_bytes": (c_size_t, [_P]),
+    "rap_voxel_downsample": (c_int32, [_P, c_int64, c_float, _P, c_float, _P, _P, _P, c_size_t, _P]),
     "rap_farthest_point_sampling": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P]),
     "rap_spinnet_weight_count": (c_int64, []),
     "rap_spinnet_create": (c_int32, [_P, c_int64, _P, ctypes.POINTER(_P)]),

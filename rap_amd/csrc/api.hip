@@ -1047,3 +1047,38 @@ extern "C" int rap_farthest_point_sampling(const float* points, const int32_t* c
     return RAP_ERR_INVALID;
   return launch_fps((hipStream_t)stream, points, cloud_start, cloud_len, k_per_cloud, start_idx, n_clouds, k_max, dist_ws, indices_out);
 }
+
+// ---------------------------------------------------------------------------------------------
+// voxel down-sampling (preprocessing)
+// ---------------------------------------------------------------------------------------------
+extern "C" int rap_voxel_bounds(const float* points, int64_t N, float voxel_size, int64_t* bounds6_out, float* dist_max_out,
+                                void* stream) {
+  if (!points || !bounds6_out || !dist_max_out || N <= 0 || !(voxel_size > 0.f)) return RAP_ERR_INVALID;
+  return launch_voxel_bounds((hipStream_t)stream, points, (long)N, voxel_size, (long long*)bounds6_out, (unsigned int*)dist_max_out);
+}
+static int64_t voxel_slots(const int64_t* b) {
+  int64_t v = 0;
+  for (int a = 0; a < 3; ++a) v = (b[3 + a] - b[a]) > v ? (b[3 + a] - b[a]) : v;
+  if (v > 2000000) return -1;
+  const __int128 s = (__int128)v + (__int128)v * v + (__int128)v * v * v + 1;      // largest key gx + gy v + gz v^2 with g <= v, plus one
+  return s > ((__int128)1 << 33) ? -1 : (int64_t)s;
+}
+extern "C" int64_t rap_voxel_table_slots(const int64_t* h_bounds6) { return h_bounds6 ? voxel_slots(h_bounds6) : -1; }
+extern "C" size_t rap_voxel_workspace_bytes(const int64_t* h_bounds6) {
+  const int64_t s = h_bounds6 ? voxel_slots(h_bounds6) : -1;
+  if (s < 0) return 0;
+  return align_up((size_t)s * 8, 256) + align_up((size_t)((s + 4095) / 4096) * 4, 256) + 256;
+}
+extern "C" int rap_voxel_downsample(const float* points, int64_t N, float voxel_size, const int64_t* h_bounds6, float dist_max,
+                                    int64_t* indices_out, int32_t* count_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!points || !h_bounds6 || !indices_out || !count_out || N <= 0 || N > 0xffffffffLL || !(voxel_size > 0.f)) return RAP_ERR_INVALID;
+  const int64_t slots = voxel_slots(h_bounds6);
+  if (slots < 0) return RAP_ERR_INVALID;                 // grid too large for the dense table (> 2^33 slots = 64 GiB)
+  if (!ws || ws_bytes < rap_voxel_workspace_bytes(h_bounds6)) return RAP_ERR_WORKSPACE;
+  char* base = (char*)ws;
+  unsigned long long* table = (unsigned long long*)base;
+  unsigned int* block_cnt = (unsigned int*)(base + align_up((size_t)slots * 8, 256));
+  return launch_voxel_downsample((hipStream_t)stream, points, (long)N, voxel_size, (const long long*)h_bounds6,
+                                 dist_max > 0.f ? dist_max : 1.f, table, (long)slots, block_cnt, (unsigned int*)count_out,
+                                 (long long*)indices_out);
+}

@@ -164,3 +164,8 @@ int launch_correspondence_rmse(hipStream_t stream, const float* source_gt, const
 int launch_fps(hipStream_t stream, const float* pts, const int32_t* cloud_start, const int32_t* cloud_len, const int32_t* Ks,
                const int32_t* starts, int C, int Kmax,
                float* dist, int32_t* out);
+
+// voxel down-sampling (voxel.hip; reference dataset_process/utils/dataset_utils.py:279-322)
+int launch_voxel_bounds(hipStream_t stream, const float* pts, long N, float vs, long long* bounds6, unsigned int* dmax_bits);
+int launch_voxel_downsample(hipStream_t stream, const float* pts, long N, float vs, const long long* h_bounds6, float dmax,
+                            unsigned long long* table, long slots, unsigned int* block_cnt, unsigned int* total, long long* idx_out);

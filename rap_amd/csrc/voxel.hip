@@ -1,0 +1,150 @@
+// Voxel down-sampling on device (preprocessing in front of FPS / MiniSpinNet): replaces
+// voxel_down_sample_torch (dataset_process/utils/dataset_utils.py:279-322): per occupied voxel keep the point closest to the
+// voxel centre -- distances quantised to 1000 levels, ties to the lowest index -- and return the kept indices in ascending
+// voxel-key order (the reference: torch.unique + scatter_reduce_(amin) on `index + level * 10^digits`, flagged there as
+// non-deterministic on CUDA).
+//
+// Sized for 288 GB of HBM instead of a sort: a DENSE table with one 64-bit slot per possible voxel key (key = gx + gy v + gz v^2
+// with v = the largest grid coordinate, exactly the reference's key incl. its wrap-around collisions), filled with
+// atomicMin(level << 32 | index) -- deterministic -- and compacted in key order by a two-level prefix count.
+//   1. voxel_bounds: per-axis min / max of floor(p / s) and the largest centre distance (the reference's three global reductions);
+//      the host reads these 7 numbers to size the table (the reference syncs at the same places: .item(), torch.unique).
+//   2. voxel_fill: one atomicMin per point.   3. voxel_count / voxel_scan / voxel_emit: ordered compaction.
+#include "kernels.h"
+
+__device__ __forceinline__ void voxel_of(const float* p, float vs, long long& gx, long long& gy, long long& gz, float& dist) {
+  const float fx = floorf(p[0] / vs), fy = floorf(p[1] / vs), fz = floorf(p[2] / vs);      // torch.floor(points / voxel_size)
+  const float cx = mul_rn_nofuse(fx + 0.5f, vs), cy = mul_rn_nofuse(fy + 0.5f, vs), cz = mul_rn_nofuse(fz + 0.5f, vs);          // center = (grid + 0.5) * voxel_size
+  const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+  float s = mul_rn_nofuse(dx, dx);
+  s = s + mul_rn_nofuse(dy, dy);
+  s = s + mul_rn_nofuse(dz, dz);                                                            // ((p - c) ** 2).sum(dim=1)
+  dist = sqrtf(s);                                                                          // ** 0.5
+  gx = (long long)fx; gy = (long long)fy; gz = (long long)fz;
+}
+
+// out[0..2] = min grid coordinate per axis, out[3..5] = max, dmax_bits = bit pattern of the largest centre distance (>= 0)
+__global__ __launch_bounds__(256) void voxel_bounds_kernel(const float* __restrict__ pts, long N, float vs, long long* __restrict__ out,
+                                                           unsigned int* __restrict__ dmax_bits) {
+  long long mn[3] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL};
+  long long mx[3] = {-0x7fffffffffffffffLL, -0x7fffffffffffffffLL, -0x7fffffffffffffffLL};
+  float dm = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
+    long long g[3]; float d;
+    voxel_of(pts + i * 3, vs, g[0], g[1], g[2], d);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = g[a] < mn[a] ? g[a] : mn[a]; mx[a] = g[a] > mx[a] ? g[a] : mx[a]; }
+    dm = fmaxf(dm, d);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    atomicMin(&out[a], mn[a]);
+    atomicMax(&out[3 + a], mx[a]);
+  }
+  atomicMax(dmax_bits, __float_as_uint(dm));          // non-negative floats order like their bit patterns
+}
+
+__global__ __launch_bounds__(256) void voxel_fill_kernel(const float* __restrict__ pts, long N, float vs, long long ox, long long oy,
+                                                         long long oz, long long v, float dmax, unsigned long long* __restrict__ table) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
+    long long gx, gy, gz; float d;
+    voxel_of(pts + i * 3, vs, gx, gy, gz, d);
+    const long long lvl = (long long)(mul_rn_nofuse(d / dmax, 999.0f));     // (dist / dist.max() * (_quantization - 1)).long()
+    const long long key = (gx - ox) + (gy - oy) * v + (gz - oz) * v * v;    // grid[:,0] + grid[:,1] * v_size + grid[:,2] * v_size^2
+    atomicMin(&table[key], ((unsigned long long)lvl << 32) | (unsigned long long)i);
+  }
+}
+
+#define VX_CHUNK 4096     // table slots per block in the compaction passes
+__global__ __launch_bounds__(256) void voxel_count_kernel(const unsigned long long* __restrict__ table, long slots,
+                                                          unsigned int* __restrict__ block_cnt) {
+  __shared__ unsigned int red[4];
+  const long base = (long)blockIdx.x * VX_CHUNK;
+  unsigned int c = 0;
+  for (int j = threadIdx.x; j < VX_CHUNK; j += 256) {
+    const long s = base + j;
+    c += (s < slots && table[s] != ~0ull) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// exclusive scan of the block counts (one block; nblk is at most a few hundred thousand); total[0] = number of occupied voxels
+__global__ __launch_bounds__(1024) void voxel_scan_kernel(unsigned int* __restrict__ block_cnt, long nblk, unsigned int* __restrict__ total) {
+  __shared__ unsigned int wsum[16];
+  __shared__ unsigned int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long b0 = 0; b0 < nblk; b0 += 1024) {
+    const long b = b0 + threadIdx.x;
+    const unsigned int x = b < nblk ? block_cnt[b] : 0u;
+    unsigned int inc = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const unsigned int carry = carry_s;
+    if (b < nblk) block_cnt[b] = carry + woff + inc - x;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total[0] = carry_s;
+}
+__global__ __launch_bounds__(256) void voxel_emit_kernel(const unsigned long long* __restrict__ table, long slots,
+                                                         const unsigned int* __restrict__ block_off, long long* __restrict__ idx_out) {
+  __shared__ unsigned int wcnt[4];
+  __shared__ unsigned int run_s;
+  const long base = (long)blockIdx.x * VX_CHUNK;
+  if (threadIdx.x == 0) run_s = block_off[blockIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j0 = 0; j0 < VX_CHUNK; j0 += 256) {            // ascending slots: ascending keys
+    const long s = base + j0 + threadIdx.x;
+    const unsigned long long e = s < slots ? table[s] : ~0ull;
+    const bool occ = e != ~0ull;
+    const unsigned long long m = __ballot(occ);
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    unsigned int before = run_s;
+    for (int w = 0; w < wave; ++w) before += wcnt[w];
+    if (occ) idx_out[before + __popcll(m & ((1ull << lane) - 1ull))] = (long long)(e & 0xffffffffull);     // idx % offset
+    __syncthreads();
+    if (threadIdx.x == 0) run_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+}
+
+int launch_voxel_bounds(hipStream_t stream, const float* pts, long N, float vs, long long* bounds6, unsigned int* dmax_bits) {
+  const long long init[6] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL,
+                             -0x7fffffffffffffffLL, -0x7fffffffffffffffLL, -0x7fffffffffffffffLL};
+  RAP_HIP_CHECK(hipMemcpyAsync(bounds6, init, sizeof(init), hipMemcpyHostToDevice, stream));
+  RAP_HIP_CHECK(hipMemsetAsync(dmax_bits, 0, 4, stream));
+  const unsigned grid = (unsigned)((N + 255) / 256 < 4096 ? (N + 255) / 256 : 4096);
+  hipLaunchKernelGGL(voxel_bounds_kernel, dim3(grid), dim3(256), 0, stream, pts, N, vs, bounds6, dmax_bits);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+int launch_voxel_downsample(hipStream_t stream, const float* pts, long N, float vs, const long long* h_bounds6, float dmax,
+                            unsigned long long* table, long slots, unsigned int* block_cnt, unsigned int* total, long long* idx_out) {
+  const long long v = h_bounds6[3] - h_bounds6[0] > h_bounds6[4] - h_bounds6[1]
+                          ? (h_bounds6[3] - h_bounds6[0] > h_bounds6[5] - h_bounds6[2] ? h_bounds6[3] - h_bounds6[0] : h_bounds6[5] - h_bounds6[2])
+                          : (h_bounds6[4] - h_bounds6[1] > h_bounds6[5] - h_bounds6[2] ? h_bounds6[4] - h_bounds6[1] : h_bounds6[5] - h_bounds6[2]);
+  RAP_HIP_CHECK(hipMemsetAsync(table, 0xff, (size_t)slots * 8, stream));
+  const unsigned grid = (unsigned)((N + 255) / 256 < 4096 ? (N + 255) / 256 : 4096);
+  hipLaunchKernelGGL(voxel_fill_kernel, dim3(grid), dim3(256), 0, stream, pts, N, vs, h_bounds6[0], h_bounds6[1], h_bounds6[2], v, dmax, table);
+  RAP_LAUNCH_CHECK();
+  const long nblk = (slots + VX_CHUNK - 1) / VX_CHUNK;
+  hipLaunchKernelGGL(voxel_count_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, table, slots, block_cnt);
+  RAP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(voxel_scan_kernel, dim3(1), dim3(1024), 0, stream, block_cnt, nblk, total);
+  RAP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(voxel_emit_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, table, slots, block_cnt, idx_out);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}

@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's batched farthest point sampling (preprocessing in front of
 MiniSpinNet): ``apply_batched_fps`` of ``dataset_process/utils/point_sampling_utils.py:263-305``, i.e.
 ``pytorch3d.ops.sample_farthest_points(points, lengths=..., K=..., random_start_point=True)`` after ``torch.manual_seed``.
+Also ``voxel_down_sample_torch`` of ``dataset_process/utils/dataset_utils.py:279-322`` (the down-sampling step before it).
 """
 from __future__ import annotations
 
@@ -50,3 +51,31 @@ def apply_batched_fps(batch_augmented_tensor, batch_lengths_tensor, batch_k_tens
     _, idx = sample_farthest_points(batch, lengths=batch_lengths_tensor, K=batch_k_tensor, random_start_point=True)
     parts = [batch[i][idx[i][: int(k)]] for i, k in enumerate(batch_k_tensor)]
     return parts, idx
+
+
+def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float) -> torch.Tensor:
+    """dataset_utils.py:279-322: points (N,3) on the GPU -> indices (M,) int64 of the point closest to each occupied voxel's
+    centre, in ascending voxel-key order (``points[indices]`` is the down-sampled cloud).  Same result as the reference's CPU path
+    bit for bit (its CUDA path divides by multiplying with 1/voxel_size and reduces with a non-deterministic scatter)."""
+    _require_cuda(points, "points")
+    device = points.device
+    pts = _f32c(points)
+    N = pts.shape[0]
+    lib = _lib.load()
+    bounds = torch.empty(6, dtype=torch.int64, device=device)
+    dmax = torch.empty(1, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        stream = _lib.current_stream(device)
+        _lib.check(lib.rap_voxel_bounds(_lib.ptr(pts), N, float(voxel_size), _lib.ptr(bounds), _lib.ptr(dmax), stream), "rap_voxel_bounds")
+        h_bounds = bounds.cpu()                            # sizes the key table (the reference synchronises here too: .item())
+        h_dmax = float(dmax.cpu())
+        slots = lib.rap_voxel_table_slots(h_bounds.data_ptr())
+        if slots < 0:
+            raise ValueError(f"voxel grid {tuple((h_bounds[3:] - h_bounds[:3]).tolist())} needs more than 2^33 table slots")
+        ws = torch.empty(lib.rap_voxel_workspace_bytes(h_bounds.data_ptr()), dtype=torch.uint8, device=device)
+        idx = torch.empty(min(N, slots), dtype=torch.int64, device=device)
+        count = torch.empty(1, dtype=torch.int32, device=device)
+        rc = lib.rap_voxel_downsample(_lib.ptr(pts), N, float(voxel_size), h_bounds.data_ptr(), h_dmax, _lib.ptr(idx), _lib.ptr(count),
+                                      _lib.ptr(ws), ws.numel(), stream)
+    _lib.check(rc, "rap_voxel_downsample")
+    return idx[: int(count.cpu())]

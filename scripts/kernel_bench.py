@@ -224,6 +224,17 @@ def main():
     t_sp = timeit(lambda: net(cloud[None], kp[None], 0.2, True, perm=perm), iters=3, warm=1)
     rows.append({"kernel": "MiniSpinNet descriptors (65536 pts, 4096 keypoints)", "ms": t_sp * 1e3, "keypoints_per_s": 4096 / t_sp,
                  "algorithmic_TFLOPs": 4096 * 119e6 / t_sp / 1e12})
+    # preprocessing in front of it: voxel down-sampling of a 2M-point scan (60 x 60 x 8 m at 0.2 m voxels: a 27M-slot key table)
+    from rap_amd.point_sampling import voxel_down_sample_torch, sample_farthest_points
+    scan = (torch.rand(2_000_000, 3, device=dev, generator=g) - 0.5) * torch.tensor([60.0, 60.0, 8.0], device=dev)
+    t_vx = timeit(lambda: voxel_down_sample_torch(scan, 0.2), iters=5, warm=1)
+    kept = voxel_down_sample_torch(scan, 0.2).numel()
+    rows.append({"kernel": "voxel down-sampling (2M points, 0.2 m voxels, incl. 2 host syncs)", "ms": t_vx * 1e3, "kept": kept,
+                 "Mpoints_per_s": 2.0 / t_vx})
+    fps_in = scan[:64 * 16384].reshape(64, 16384, 3).contiguous()
+    t_fps = timeit(lambda: sample_farthest_points(fps_in, K=2048), iters=3, warm=1)
+    rows.append({"kernel": "farthest point sampling (64 clouds x 16384 points -> 2048 each)", "ms": t_fps * 1e3,
+                 "picks_per_s": 64 * 2048 / t_fps})
     for r in rows:
         print(json.dumps(r))
 

@@ -102,4 +102,9 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
     assert lib.rap_overlap_workspace_bytes(262144, 32, 2) > 262144 * 8
     assert lib.rap_nn_metrics_workspace_bytes(262144, 32) > 262144 * 12
     assert lib.rap_spinnet_workspace_bytes(2048) > 2048 * 140 * 1152 * 4 and lib.rap_spinnet_workspace_bytes(0) == 0
+    assert lib.rap_voxel_bounds(N, 10, 0.1, N, N, N) == -1 and lib.rap_voxel_downsample(N, 10, 0.1, N, 1.0, N, N, N, 0, N) == -1
+    b = (ctypes.c_int64 * 6)(-3, -2, 0, 6, 4, 1)                   # extents 9, 6, 1 -> v = 9 -> 9 + 81 + 729 + 1 slots
+    assert lib.rap_voxel_table_slots(b) == 820 and lib.rap_voxel_workspace_bytes(b) >= 820 * 8
+    huge = (ctypes.c_int64 * 6)(0, 0, 0, 10 ** 7, 10, 10)
+    assert lib.rap_voxel_table_slots(huge) == -1 and lib.rap_voxel_workspace_bytes(huge) == 0
     del one

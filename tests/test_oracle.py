@@ -255,3 +255,30 @@ def test_oracle_correspondence_rmse_matches_reference_golden():
         assert abs(n - ref[1]) <= 1 and abs(float(rmse) - ref[0]) < 1e-4 * ref[0] + 1e-6       # fp32 cdist vs fp64 at the threshold
     rmse, n, ratio, _ = O.compute_correspondence_rmse(T("source_gt"), T("target_gt") + 10.0, T("source_pred"), T("target_pred"), 0.05)
     assert n == 0 and np.isinf(float(rmse)) and np.isinf(z["corr_none"][0])
+
+
+# ---------------------------------------------------------------------------------------------
+# voxel down-sampling (preprocessing)
+# ---------------------------------------------------------------------------------------------
+def _voxel_golden():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voxel_downsample.npz"))
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    p = (torch.rand(int(z["n"]), 3, generator=g) - 0.4) * torch.from_numpy(z["scale"])
+    return z, p
+
+
+def test_oracle_voxel_downsample_matches_reference_golden():
+    z, p = _voxel_golden()
+    for vs in (0.25, 1.0):
+        assert np.array_equal(O.voxel_down_sample(p.numpy(), vs), z[f"idx_{vs}"])
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
+def test_oracle_voxel_downsample_matches_live_reference():
+    du = ref_loader.load_reference_dataset_utils()
+    for seed, (n, vs, scale) in enumerate([(1000, 0.1, 1.0), (7, 0.3, 1.0), (1, 0.3, 1.0), (20000, 0.02, 1.0), (30000, 0.5, 40.0)]):
+        g = torch.Generator().manual_seed(seed)
+        p = (torch.rand(n, 3, generator=g) - 0.4) * scale
+        if n == 1:
+            p = p + 0.01                       # a point exactly on its voxel centre makes the reference divide 0 / 0
+        assert np.array_equal(O.voxel_down_sample(p.numpy(), vs), du.voxel_down_sample_torch(p, vs).numpy()), (n, vs)
