@@ -116,6 +116,7 @@ static bool desc_ok(const rap_model_desc* d) {
 }
 
 extern int g_rap_gemm_variant;   // gemm_f32.hip
+extern int g_rap_gemm_stagger;   // gemm_f32.hip
 extern int g_rap_attn_variant;   // attn_f32.hip
 extern int g_rap_gemm_h16_variant;   // gemm_h16.hip
 extern int g_rap_attn_h16_variant;   // attn_h16.hip
@@ -124,6 +125,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
   if (key == 2 && value >= 0 && value <= 4) { g_rap_gemm_h16_variant = value; return RAP_OK; }
   if (key == 3 && value >= 0 && value <= 11) { g_rap_attn_h16_variant = value; return RAP_OK; }
+  if (key == 4 && value >= 0 && value <= 2) { g_rap_gemm_stagger = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 

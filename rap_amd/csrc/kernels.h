@@ -26,6 +26,7 @@ struct GemmParams {
   const float* resid; int ldr;
   const uint8_t* anchor; const float* anchor_emb;
   int heads;
+  int stagger;     // set by launch_gemm_f32 (tuning key 4): 0 off, 1 first-wave blocks [256,512) start half a tile late, 2 by CU slot
 };
 int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p);
 

@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--views", type=int, default=2)
+    ap.add_argument("--gemm-stagger", type=int, default=-1, help="fp32 GEMM tuning key 4")
     ap.add_argument("--only", default="", help="'attention' or 'gemm': restrict to one kernel family (PMC passes)")
     ap.add_argument("--pmc", action="store_true", help="one launch per kernel, no warm-up (for rocprofv3 --pmc passes)")
     ap.add_argument("--gemm-variant", type=int, default=-1)
@@ -118,6 +119,8 @@ def main():
     lib = _lib.load()
     if args.gemm_variant >= 0:
         assert lib.rap_set_tuning(0, args.gemm_variant) == 0
+    if args.gemm_stagger >= 0:
+        assert lib.rap_set_tuning(4, args.gemm_stagger) == 0
     if args.attn_variant >= 0:
         assert lib.rap_set_tuning(1, args.attn_variant) == 0
     st = lambda: _lib.current_stream(dev)
@@ -141,7 +144,7 @@ def main():
             assert rc == 0, rc
         t = timeit(fn)
         fl = 2.0 * TP * N * K
-        rows.append({"kernel": f"gemm_f32[{name}]", "variant": args.gemm_variant, "M": TP, "N": N, "K": K, "ms": t * 1e3, "tflops": fl / t / 1e12,
+        rows.append({"kernel": f"gemm_f32[{name}]", "variant": args.gemm_variant, "stagger": args.gemm_stagger, "M": TP, "N": N, "K": K, "ms": t * 1e3, "tflops": fl / t / 1e12,
                      "frac_of_157.3TF": fl / t / 1e12 / 157.3})
 
     if args.only in ("", "gemm"):
