@@ -106,10 +106,16 @@ def cpu_baseline(cfg, sd, args, gpu_first_step):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON result: RCCL prints a version banner to fd 1 when the first communicator is
+    # created, so everything else this process (or a library in it) writes to fd 1 is sent to stderr instead.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # RAP_BENCH_FORCE_DIST=1: take the torch.distributed / RCCL path with a single rank too (exercises it on a 1-GPU box)
+    distributed = world > 1 or os.environ.get("RAP_BENCH_FORCE_DIST") == "1"
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -258,7 +264,7 @@ def main():
             result["cpu_baseline"] = base
             result["se3_vs_cpu_oracle"] = err
             result["speedup_vs_cpu_baseline"] = value / base["value"]
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=json_out, flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
