@@ -213,7 +213,9 @@ int rap_geglu_interleave(const float* W, const float* b, float* Wp, float* bp, i
  * [3][H][TP][64]; out (TP, H*64).  ws >= rap_attention_workspace_bytes(TP, nseg). */
 size_t rap_attention_workspace_bytes(int64_t TP, int32_t nseg);
 int rap_attention_f32(const float* qkv_headmajor, const int32_t* cu_seqlens, int32_t nseg, float* out, int64_t TP,
-                      int32_t heads, const float* logit_bound /* NULL or H device floats, see rap_attention_h16 */, void* ws,
+                      int32_t heads, const float* logit_bound /* NULL or H device floats, see rap_attention_h16; each must be
+                      <= 40 (the fp32 kernel then drops the softmax offset: |score| log2 e <= 58); a head whose bound is larger gets
+                      NaN outputs */, void* ws,
                       size_t ws_bytes, void* stream);
 int rap_layernorm_mod(const float* x, float* out, int64_t TP, int32_t d, const float* mod, int64_t mod_stride,
                       const int32_t* token_row, void* stream);

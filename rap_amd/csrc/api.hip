@@ -415,12 +415,13 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         g.vt = w.vth; g.vt_nblk = w.vt_nblk;
         { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV, g); }
         if (rc) return rc;
-        if ((rc = launch_qknorm_h16(stream, dt, w.qkh, TP, H, lw.gq[a], lw.gk[a]))) return rc;
+        const bool prescale = attention_h16_wants_prescaled_q(dt, m->bounded_ok) && g_rap_attn_h16_variant != 9;
+        if ((rc = launch_qknorm_h16(stream, dt, w.qkh, TP, H, lw.gq[a], lw.gk[a], prescale ? RAP_QMUL_PRESCALED : 8.0f))) return rc;
         {
           ProfScope ps(stream, a);
           const float* bound = m->bounded_ok ? m->logit_bound + (size_t)j * H : nullptr;
           rc = launch_attention_h16(stream, dt, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch,
-                                    a == 0 ? w.max_items_part : w.max_items_batch, bound);
+                                    a == 0 ? w.max_items_part : w.max_items_batch, bound, prescale ? 1 : 0);
         }
         if (rc) return rc;
         GemmParamsH o{};
@@ -729,7 +730,9 @@ extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
   if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, RAP_ATTN_BQ))) return rc;
-  return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound);
+  // tuning variant 10 (timing only): treat q as already pre-scaled, i.e. run the kernel the model path runs
+  return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound,
+                              (g_rap_attn_h16_variant == 10 && logit_bound && dtype == RAP_DT_BF16) ? 1 : 0);
 }
 extern "C" int rap_layernorm_mod_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* mod,
                                      int64_t mod_stride, const int32_t* token_row, void* stream) {
@@ -744,7 +747,7 @@ extern "C" int rap_layernorm_affine_h16(int32_t dtype, const float* x, uint16_t*
 extern "C" int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t heads, const float* gamma_q,
                               const float* gamma_k, void* stream) {
   if (!qk || !gamma_q || !gamma_k) return RAP_ERR_INVALID;
-  return launch_qknorm_h16((hipStream_t)stream, dtype, qk, (int)TP, heads, gamma_q, gamma_k);
+  return launch_qknorm_h16((hipStream_t)stream, dtype, qk, (int)TP, heads, gamma_q, gamma_k, 8.0f);
 }
 
 // ---------------------------------------------------------------------------------------------

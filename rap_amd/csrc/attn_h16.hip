@@ -91,7 +91,12 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   // OPT bit 3: bounded softmax -- the caller guarantees q.k/8 <= bound[head] (after qk-norm: 8 max|gamma_q| max|gamma_k|), so
   // the fixed offset bound replaces the running maximum: p = exp(s - bound), no max chain, no rescale, no branch.
-  float mrun = (OPT & 8) ? bound[head] * 8.0f : -1e30f, lsum = 0.f;
+  // OPT bit 4 (with bit 3, bf16 only): q arrives pre-scaled by log2(e)/8 (qknorm_h16, q_mul = log2 e), so a score IS the exp2
+  // argument, and because |score| <= bound * log2(e) <= 58 the offset is dropped altogether: p = exp2(score) lies in
+  // [2^-58, 2^58], far inside the range of fp32 and bf16, and softmax is invariant to the common factor.  No per-score FMA:
+  // 848 -> 917 TF per part, 952 -> 1032 per sample (r01 run 43).  Measured and rejected on top of it (run 44): row sums from the
+  // matrix pipe (a third O tile against an all-ones V^T: 4 more MFMAs instead of 16 v_pk_add_f32 per key tile) -> 903 / 969.
+  float mrun = (OPT & 16) ? 0.f : (OPT & 8) ? bound[head] * 8.0f : -1e30f, lsum = 0.f;
   const float c = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e)
 
   // ---- staging: 512 threads, one 16-byte chunk of K and one of V^T per thread per tile
@@ -199,8 +204,10 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
         for (int k = 0; k < 8; ++k) {
           f32x2 a = {s0[2 * k], s0[2 * k + 1]};
           f32x2 b = {s1[2 * k], s1[2 * k + 1]};
-          a = __builtin_elementwise_fma(a, c2, nmc2);
-          b = __builtin_elementwise_fma(b, c2, nmc2);
+          if (!(OPT & 16)) {
+            a = __builtin_elementwise_fma(a, c2, nmc2);
+            b = __builtin_elementwise_fma(b, c2, nmc2);
+          }
           if (ABL & 8) {                              // timing-only: no transcendental
             a *= 0.001f; b *= 0.001f;
           } else {
@@ -447,12 +454,20 @@ __global__ __launch_bounds__(512, 4) void attention_h16_pp_kernel(const u16* __r
 // tuning knob (rap_set_tuning key 3): 0 = v1 (bounded softmax when per-head logit bounds are supplied -- bf16 only -- else
 // v_max3 row maximum + deferred rescale); 5 = v1 online softmax even with bounds; 11 = ping-pong schedule (slower, see above); 8 = first v1 (fmaxf chain, rescale
 // every tile); 4 = max3 only; 1..3, 6, 7 = timing-only ablations (bf16 only), see ABL above.
+// 9 = as 0 but the model path keeps q un-scaled (the per-score FMA form, for A/B timing of the pre-scaled default).
 int g_rap_attn_h16_variant = 0;
 
+// the model path asks before it runs qk-norm: pre-scaled q only feeds the default bounded bf16 kernel
+bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {
+  const int v = g_rap_attn_h16_variant;
+  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10);
+}
+
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
-                         int heads, const AttnWorkItem* items, int max_items, const float* bound) {
+                         int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0 || vt_nblk * 64 < TP) return RAP_ERR_INVALID;
+  if (q_prescaled && !(bound && attention_h16_wants_prescaled_q(dtype, true))) return RAP_ERR_INVALID;
 #define HPP_LAUNCH(DTV, BV) \
   hipLaunchKernelGGL((attention_h16_pp_kernel<DTV, BV>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound)
   if (g_rap_attn_h16_variant == 11) {
@@ -475,7 +490,9 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
       case 7: HATT_LAUNCH(RAP_DT_BF16, 32, 3); break;    // ... without the max chain
       case 8: HATT_LAUNCH(RAP_DT_BF16, 0, 0); break;     // v1: fmaxf chain, rescale every tile
       default:
-        if (bound) HATT_LAUNCH(RAP_DT_BF16, 0, 8); else HATT_LAUNCH(RAP_DT_BF16, 0, 3);
+        if (bound && q_prescaled) HATT_LAUNCH(RAP_DT_BF16, 0, 24);
+        else if (bound) HATT_LAUNCH(RAP_DT_BF16, 0, 8);
+        else HATT_LAUNCH(RAP_DT_BF16, 0, 3);
         break;
     }
   } else if (dtype == RAP_DT_F16) {

@@ -111,8 +111,10 @@ int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParam
 int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t* dst, size_t n);
 // attention on q,k half [2][H][TP][64] + transposed-blocked v (vt); out half (TP, H*64)
 // bound: optional per-head upper bounds (device, H floats) on the logits q.k/8 -- enables the bounded-softmax kernel (bf16)
+// q_prescaled: q was written by launch_qknorm_h16(..., RAP_QMUL_PRESCALED) -- scores arrive in log2 units (needs bound, bf16)
 int launch_attention_h16(hipStream_t stream, int dtype, const uint16_t* qk, const uint16_t* vt, int vt_nblk, uint16_t* out,
-                         int TP, int heads, const AttnWorkItem* items, int max_items, const float* bound);
+                         int TP, int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled);
+bool attention_h16_wants_prescaled_q(int dtype, bool bounded);
 // per-head logit bounds of one attention branch after qk-norm: out[h] = 8 * max_j|gamma_q[h][j]| * max_j|gamma_k[h][j]|
 int launch_qk_logit_bound(hipStream_t stream, const float* gamma_q, const float* gamma_k, int heads, float* out);
 // LayerNorm with 16-bit output (fp32 statistics), same modulation forms as launch_layernorm_*
@@ -120,8 +122,10 @@ int launch_layernorm_mod_h16(hipStream_t stream, int dtype, const float* x, uint
                              long mod_stride, const int32_t* token_row);
 int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const float* x, uint16_t* out, int TP, int d,
                                 const float* gain, const float* shift);
+// q_mul: factor of the q plane (8 = the reference's sqrt(Dh); RAP_QMUL_PRESCALED = log2(e) for the pre-scaled attention path)
+#define RAP_QMUL_PRESCALED 1.44269504088896340736f
 int launch_qknorm_h16(hipStream_t stream, int dtype, uint16_t* qk, int TP, int heads, const float* gamma_q,
-                      const float* gamma_k);
+                      const float* gamma_k, float q_mul);
 
 // ---------------------------------------------------------------------------------------------
 // generation selection by rigidity (rigidity.hip; reference modeling.py:456-592, eval/metrics.py:511-622)

@@ -81,7 +81,8 @@ int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const float* x, u
 // 8 lanes per (plane, head, token) row of 64 values (16 bytes per lane); 32 rows per 256-thread block.
 template <int DT>
 __global__ __launch_bounds__(256) void qknorm_h16_kernel(u16* __restrict__ qk, long rows_per_plane, int TP, int heads,
-                                                         const float* __restrict__ gamma_q, const float* __restrict__ gamma_k) {
+                                                         const float* __restrict__ gamma_q, const float* __restrict__ gamma_k,
+                                                         float q_mul) {
   const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
   if (row >= 2 * rows_per_plane) return;
   const int sub = threadIdx.x & 7;
@@ -100,20 +101,24 @@ __global__ __launch_bounds__(256) void qknorm_h16_kernel(u16* __restrict__ qk, l
   const float* g = (plane ? gamma_k : gamma_q) + head * 64 + sub * 8;
   const float4 g0 = *reinterpret_cast<const float4*>(g);
   const float4 g1 = *reinterpret_cast<const float4*>(g + 4);
-  const typename H16<DT>::T8 o8 = h16_pack8<DT>(v[0] / nrm * g0.x * 8.0f, v[1] / nrm * g0.y * 8.0f, v[2] / nrm * g0.z * 8.0f,
-                                                v[3] / nrm * g0.w * 8.0f, v[4] / nrm * g1.x * 8.0f, v[5] / nrm * g1.y * 8.0f,
-                                                v[6] / nrm * g1.z * 8.0f, v[7] / nrm * g1.w * 8.0f);
+  // the reference's factor sqrt(64) = 8 (norm.py:33); the q plane may instead be written PRE-SCALED for the attention kernel:
+  // q_mul = 8 * (log2(e) / 8) folds the softmax scale and the exp -> exp2 conversion into this (single) rounding of q
+  const float mul = plane ? 8.0f : q_mul;
+  const typename H16<DT>::T8 o8 = h16_pack8<DT>(v[0] / nrm * g0.x * mul, v[1] / nrm * g0.y * mul, v[2] / nrm * g0.z * mul,
+                                                v[3] / nrm * g0.w * mul, v[4] / nrm * g1.x * mul, v[5] / nrm * g1.y * mul,
+                                                v[6] / nrm * g1.z * mul, v[7] / nrm * g1.w * mul);
   *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, o8);
 }
 
-int launch_qknorm_h16(hipStream_t stream, int dtype, u16* qk, int TP, int heads, const float* gamma_q, const float* gamma_k) {
+int launch_qknorm_h16(hipStream_t stream, int dtype, u16* qk, int TP, int heads, const float* gamma_q, const float* gamma_k,
+                      float q_mul) {
   if (TP <= 0) return RAP_OK;
   const long rows_per_plane = (long)heads * TP;
   const long nblk = (2 * rows_per_plane + 31) / 32;
   if (dtype == RAP_DT_BF16)
-    hipLaunchKernelGGL(qknorm_h16_kernel<RAP_DT_BF16>, dim3((unsigned)nblk), dim3(256), 0, stream, qk, rows_per_plane, TP, heads, gamma_q, gamma_k);
+    hipLaunchKernelGGL(qknorm_h16_kernel<RAP_DT_BF16>, dim3((unsigned)nblk), dim3(256), 0, stream, qk, rows_per_plane, TP, heads, gamma_q, gamma_k, q_mul);
   else if (dtype == RAP_DT_F16)
-    hipLaunchKernelGGL(qknorm_h16_kernel<RAP_DT_F16>, dim3((unsigned)nblk), dim3(256), 0, stream, qk, rows_per_plane, TP, heads, gamma_q, gamma_k);
+    hipLaunchKernelGGL(qknorm_h16_kernel<RAP_DT_F16>, dim3((unsigned)nblk), dim3(256), 0, stream, qk, rows_per_plane, TP, heads, gamma_q, gamma_k, q_mul);
   else
     return RAP_ERR_INVALID;
   RAP_LAUNCH_CHECK();

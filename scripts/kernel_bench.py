@@ -67,6 +67,8 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
         gemm_case("ff2 +bias +resid (fp32 out)", 1, d, 4 * d, False)
     if args.only in ("", "attention"):
         qk = torch.nn.functional.normalize(torch.randn(2, H, TP, 64, device=dev, generator=g), dim=-1) * 8
+        if args.h16_attn_variant == 10:
+            qk[0] *= 0.125 * 1.4426950408889634      # what the model path's qk-norm writes for the pre-scaled kernel
         qk = qk.to(tdt)
         vt = torch.randn(H, nblk, 64, 64, device=dev, generator=g).to(tdt)
         out = torch.empty(TP, d, device=dev, dtype=tdt)

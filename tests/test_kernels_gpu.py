@@ -179,6 +179,18 @@ def test_attention_single_token_segments_return_v(lib, dev):
     assert (outb - qkv[:, 2]).abs().max().item() < 2e-6
 
 
+def test_attention_bound_above_40_is_refused_loudly(lib, dev):
+    """The bounded fp32 kernel drops the softmax offset, which is only safe for bounds <= 40: a head with a larger bound gets NaN
+    outputs (never a silently overflowed softmax); the other heads are unaffected."""
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(300, 3, 2, 64, generator=g)
+    cu = torch.tensor([0, 300])
+    ref = O.varlen_attention(qkv.double(), cu.to(torch.int32))
+    out = run_attention(lib, dev, qkv, cu, bound=torch.tensor([39.0, 41.0]))
+    assert (out[:, 0].double() - ref[:, 0]).abs().max().item() < 5e-6
+    assert torch.isnan(out[:, 1]).all()
+
+
 def test_attention_sharp_softmax_and_late_maximum(lib, dev):
     """Forces the online-softmax rescale path: the dominant key sits in the LAST 64-key tile and logits are large."""
     g = torch.Generator().manual_seed(3)
