@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
     }
     if (late) {
       const unsigned long long t0 = wall_clock64();                        // 100 MHz
-      const unsigned long long ticks = (unsigned long long)(p.K / GBK) * 178ull;   // 4096 cycles at ~2.3 GHz per k-tile
+      unsigned long long ticks = (unsigned long long)(p.K / GBK) * 178ull;         // 4096 cycles at ~2.3 GHz per k-tile
+      ticks = ticks < 20000ull ? ticks : 20000ull;                                 // never more than 0.2 ms
       while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
     }
   }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end walk through everything rap_amd replaces, in the order the reference's demo.py runs it, on synthetic scans
-(no dataset / checkpoint offline): raw views -> MiniSpinNet descriptors -> n generations of the rectified-flow sampler ->
-rigidity / overlap-ratio selection -> per-view transform files.  Prints one JSON line with the stage timings.
+(no dataset / checkpoint offline): dense raw scans -> voxel down-sampling -> farthest point sampling -> MiniSpinNet descriptors
+-> n generations of the rectified-flow sampler -> rigidity / overlap-ratio selection -> per-view transform files.  Prints one
+JSON line with the stage timings.
 
     python scripts/demo_pipeline.py [--views 2] [--points 4096] [--generations 3] [--dtype bfloat16] [--out /tmp/rap_demo]
 """
@@ -18,6 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rap_amd  # noqa: E402
 from rap_amd import synthetic as S  # noqa: E402
 from rap_amd.evaluator import save_transformation_files  # noqa: E402
+from rap_amd.point_sampling import sample_farthest_points, voxel_down_sample_torch  # noqa: E402
 from rap_amd.spinnet import MiniSpinNet, make_spinnet_weights  # noqa: E402
 
 
@@ -29,6 +31,8 @@ def main():
     ap.add_argument("--generations", type=int, default=3)
     ap.add_argument("--flow-steps", type=int, default=20)
     ap.add_argument("--dtype", default="bfloat16", choices=["float32", "bfloat16", "float16"])
+    ap.add_argument("--raw-factor", type=int, default=8, help="raw scan = this many jittered copies of every view point")
+    ap.add_argument("--voxel", type=float, default=0.004, help="voxel size of the down-sampling (normalised units)")
     ap.add_argument("--out", default="/tmp/rap_demo")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -37,17 +41,39 @@ def main():
     data = {k: v.to(dev) for k, v in inp.items()}
     B, P = inp["points_per_part"].shape
 
-    # 1. local features: MiniSpinNet on every view (the reference: extract_sample_features.py:151-220), keypoints = the points
-    spin = MiniSpinNet(des_r=0.2); spin.load_state_dict(make_spinnet_weights(0)); spin.to(dev)
+    # 0. preprocessing (extract_sample_features.py:378-470): every view arrives as a dense raw scan (here: jittered copies of the
+    # synthetic view), is voxel down-sampled (dataset_utils.py:279-322) and reduced to its n points by farthest point sampling
+    # (point_sampling_utils.py:263-305); the sampled points replace the view, the down-sampled cloud is MiniSpinNet's support.
+    g = torch.Generator(device=dev).manual_seed(3)
     t0 = time.perf_counter()
-    feats = []
+    supports, ns, raw_points = [], [], 0
     off = 0
     for b in range(B):
         for p in range(P):
             n = int(inp["points_per_part"][b, p])
             view = data["pointclouds"][off:off + n]
-            feats.append(spin(view[None], view[None], 0.2, True, perm=np.arange(n))["desc"])
+            raw = view.repeat_interleave(args.raw_factor, 0) + 0.002 * torch.randn(n * args.raw_factor, 3, device=dev, generator=g)
+            supports.append(raw[voxel_down_sample_torch(raw, args.voxel)])
+            ns.append(n); raw_points += raw.shape[0]
             off += n
+    kept_points = sum(d.shape[0] for d in supports)
+    # ONE batched FPS over all views (a block per cloud): zero-padded batch + lengths + per-cloud K, as apply_batched_fps does
+    lens = torch.tensor([d.shape[0] for d in supports])
+    padded = torch.zeros(len(supports), int(lens.max()), 3, device=dev)
+    for i, d in enumerate(supports):
+        padded[i, : d.shape[0]] = d
+    sampled, _ = sample_farthest_points(padded, lengths=lens, K=torch.minimum(torch.tensor(ns), lens), random_start_point=True)
+    keys = []
+    for i, (d, n) in enumerate(zip(supports, ns)):
+        k = sampled[i, : min(n, d.shape[0])]
+        keys.append(k if k.shape[0] == n else torch.cat([k, d[: n - k.shape[0]]]))     # a very coarse grid: pad with the first points
+    data["pointclouds"] = torch.cat(keys)
+    sync(); t_pre = time.perf_counter() - t0
+
+    # 1. local features: MiniSpinNet descriptors of the sampled points over the down-sampled support (extract_sample_features.py:151-220)
+    spin = MiniSpinNet(des_r=0.2); spin.load_state_dict(make_spinnet_weights(0)); spin.to(dev)
+    t0 = time.perf_counter()
+    feats = [spin(ds[None], key[None], 0.2, True, perm=np.arange(ds.shape[0]))["desc"] for ds, key in zip(supports, keys)]
     data["features"] = torch.cat(feats)
     sync(); t_feat = time.perf_counter() - t0
 
@@ -79,7 +105,8 @@ def main():
                                       out["translations_selected"])
     t_files = time.perf_counter() - t0
     print(json.dumps({"pairs": B, "views": P, "points_per_view": args.points, "generations": args.generations, "dtype": args.dtype,
-                      "seconds": {"miniSpinNet_features": t_feat, "sample_generations_incl_rigidity_selection": t_sample,
+                      "raw_points": raw_points, "points_after_voxel_downsampling": kept_points,
+                      "seconds": {"voxel_downsample_and_fps": t_pre, "miniSpinNet_features": t_feat, "sample_generations_incl_rigidity_selection": t_sample,
                                   "overlap_ratio_selection": t_overlap, "transform_files": t_files},
                       "best_by_rigidity": out["best_gen_indices"].tolist(), "best_by_overlap": best_ov.tolist(),
                       "rigidity_rmse_m": out["rigidity_rmse"].cpu().tolist(), "files_written": len(paths), "out_dir": args.out}))
