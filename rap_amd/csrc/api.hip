@@ -117,7 +117,9 @@ static bool desc_ok(const rap_model_desc* d) {
 
 extern int g_rap_gemm_variant;   // gemm_f32.hip
 extern int g_rap_gemm_stagger;   // gemm_f32.hip
+extern int g_rap_gemm_splitk;    // gemm_f32.hip
 extern int g_rap_attn_variant;   // attn_f32.hip
+extern int g_rap_attn_split;     // attn_f32.hip
 extern int g_rap_gemm_h16_variant;   // gemm_h16.hip
 extern int g_rap_attn_h16_variant;   // attn_h16.hip
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
@@ -126,6 +128,8 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 2 && value >= 0 && value <= 4) { g_rap_gemm_h16_variant = value; return RAP_OK; }
   if (key == 3 && value >= 0 && value <= 11) { g_rap_attn_h16_variant = value; return RAP_OK; }
   if (key == 4 && value >= 0 && value <= 2) { g_rap_gemm_stagger = value; return RAP_OK; }
+  if (key == 5 && (value == 0 || value == 1)) { g_rap_attn_split = value; return RAP_OK; }
+  if (key == 6 && (value == 0 || value == 1)) { g_rap_gemm_splitk = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 
@@ -454,8 +458,12 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       {
         ProfScope ps(stream, a);
         const float* bound = m->bounded_ok ? m->logit_bound + (size_t)j * H : nullptr;
-        if (a == 0) rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_part, w.max_items_part, bound);
-        else rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, w.items_batch, w.max_items_batch, bound);
+        // few-token calls: split the keys of every work item over up to 4 blocks; the partial O planes live in the (idle) FFN
+        // buffer (4 x TP x d floats), the partial row sums in the (idle) LN-output buffer
+        const int max_items = a == 0 ? w.max_items_part : w.max_items_batch;
+        const int splits = attention_f32_splits(max_items, H, bound != nullptr);
+        rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, a == 0 ? w.items_part : w.items_batch, max_items, bound, w.ffmid, w.xn,
+                                  splits);
       }
       if (rc) return rc;
       GemmParams o{};
@@ -473,6 +481,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
     GemmParams f2{};
     f2.A = w.ffmid; f2.lda = 4 * d; f2.W = lw.Wff2; f2.ldw = 4 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 4 * d;
     f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d;
+    f2.splitk_ws = w.qkv;      // idle during the FFN; qkv (3 T d) and att (T d) are adjacent: 4 partial (T,d) planes
     { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_BIAS_RESID, f2); }
     if (rc) return rc;
   }
@@ -670,7 +679,7 @@ extern "C" int rap_attention_f32(const float* qkv_headmajor, const int32_t* cu_s
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
   if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, 0))) return rc;
-  return launch_attention_f32(stream, qkv_headmajor, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound);
+  return launch_attention_f32(stream, qkv_headmajor, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound, nullptr, nullptr, 1);
 }
 
 extern "C" int rap_layernorm_mod(const float* x, float* out, int64_t TP, int32_t d, const float* mod, int64_t mod_stride,

@@ -52,10 +52,15 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 // bound = 8 max|gamma_q| max|gamma_k|, a property of the weights).  The softmax is then evaluated with that constant as
 // its offset, p = exp(s - bound): no running maximum, no rescale of O, ~1/3 of the VALU work between the two MFMA phases
 // (the section that costs the online version its last 13 % of the matrix peak).  Same softmax, different rounding points.
-template <int NW, bool BOUNDED>
+// SPLIT (few-token calls, BOUNDED only): gridDim.y key ranges per (work item, head).  With the offset-free softmax the partial
+// results of disjoint key ranges simply ADD (numerators and row sums share the common factor 1), so every range writes its
+// un-normalised O and l to a scratch plane and attention_combine_kernel divides the sums: 4x the blocks for a call whose work
+// list would otherwise cover a quarter of the CUs.
+template <int NW, bool BOUNDED, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                   int TP, int heads, const AttnWorkItem* __restrict__ items,
-                                                                  const float* __restrict__ bound) {
+                                                                  const float* __restrict__ bound, float* __restrict__ part_o,
+                                                                  float* __restrict__ part_l) {
   __shared__ __attribute__((aligned(16))) float smem[2 * AKV * KLD + 2 * AKV * VLD];
   float* Ks = smem;                    // [2][64][68]
   float* Vs = smem + 2 * AKV * KLD;    // [2][64][64]
@@ -116,6 +121,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
   const int sc4 = (tid & 15) * 4;
   float4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
   const int nkv = (len + AKV - 1) / AKV;
+  int t_begin = 0, t_end = nkv;
+  if (SPLIT) {
+    t_begin = (int)((long)nkv * blockIdx.y / gridDim.y);
+    t_end = (int)((long)nkv * (blockIdx.y + 1) / gridDim.y);
+  }
   const int koff = srow * KLD + sc4;
   const int voff = srow * VLD + sc4;
 
@@ -144,13 +154,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
     ATTN_STORE_ONE(BUF, 3, rk3, rv3)   \
   }
 
-  ATTN_LOAD_TILE(0)
+  ATTN_LOAD_TILE(t_begin)
   ATTN_STORE_TILE(0)
   __syncthreads();
 
-  for (int t = 0; t < nkv; ++t) {
-    const int cur = t & 1;
-    const bool more = (t + 1) < nkv;
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = (t - t_begin) & 1;
+    const bool more = (t + 1) < t_end;
     if (more) { ATTN_LOAD_TILE(t + 1) }
 
     if (wave_active) {
@@ -276,9 +286,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
   for (int qt = 0; qt < 2; ++qt) {
     const int q = qw0 + qt * 32 + l31;
     const float ltot = xhalf_sum(lsum[qt]);
-    const float inv = bound_ok ? 1.0f / ltot : __builtin_nanf("");
+    const float inv = SPLIT ? 1.0f : (bound_ok ? 1.0f / ltot : __builtin_nanf(""));
     if (q < len) {
-      float* op = out + (size_t)(it.seg_start + q) * dmodel + head * 64;
+      float* op = (SPLIT ? part_o + (size_t)blockIdx.y * TP * dmodel : out) + (size_t)(it.seg_start + q) * dmodel + head * 64;
+      if (SPLIT && hi == 0)
+        part_l[((size_t)blockIdx.y * TP + it.seg_start + q) * heads + head] = bound_ok ? ltot : __builtin_nanf("");
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         // registers 4rg..4rg+3 -> c = 8rg + 4hi + (0..3) -> d = 2c .. 2c+7 : 8 contiguous floats
@@ -561,6 +573,7 @@ __global__ void build_attn_worklist_kernel(const int32_t* __restrict__ cu, int n
 // profiles/r01_run3_kernel_variant_sweep.jsonl), 5 = v1 with 8 waves + static priority split (512 queries per block,
 // 134 TF), 3 = v3 (one query tile per wave, cross-sub-tile pipelining, 124 TF).
 int g_rap_attn_variant = 1;
+int g_rap_attn_split = 1;     // tuning key 5: 0 = never split few-token calls over key ranges
 static int attn_block_queries() { return g_rap_attn_variant == 5 ? 512 : RAP_ATTN_BQ; }
 
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,
@@ -572,17 +585,57 @@ int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, in
   return RAP_OK;
 }
 
+// out[t][c] = sum_s part_o[s][t][c] / sum_s part_l[s][t][head(c)]   (one thread per 4 columns)
+__global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_l,
+                                                                float* __restrict__ out, int TP, int heads, int splits) {
+  const int dmodel = heads * 64;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;           // float4 index
+  if (i >= (long)TP * dmodel / 4) return;
+  const long t = i / (dmodel / 4);
+  const int c = (int)(i % (dmodel / 4)) * 4;
+  float4 acc = {0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(part_o + ((size_t)s * TP + t) * dmodel + c);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    l += part_l[((size_t)s * TP + t) * heads + (c >> 6)];
+  }
+  const float inv = 1.0f / l;
+  acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+  *reinterpret_cast<float4*>(out + t * dmodel + c) = acc;
+}
+
+// How many key ranges a few-token call is split into (1 = no split): only the bounded (offset-free) kernel can add partial
+// results, and only work lists that leave most of the 2 x 256 block slots empty are worth the extra pass.
+int attention_f32_splits(int max_items, int heads, bool bounded) {
+  if (!bounded || g_rap_attn_variant != 1 || g_rap_attn_split == 0) return 1;
+  const long blocks = (long)max_items * heads;
+  return blocks <= 160 ? 4 : blocks <= 320 ? 2 : 1;
+}
+
 int launch_attention_f32(hipStream_t stream, const float* qkv, float* out, int TP, int heads, const AttnWorkItem* items,
-                         int max_items, const float* bound) {
+                         int max_items, const float* bound, float* part_o, float* part_l, int splits) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0) return RAP_ERR_INVALID;
+  if (splits > 1) {
+    if (!bound || !part_o || !part_l || g_rap_attn_variant != 1) return RAP_ERR_INVALID;
+    hipLaunchKernelGGL((attention_f32_kernel<4, true, true>), dim3(max_items * heads, splits), dim3(256), 0, stream, qkv, out, TP,
+                       heads, items, bound, part_o, part_l);
+    RAP_LAUNCH_CHECK();
+    const long n4 = (long)TP * heads * 16;
+    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, part_o, part_l, out, TP,
+                       heads, splits);
+    RAP_LAUNCH_CHECK();
+    return RAP_OK;
+  }
+  float* const no = nullptr;
   if (g_rap_attn_variant == 1)
   {
-    if (bound) hipLaunchKernelGGL((attention_f32_kernel<4, true>), dim3(max_items * heads), dim3(256), 0, stream, qkv, out, TP, heads, items, bound);
-    else hipLaunchKernelGGL((attention_f32_kernel<4, false>), dim3(max_items * heads), dim3(256), 0, stream, qkv, out, TP, heads, items, bound);
+    if (bound) hipLaunchKernelGGL((attention_f32_kernel<4, true>), dim3(max_items * heads), dim3(256), 0, stream, qkv, out, TP, heads, items, bound, no, no);
+    else hipLaunchKernelGGL((attention_f32_kernel<4, false>), dim3(max_items * heads), dim3(256), 0, stream, qkv, out, TP, heads, items, bound, no, no);
   }
   else if (g_rap_attn_variant == 5)
-    hipLaunchKernelGGL((attention_f32_kernel<8, false>), dim3(max_items * heads), dim3(512), 0, stream, qkv, out, TP, heads, items, bound);
+    hipLaunchKernelGGL((attention_f32_kernel<8, false>), dim3(max_items * heads), dim3(512), 0, stream, qkv, out, TP, heads, items, bound, no, no);
   else
     hipLaunchKernelGGL(attention_f32_v3_kernel, dim3(max_items * heads), dim3(512), 0, stream, qkv, out, TP, heads, items);
   RAP_LAUNCH_CHECK();

@@ -476,7 +476,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   struct Frag { float4 a0, a1, b0, b1; } f0, f1;
-  const int nk = p.K / GBK;
+  int nk = p.K / GBK;
+  if (EPI == EPI_SPLITK_PART) {                      // this block's share of the k-tiles
+    const int k0 = (int)((long)nk * blockIdx.y / gridDim.y), k1 = (int)((long)nk * (blockIdx.y + 1) / gridDim.y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a_src[i] += (size_t)k0 * GBK; w_src[i] += (size_t)k0 * GBK; }
+    nk = k1 - k0;
+  }
   const int sw = (l31 >> 1) & 7;
   const int a_row = (wm * 64 + l31) * 32;
   const int b_row = 2 * 4096 + (wn * 64 + l31) * 32;
@@ -589,6 +595,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
         float v = acc[mi][ni][r] + bn;
         if (EPI == EPI_BIAS) {
           p.C[(size_t)m * p.ldc + n] = v;
+        } else if (EPI == EPI_SPLITK_PART) {
+          p.splitk_ws[((size_t)blockIdx.y * p.M + m) * p.N + n] = acc[mi][ni][r];
         } else if (EPI == EPI_BIAS_RESID) {
           p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
         } else if (EPI == EPI_BIAS_SILU) {
@@ -608,6 +616,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
       }
     }
   }
+}
+
+// C[m][n] = resid[m][n] + bias[n] + sum_s part[s][m][n]   (the split-K path of EPI_BIAS_RESID; one thread per 4 columns)
+__global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(GemmParams p, int splits) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = p.N / 4;
+  if (i >= (long)p.M * n4) return;
+  const long m = i / n4;
+  const int n = (int)(i % n4) * 4;
+  float4 acc = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
+  if (p.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+  }
+  for (int s = 0; s < splits; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(p.splitk_ws + ((size_t)s * p.M + m) * p.N + n);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(p.C + m * p.ldc + n) = acc;
 }
 
 // tuning knob (rap_set_tuning key 0): 0 = v1 128x128, 2 = pipelined 128x128 (two 4-wave blocks per CU),
@@ -632,6 +659,7 @@ static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int var
   }
 }
 
+int g_rap_gemm_splitk = 1;      // tuning key 6: 0 = never split K for few-row calls
 int g_rap_gemm_stagger = 1;     // measured (r01 run 39): +1.3 % on the K = 512 shapes, +1.2 % at K = 2048; 2 (by CU id) is no better
 int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
   GemmParams p = p_in;
@@ -640,6 +668,15 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
   if (p.N % GBN != 0 || p.K % GBK != 0 || p.K <= 0) return RAP_ERR_INVALID;
   if ((p.lda & 3) || (p.ldw & 3)) return RAP_ERR_INVALID;
   const int v = g_rap_gemm_variant;
+  if (epilogue == EPI_BIAS_RESID && v == 16 && p.splitk_ws && g_rap_gemm_splitk && p.K >= 1024 && (p.ldr & 3) == 0 && (p.ldc & 3) == 0 &&
+      (long)((p.M + GBM - 1) / GBM) * (p.N / GBN) <= 128) {
+    const int splits = 4;
+    hipLaunchKernelGGL(gemm_f32_dma_kernel<EPI_SPLITK_PART>, dim3(((p.M + GBM - 1) / GBM) * (p.N / GBN), splits), dim3(256), 0, stream, p);
+    RAP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_splitk_combine_kernel, dim3((unsigned)(((long)p.M * (p.N / 4) + 255) / 256)), dim3(256), 0, stream, p, splits);
+    RAP_LAUNCH_CHECK();
+    return RAP_OK;
+  }
   switch (epilogue) {
     case EPI_BIAS: launch_gemm_variant<EPI_BIAS>(stream, p, v); break;
     case EPI_BIAS_RESID: launch_gemm_variant<EPI_BIAS_RESID>(stream, p, v); break;

@@ -15,6 +15,7 @@ enum GemmEpilogue {
   EPI_QKV_HEADMAJOR = 4, // N = 3*H*64: scatter to [3][H][M][64]
   EPI_BIAS_ANCHOR = 5,   // C = acc + bias[n] + anchor_emb[anchor[m] ? 1 : 0][n]
   EPI_BIAS_RELU = 6,     // C = max(acc + bias[n], 0)      (MiniSpinNet convolutions with folded BatchNorm)
+  EPI_SPLITK_PART = 7,   // internal: C[blockIdx.y][m][n] = acc over this block's share of the k-tiles (see splitk_ws)
 };
 
 struct GemmParams {
@@ -26,6 +27,10 @@ struct GemmParams {
   const float* resid; int ldr;
   const uint8_t* anchor; const float* anchor_emb;
   int heads;
+  // few-row calls of the bias + residual epilogue with a long K (the FFN down-projection at a few thousand tokens): when
+  // splitk_ws (>= 4 * M * N floats) is given and the tile grid would cover under a quarter of the block slots, K is split over 4
+  // blocks per tile writing partial tiles to splitk_ws, and a combine pass adds residual + bias + partials (deterministic order)
+  float* splitk_ws;
   int stagger;     // set by launch_gemm_f32 (tuning key 4): 0 off, 1 first-wave blocks [256,512) start half a tile late, 2 by CU slot
 };
 int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p);
@@ -41,8 +46,11 @@ struct AttnWorkItem { int seg_start, seg_len, q0, pad; };
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,
                                int max_items, int block_queries);
 // bound: optional per-head upper bounds (device, H floats) on the logits q.k/8 -> bounded-softmax instantiation
+// splits > 1 (few-token calls, needs bound): key ranges per work item, partial O in part_o [splits][TP][heads*64] and partial row
+// sums in part_l [splits][TP][heads], then one combine pass.  attention_f32_splits() picks the count for a work list (1-4).
 int launch_attention_f32(hipStream_t stream, const float* qkv_headmajor, float* out, int TP, int heads,
-                         const AttnWorkItem* items, int max_items, const float* bound);
+                         const AttnWorkItem* items, int max_items, const float* bound, float* part_o, float* part_l, int splits);
+int attention_f32_splits(int max_items, int heads, bool bounded);
 
 // ---------------------------------------------------------------------------------------------
 // memory-bound ring

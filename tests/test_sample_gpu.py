@@ -421,3 +421,26 @@ def test_sample_call_is_hip_graph_capturable(dev):
         eager = flow.sample_and_register(src, x_1=src["x_1"])
         for k in ("end_point_trajectory", "trajectory", "R", "t"):
             assert torch.equal(out[k], eager[k]), k
+
+
+def test_few_token_split_attention_matches_unsplit(dev):
+    """Few-token calls split every attention work item over up to 4 key ranges (partial O and row sums added by a combine pass --
+    exact for the offset-free bounded softmax up to fp32 summation order) and the K = 2048 FFN down-projection over 4 k ranges
+    (partial tiles + a combine pass in fixed order).  Same call with both splits disabled (tuning keys 5, 6)."""
+    from rap_amd import _lib
+    lib = _lib.load()
+    cfg, sd, model = get_model(2, 5, dev)
+    inp = S.make_inputs([[700, 324], [130, 257]], seed=3)      # 9 + 4 work items x 8 heads: 4-way split
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=3, rigidity_forcing=True)
+    d = to_dev(inp, dev)
+    try:
+        assert lib.rap_set_tuning(5, 0) == 0 and lib.rap_set_tuning(6, 0) == 0      # key 6: split-K of the FFN down-projection
+        ref = flow.sample_and_register(d, x_1=d["x_1"])
+    finally:
+        assert lib.rap_set_tuning(5, 1) == 0 and lib.rap_set_tuning(6, 1) == 0
+    out = flow.sample_and_register(d, x_1=d["x_1"])
+    for k in ("end_point_trajectory", "trajectory", "R", "t"):
+        assert (out[k] - ref[k]).abs().max().item() < 5e-6, k
+    assert not torch.equal(out["trajectory"], ref["trajectory"])        # the split path really ran (different summation order)
+    gold = O.sample(sd, cfg, inp, 3, True)
+    assert (out["end_point_trajectory"].cpu() - gold["end_point_trajectory"]).abs().max().item() < 5e-5
