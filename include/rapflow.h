@@ -264,7 +264,10 @@ int rap_profile_enable(int on);
 /* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py): key 0 = fp32 GEMM {0: 128x128 v1, 2: pipelined
  * 128x128, 4: pipelined 128x256, 8: 256x128 8-wave, 16: LDS-DMA staged 128x128 (default)}, key 1 = fp32 attention
  * {1: 4-wave v1 (default), 3: pipelined, 5: 8-wave v1}, key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave (default),
- * 2: 256x128 8-wave}.  All variants compute the same function. */
+ * 2: 256x128 8-wave, 3/4: ring-buffered}, key 3 = 16-bit attention schedule (0 default, see attn_h16.hip), key 4 = fp32 GEMM
+ * phase stagger {0 off, 1 by block index (default), 2 by CU id}, key 5 = split-KV attention for few-token calls {0 off, 1 on
+ * (default)}, key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}.
+ * All variants compute the same function. */
 int rap_set_tuning(int32_t key, int32_t value);
 int rap_profile_reset(void);
 int rap_profile_collect(float* h_ms_out, int64_t* h_count_out);
