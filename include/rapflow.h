@@ -244,7 +244,9 @@ int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda
  * out half (TP, H*64).  ws >= rap_attention_workspace_bytes(TP, nseg).
  * logit_bound: NULL, or H device floats B[h] with q.k/8 <= B[h] <= 40 for every query/key pair of head h GUARANTEED by
  * the caller (after the reference's qk-norm B = 8 max|gamma_q| max|gamma_k|): selects the bounded-softmax kernel
- * (p = exp(s - B), no running maximum; bf16 only -- other dtypes ignore it).  Same softmax, different evaluation order. */
+ * (p = exp(s - B), no running maximum; bf16 only -- other dtypes ignore it).  Same softmax, different evaluation order.
+ * (Inside rap_sample / rap_dit_forward the bf16 path additionally has qk-norm write q pre-scaled by log2(e)/8 and drops the
+ * offset: p = exp2(q'.k); this entry point keeps the un-scaled q convention.) */
 int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk, const int32_t* cu_seqlens,
                       int32_t nseg, uint16_t* out, int64_t TP, int32_t heads, const float* logit_bound, void* ws,
                       size_t ws_bytes, void* stream);
