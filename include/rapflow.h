@@ -264,7 +264,7 @@ int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t heads, const
  * into HOST arrays of 3 entries.  Not thread-safe; off by default. */
 int rap_profile_enable(int on);
 /* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py): key 0 = fp32 GEMM {0: 128x128 v1, 2: pipelined
- * 128x128, 4: pipelined 128x256, 8: 256x128 8-wave, 16: LDS-DMA staged 128x128 (default)}, key 1 = fp32 attention
+ * 128x128, 4: pipelined 128x256, 8: 256x128 8-wave, 16: LDS-DMA staged 128x128 (default), 32: LDS-DMA staged 256x256 8-wave}, key 1 = fp32 attention
  * {1: 4-wave v1 (default), 3: pipelined, 5: 8-wave v1}, key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave (default),
  * 2: 256x128 8-wave, 3/4: ring-buffered}, key 3 = 16-bit attention schedule (0 default, see attn_h16.hip), key 4 = fp32 GEMM
  * phase stagger {0 off, 1 by block index (default), 2 by CU id}, key 5 = split-KV attention for few-token calls {0 off, 1 on

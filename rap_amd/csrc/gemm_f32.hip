@@ -618,6 +618,194 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// variant 32 (opt-in, rap_set_tuning(0, 32)): the same LDS-DMA loop on a 256x256 block tile, 8 waves (2 x 4), wave tile
+// 128 x 64 = 4 x 2 MFMA tiles -- the shape of the 16-bit GEMM (gemm_h16.hip).  Per 4 k-values a wave reads 6 fragments for 32
+// MFMAs (the 128x128 kernel: 4 for 16) and meets a barrier every 256 MFMAs instead of every 64; one block per CU (128 KB LDS), so
+// prologue and epilogue are not covered by a second block.  N % 256 == 0, else the launcher falls back to the 128x128 kernel.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_f32_dma256_kernel(GemmParams p) {
+  constexpr int WN = 4, TM = 4, TN = 2, NT = 512, BM = 256, BN = 256;
+  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;          // 16-byte chunks per thread per k-tile
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];   // [A0 A1 B0 B1]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nt = p.N / BN;
+  const int mt = (p.M + BM - 1) / BM;
+  const int logical = xcd_remap(blockIdx.x, mt * nt);
+  const int m0 = (logical / nt) * BM;
+  const int n0 = (logical % nt) * BN;
+
+  const float* a_src[CA];
+  const float* w_src[CB];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 3;
+    const int lslot = (id & 7) ^ ((row >> 1) & 7);
+    int r = m0 + row;
+    r = r < p.M ? r : p.M - 1;
+    a_src[i] = p.A + (size_t)r * p.lda + 4 * lslot;
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 3;
+    const int lslot = (id & 7) ^ ((row >> 1) & 7);
+    w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + 4 * lslot;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / GBK;
+  const int sw = (l31 >> 1) & 7;
+  const int a_row = (wm * TM * 32 + l31) * 128;              // byte offsets inside one A / B buffer
+  const int b_row = (wn * TN * 32 + l31) * 128;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem256;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+#define BG_DMA1(GSRC, LDSB)                                                                                   \
+  {                                                                                                           \
+    unsigned keep_;                                                                                           \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(GSRC), "s"(LDSB) : "memory");                                           \
+  }
+#define BG_DMA(KT, BUF)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < CA; ++i)                                                              \
+    BG_DMA1(a_src[i] + (size_t)(KT) * GBK, lds_wave + (unsigned)((BUF) * ABYTES + i * NT * 16))               \
+  _Pragma("unroll") for (int i = 0; i < CB; ++i)                                                              \
+    BG_DMA1(w_src[i] + (size_t)(KT) * GBK, lds_wave + (unsigned)(2 * ABYTES + (BUF) * BBYTES + i * NT * 16))
+#define BG_SYNC asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+#define BG_FENCE __builtin_amdgcn_sched_barrier(0);
+
+  struct Frag { float4 a[TM]; float4 b[TN]; };
+  Frag f0, f1;
+  auto read_frag = [&](Frag& f, int buf, int g) {
+    const int co = ((2 * g + hi) ^ sw) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      f.a[i] = *reinterpret_cast<const float4*>(smem256 + buf * ABYTES + a_row + i * 32 * 128 + co);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      f.b[j] = *reinterpret_cast<const float4*>(smem256 + 2 * ABYTES + buf * BBYTES + b_row + j * 32 * 128 + co);
+  };
+#define BG_MMA_C(F, C)                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                        \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                      \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[i].C, F.b[j].C, acc[i][j], 0, 0, 0);
+#define BG_MMA(F) BG_MMA_C(F, x) BG_MMA_C(F, y) BG_MMA_C(F, z) BG_MMA_C(F, w)
+
+  BG_DMA(0, 0)
+  BG_SYNC
+  read_frag(f0, 0, 0);
+
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {
+    const int cur = kt & 1;
+    BG_DMA(kt + 1, cur ^ 1)
+    read_frag(f1, cur, 1);
+    BG_FENCE
+    BG_MMA(f0)
+    BG_FENCE
+    read_frag(f0, cur, 2);
+    BG_FENCE
+    BG_MMA(f1)
+    BG_FENCE
+    read_frag(f1, cur, 3);
+    BG_FENCE
+    BG_MMA(f0)
+    BG_FENCE
+    BG_SYNC
+    read_frag(f0, cur ^ 1, 0);
+    BG_FENCE
+    BG_MMA(f1)
+    BG_FENCE
+  }
+  {
+    const int cur = kt & 1;
+    read_frag(f1, cur, 1);
+    BG_FENCE
+    BG_MMA(f0)
+    BG_FENCE
+    read_frag(f0, cur, 2);
+    BG_FENCE
+    BG_MMA(f1)
+    BG_FENCE
+    read_frag(f1, cur, 3);
+    BG_FENCE
+    BG_MMA(f0)
+    BG_FENCE
+    BG_MMA(f1)
+  }
+
+  // ---------------- epilogue: as the 128x128 kernels, over 4 x 2 MFMA tiles ----------------
+  const int mw = m0 + wm * TM * 32;
+  const int nw = n0 + wn * TN * 32;
+  if (EPI == EPI_GEGLU) {
+    const int nout = (nw >> 1) + l31;
+    const float bh = p.bias ? p.bias[nw + l31] : 0.f;
+    const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + mi * 32 + mfma32_crow(r, hi);
+        if (m < p.M) {
+          const float h = acc[mi][0][r] + bh;
+          const float g = acc[mi][1][r] + bg;
+          const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+          p.C[(size_t)m * p.ldc + nout] = h * ge;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int n = nw + ni * 32 + l31;
+      const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + mi * 32 + mfma32_crow(r, hi);
+        if (m >= p.M) continue;
+        const float v = acc[mi][ni][r] + bn;
+        if (EPI == EPI_BIAS) {
+          p.C[(size_t)m * p.ldc + n] = v;
+        } else if (EPI == EPI_BIAS_RESID) {
+          p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
+        } else if (EPI == EPI_BIAS_SILU) {
+          p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
+        } else if (EPI == EPI_BIAS_RELU) {
+          p.C[(size_t)m * p.ldc + n] = fmaxf(v, 0.f);
+        } else if (EPI == EPI_BIAS_ANCHOR) {
+          const int sel = p.anchor[m] ? 1 : 0;
+          p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
+        } else if (EPI == EPI_QKV_HEADMAJOR) {
+          const int dmodel = p.heads * 64;
+          const int c = n / dmodel;
+          const int rem = n - c * dmodel;
+          const int h = rem >> 6, j = rem & 63;
+          p.C[(((size_t)c * p.heads + h) * p.M + m) * 64 + j] = v;
+        }
+      }
+    }
+  }
+}
+
 // C[m][n] = resid[m][n] + bias[n] + sum_s part[s][m][n]   (the split-K path of EPI_BIAS_RESID; one thread per 4 columns)
 __global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(GemmParams p, int splits) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -646,7 +834,16 @@ int g_rap_gemm_variant = 16;
 template <int EPI>
 static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int variant) {
   const int mt = (p.M + GBM - 1) / GBM;
-  if (variant == 16) {
+  if (variant == 32 && p.N % 256 == 0) {
+    constexpr int LDS = 2 * (256 + 256) * 128;
+    static bool attr_done = false;
+    auto kern = gemm_f32_dma256_kernel<EPI>;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(((p.M + 255) / 256) * (p.N / 256)), dim3(512), LDS, stream, p);
+  } else if (variant == 16 || variant == 32) {
     hipLaunchKernelGGL(gemm_f32_dma_kernel<EPI>, dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
   } else if (variant == 8) {
     hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 2, 4>), dim3(((p.M + 255) / 256) * (p.N / GBN)), dim3(512), 0, stream, p);
@@ -668,7 +865,7 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
   if (p.N % GBN != 0 || p.K % GBK != 0 || p.K <= 0) return RAP_ERR_INVALID;
   if ((p.lda & 3) || (p.ldw & 3)) return RAP_ERR_INVALID;
   const int v = g_rap_gemm_variant;
-  if (epilogue == EPI_BIAS_RESID && v == 16 && p.splitk_ws && g_rap_gemm_splitk && p.K >= 1024 && (p.ldr & 3) == 0 && (p.ldc & 3) == 0 &&
+  if (epilogue == EPI_BIAS_RESID && (v == 16 || v == 32) && p.splitk_ws && g_rap_gemm_splitk && p.K >= 1024 && (p.ldr & 3) == 0 && (p.ldc & 3) == 0 &&
       (long)((p.M + GBM - 1) / GBM) * (p.N / GBN) <= 128) {
     const int splits = 4;
     hipLaunchKernelGGL(gemm_f32_dma_kernel<EPI_SPLITK_PART>, dim3(((p.M + GBM - 1) / GBM) * (p.N / GBN), splits), dim3(256), 0, stream, p);

@@ -24,7 +24,15 @@ def dev():
 
 @pytest.fixture(scope="module")
 def lib():
-    return _lib.load()
+    """RAP_TEST_GEMM_VARIANT=<n> runs this module against an opt-in fp32 GEMM variant (rap_set_tuning key 0) instead of the default."""
+    import os
+    lib = _lib.load()
+    v = os.environ.get("RAP_TEST_GEMM_VARIANT")
+    if v is not None:
+        assert lib.rap_set_tuning(0, int(v)) == 0
+    yield lib
+    if v is not None:
+        assert lib.rap_set_tuning(0, 16) == 0
 
 
 def stream(dev):
