@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Run scripts/ldsdma_fill.hip: global -> LDS DMA streaming rate per CU and chip-wide vs waves, pieces in flight, drain pattern and
+source residency (see the header of the .hip file).  One JSON line per configuration; ~20 s on the GPU box."""
+import ctypes, json, os, subprocess, sys
+here = os.path.dirname(os.path.abspath(__file__))
+so = os.path.join(here, "libldsdma_fill.so")
+src = os.path.join(here, "ldsdma_fill.hip")
+if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", src, "-o", so])
+if "--build-only" in sys.argv:
+    sys.exit(0)
+lib = ctypes.CDLL(so)
+lib.ldsdma_fill.restype = ctypes.c_double
+lib.ldsdma_fill.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_double)]
+BLOCKS = 256
+for window_kb, where in ((256, "L2-resident window (256 KB per CU, re-read)"), (65536, "HBM stream (64 MB per CU)")):
+    for mode, pattern in ((0, "drain each batch (vmcnt(0) + barrier)"), (1, "queue kept full (wait for the previous batch only)")):
+        for waves in (1, 2, 4, 8):
+            for depth in (1, 2, 4, 8):
+                per_iter = waves * depth * 1024
+                iters = max(64, (32 << 20) // per_iter)            # ~32 MB per CU per launch
+                ms = ctypes.c_double()
+                tbs = lib.ldsdma_fill(waves, depth, mode, window_kb, BLOCKS, iters, ctypes.byref(ms))
+                if tbs < 0:
+                    continue
+                print(json.dumps({"source": where, "pattern": pattern, "waves_per_cu": waves, "pieces_in_flight_per_wave": depth,
+                                  "kb_per_batch_per_cu": per_iter // 1024, "chip_TBps": round(tbs, 3),
+                                  "GBps_per_cu": round(tbs * 1e3 / BLOCKS, 1), "ms": round(ms.value, 3)}), flush=True)
