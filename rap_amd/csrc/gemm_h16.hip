@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_h16_ring_kernel(GemmPara
 // (wave tile 128x64), two 64 KB stages (the default); 2 = 256x128 tile, 8 waves (wave tile 64x64); 3 = 256x256 ring of four 32 KB stages,
 // one block per CU; 4 = 256x128 ring (4 waves of 128x64, three 24 KB stages, TWO blocks per CU: one block's epilogue and
 // barrier stalls are covered by the other's k-loop).
-int g_rap_gemm_h16_variant = 1;
+int g_rap_gemm_h16_variant = 1;     // 5: 128x512 tile (opt-in, see launch_variant)
 
 template <int EPI, int DT, int WM, int WN, int TM, int NSTAGE>
 static int launch_ring(hipStream_t stream, const GemmParamsH& p) {
@@ -471,7 +471,10 @@ static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
   const int v = g_rap_gemm_h16_variant;
   if (v == 4) return launch_ring<EPI, DT, 2, 2, 4, 3>(stream, p);
   if (v == 3 && p.N % 256 == 0) return launch_ring<EPI, DT, 2, 4, 4, 4>(stream, p);
-  if ((v == 1 || v == 3) && p.N % 256 == 0) return launch_cfg<EPI, DT, 2, 4, 4, 2>(stream, p);
+  // 5 (opt-in, r01 run 56/57 analysis): 128 x 512 block tile, waves 1 x 8 -- the operand streamed from beyond L2 (A) is the SMALL
+  // side of the tile (16 KB per k-tile instead of 32), the L2-hot weights the large one; all 160 KiB of the LDS.
+  if (v == 5 && p.N % 512 == 0) return launch_cfg<EPI, DT, 1, 8, 4, 2>(stream, p);
+  if ((v == 1 || v == 3 || v == 5) && p.N % 256 == 0) return launch_cfg<EPI, DT, 2, 4, 4, 2>(stream, p);
   if (v == 2) return launch_cfg<EPI, DT, 4, 2, 2, 2>(stream, p);
   return launch_cfg<EPI, DT, 2, 2, 2, 2>(stream, p);
 }

@@ -13,7 +13,12 @@ lib = ctypes.CDLL(so)
 lib.ldsdma_fill.restype = ctypes.c_double
 lib.ldsdma_fill.argtypes = [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_double)]
 BLOCKS = 256
-for window_kb, where in ((256, "L2-resident window (256 KB per CU, re-read)"), (65536, "HBM stream (64 MB per CU)")):
+# 64 KB x 256 CUs = 16 MB: inside the 8 x 4 MB of L2; 256 KB x 256 = 64 MB: beyond L2, inside the 256 MB Infinity Cache
+WINDOWS = ((64, "L2-resident window (64 KB per CU, re-read)"), (256, "Infinity-Cache-resident window (256 KB per CU, re-read)"),
+           (65536, "HBM stream (64 MB per CU)"))
+if "--l2-only" in sys.argv:
+    WINDOWS = WINDOWS[:1]
+for window_kb, where in WINDOWS:
     for mode, pattern in ((0, "drain each batch (vmcnt(0) + barrier)"), (1, "queue kept full (wait for the previous batch only)")):
         for waves in (1, 2, 4, 8):
             for depth in (1, 2, 4, 8):
