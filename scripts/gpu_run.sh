@@ -17,7 +17,7 @@ if has tests; then
 fi
 if has h16; then
   : > "$OUT/kernel_bench_h16.jsonl"
-  for v in 0 1 2 3; do
+  for v in 0 1 2 3 5; do
     timeout 300 python scripts/kernel_bench.py --dtype bfloat16 --only gemm --h16-gemm-variant $v >> "$OUT/kernel_bench_h16.jsonl" 2>> "$OUT/kernel_bench.err"
   done
   timeout 300 python scripts/kernel_bench.py --dtype bfloat16 --only attention >> "$OUT/kernel_bench_h16.jsonl" 2>> "$OUT/kernel_bench.err"

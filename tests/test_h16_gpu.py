@@ -33,7 +33,15 @@ def dev():
 
 @pytest.fixture(scope="module")
 def lib():
-    return _lib.load()
+    """RAP_TEST_GEMM_H16_VARIANT=<n> runs this module against an opt-in 16-bit GEMM variant (rap_set_tuning key 2)."""
+    import os
+    lib = _lib.load()
+    v = os.environ.get("RAP_TEST_GEMM_H16_VARIANT")
+    if v is not None:
+        assert lib.rap_set_tuning(2, int(v)) == 0
+    yield lib
+    if v is not None:
+        assert lib.rap_set_tuning(2, 1) == 0
 
 
 def stream(dev):
