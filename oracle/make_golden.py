@@ -212,8 +212,87 @@ def make_transform_golden():
     print("transform_files", os.path.getsize(path) // 1024, "KiB", len(out["plain_names"]), "files per mode")
 
 
+def _traj_summary(ref, stride):
+    """What a full-geometry fixture keeps of a sampling call: the final registered cloud, the last x_t, the poses, the
+    per-step max-norms of both trajectories and every `stride`-th point of every step (so error growth over the re-noised
+    steps can be checked step by step without storing S x TP x 3 floats)."""
+    ep, tr = ref["end_point_trajectory"], ref["trajectory"]
+    return {"final_end_point": ep[-1].numpy(), "final_x_t": tr[-1].numpy(), "R": ref["R"].numpy(), "t": ref["t"].numpy(),
+            "end_point_step_max": ep.abs().amax(dim=(1, 2)).numpy(), "x_t_step_max": tr.abs().amax(dim=(1, 2)).numpy(),
+            "stride": np.int64(stride), "end_point_strided": ep[:, ::stride].numpy(), "x_t_strided": tr[:, ::stride].numpy()}
+
+
+def make_headline_goldens(which=("c1_rigid", "c1_free", "c3", "c4")):
+    """Full-geometry, ALL-STEP fixtures at the BASELINE.json geometries, from the reference's unmodified
+    modules (ref_loader.reference_sample).  Inputs are `make_uniform_inputs(1, views, points, seed=1234)` = sample 0 of
+    bench.py's batch, weights `make_weights(RAP_12, 0)`: the fixtures keep seeds, not inputs.
+      headline_c1_rigid / headline_c1_free : configs[1] geometry, 1 pair x 2 x 4096, rap_12, all 20 steps, rigidity on / off
+      headline_c3_rigid                    : configs[3] geometry, 1 sample x 8 x 2048, rap_12, all 30 steps, rigidity on
+      headline_c4_forward                  : configs[4] geometry, 2 x 32768, ONE forward of a 2-layer model at t = 0.5
+    The wall time of the configs[1] call is the CPU baseline of record (live reference, all 20 steps of one pair) and is
+    written to profiles/r02_cpu_reference_headline.json."""
+    import json, time
+    torch.set_num_threads(int(os.environ.get("RAP_GOLDEN_THREADS", os.cpu_count() or 1)))
+    timings = {}
+    cfg = dict(S.RAP_12)
+    sd = S.make_weights(cfg, 0)
+    jobs = {"c1_rigid": ("headline_c1_rigid", 2, 4096, 20, True, 32), "c1_free": ("headline_c1_free", 2, 4096, 20, False, 32),
+            "c3": ("headline_c3_rigid", 8, 2048, 30, True, 64)}
+    for key in which:
+        if key not in jobs:
+            continue
+        name, views, points, steps, rigid, stride = jobs[key]
+        inp = S.make_uniform_inputs(1, views, points, seed=1234)
+        t0 = time.perf_counter()
+        ref = ref_loader.reference_sample(cfg, sd, inp, steps, rigid)
+        dt = time.perf_counter() - t0
+        out = {"num_layers": np.int64(12), "weight_seed": np.int64(0), "input_seed": np.int64(1234), "views": np.int64(views),
+               "points": np.int64(points), "num_steps": np.int64(steps), "rigidity": np.int64(int(rigid)),
+               "weights_checksum": np.float64(weights_checksum(sd)), "reference_seconds": np.float64(dt),
+               "reference_threads": np.int64(torch.get_num_threads())}
+        out.update(_traj_summary(ref, stride))
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        timings[name] = {"seconds": dt, "threads": torch.get_num_threads(), "points": views * points, "flow_steps": steps,
+                         "points_per_s": views * points / dt, "rigidity_forcing": rigid,
+                         "what": "unmodified reference modules (oracle/ref_loader.reference_sample), fp32, CPU of the build container, "
+                                 "all flow steps + final fit_transformations"}
+        print(name, os.path.getsize(path) // 1024, "KiB", f"{dt:.1f} s", flush=True)
+    if "c4" in which:
+        cfg2 = dict(S.RAP_12); cfg2["num_layers"] = 2
+        sd2 = S.make_weights(cfg2, 0)
+        inp = S.make_uniform_inputs(1, 2, 32768, seed=1234)
+        model = ref_loader.build_reference_dit(cfg2, sd2)
+        cu_b, cu_p = O.prepare_cu_seqlens(inp)
+        t0 = time.perf_counter()
+        with torch.inference_mode():
+            fw = model(x=inp["x_1"], timesteps=torch.tensor([0.5]), cond_coord=inp["pointclouds"], local_features=inp["features"],
+                       latent_features=None, scales=inp["scales"], anchor_indices=inp["anchor_indices"],
+                       cu_seqlens_batch=cu_b, cu_seqlens_part=cu_p)
+        dt = time.perf_counter() - t0
+        v = fw["velocity"] if isinstance(fw, dict) else fw
+        path = os.path.join(GOLDEN_DIR, "headline_c4_forward.npz")
+        np.savez_compressed(path, num_layers=np.int64(2), weight_seed=np.int64(0), input_seed=np.int64(1234), views=np.int64(2),
+                            points=np.int64(32768), timestep=np.float32(0.5), weights_checksum=np.float64(weights_checksum(sd2)),
+                            velocity=v.numpy(), reference_seconds=np.float64(dt))
+        timings["headline_c4_forward"] = {"seconds": dt, "threads": torch.get_num_threads(), "points": 65536, "layers": 2}
+        print("headline_c4_forward", os.path.getsize(path) // 1024, "KiB", f"{dt:.1f} s", flush=True)
+    prof = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "profiles", "r02_cpu_reference_headline.json")
+    prof = os.path.normpath(prof)
+    old = {}
+    if os.path.exists(prof):
+        with open(prof) as f:
+            old = json.load(f)
+    old.update(timings)
+    with open(prof, "w") as f:
+        json.dump(old, f, indent=1)
+
+
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.endswith("-only")]     # e.g. --overlap-only regenerates one fixture
+    if "--headline-only" in only:                               # ~1.5 h of CPU: never part of the default regeneration
+        make_headline_goldens(tuple(a[2:] for a in sys.argv[1:] if a[2:] in ("c1_rigid", "c1_free", "c3", "c4")) or ("c1_rigid", "c1_free", "c3", "c4"))
+        sys.exit(0)
     if not only:
         main()
     if not only or "--selection-only" in only:

@@ -49,6 +49,7 @@ def reference_available() -> bool:
 # ----------------------------------------------------------------------------
 # stubs
 # ----------------------------------------------------------------------------
+_FLASH_STUB_SCORE_BYTES = 1 << 31      # largest (H, rows, L) score block the flash-attn stand-in materialises at once
 def _flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
                                       softmax_scale=None, causal=False,
                                       window_size=(-1, -1), softcap=0.0,
@@ -69,8 +70,13 @@ def _flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0
         q = qkv[a:b, 0].transpose(0, 1)  # (H,L,D)
         k = qkv[a:b, 1].transpose(0, 1)
         v = qkv[a:b, 2].transpose(0, 1)
-        att = torch.softmax((q @ k.transpose(1, 2)) * scale, dim=-1)
-        out[a:b] = (att @ v).transpose(0, 1)
+        L = b - a
+        # Rows of a softmax are independent, so long segments are evaluated in query chunks (same formula per row; keeps the
+        # (H,L,L) score matrix of the BASELINE configs[3]/[4] geometries -- up to 137 GB -- out of memory).
+        rows = L if H * L * L * qkv.element_size() <= _FLASH_STUB_SCORE_BYTES else max(1, _FLASH_STUB_SCORE_BYTES // (H * L * qkv.element_size()))
+        for r0 in range(0, L, rows):
+            att = torch.softmax((q[:, r0:r0 + rows] @ k.transpose(1, 2)) * scale, dim=-1)
+            out[a + r0:min(b, a + r0 + rows)] = (att @ v).transpose(0, 1)
     return out
 
 

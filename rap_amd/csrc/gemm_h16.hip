@@ -423,6 +423,165 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_h16_ring_kernel(GemmPara
   gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pipelined ring (r02; rap_set_tuning(2, 6 | 7 | 8)): what r02 call 1 measured about the default kernel -- L2 counters
+// (profiles/r02_c1_gemm_h16_l2_counters.txt): the A operand is fetched from the fabric about ONCE (TCC_EA0_RDREQ x 128 B = operand
+// bytes), i.e. the sibling n-tiles do hit the L2; the same-line requests of the CUs of one XCD merge (ldsdma_fill --shared:
+// 99-130 GB/s per CU for a window shared in lockstep vs 26 private).  So the fabric is not saturated; what the two-stage loop
+// cannot hide is the LATENCY of the first-touch fetch: every k-tile of every block (and of its lockstep siblings) waits for one
+// (a 64 KB batch drained before the next: 1.05 us from beyond the L2 vs 0.6 us L2-resident, against 0.85 us of MFMA work).
+// This variant keeps NSTAGE - 1 slices of BK = 32 in flight (5 x 32 KB = all 160 KB of the LDS: a slice is waited for three
+// slice-times after it was issued), and -- unlike the ring above -- keeps the fragment reads software-pipelined ACROSS the slice
+// barrier (the barrier sits in front of the slice's last MFMA group, the first fragments of the next slice are read behind it).
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int DT, int WM, int WN, int TM, int NSTAGE, int PRIO>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_h16_pipe_kernel(GemmParamsH p) {
+  typedef typename H16<DT>::T8 T8;
+  constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 64 * WN, TN = 2;
+  constexpr int CA = BM * 4 / NT, CB = BN * 4 / NT;      // 16-byte chunks per thread per k-slice (64-byte rows)
+  constexpr int STAGE = (BM + BN) * 64;                  // bytes: [A BM x 64 B][B BN x 64 B]
+  constexpr int NDMA = CA + CB;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nt = p.N / BN;
+  const int mt = (p.M + BM - 1) / BM;
+  const int logical = xcd_remap(blockIdx.x, mt * nt);
+  const int m0 = (logical / nt) * BM;
+  const int n0 = (logical % nt) * BN;
+
+  const u16* a_src[CA];
+  const u16* w_src[CB];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 2;
+    int r = m0 + row;
+    r = r < p.M ? r : p.M - 1;
+    a_src[i] = p.A + (size_t)r * p.lda + 8 * ((id & 3) ^ ((row >> 2) & 3));
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 2;
+    w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + 8 * ((id & 3) ^ ((row >> 2) & 3));
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / 32;
+  const int sw = (l31 >> 2) & 3;
+  const int a_row = (wm * TM * 32 + l31) * 64;
+  const int b_row = BM * 64 + (wn * TN * 32 + l31) * 64;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+#define HP_DMA(KT, SLOT)                                                                                      \
+  {                                                                                                           \
+    const unsigned sb_ = lds_wave + (unsigned)((SLOT) * STAGE);                                               \
+    _Pragma("unroll") for (int i = 0; i < CA; ++i) HG_DMA1(a_src[i] + (size_t)(KT) * 32, sb_ + (unsigned)(i * NT * 16))          \
+    _Pragma("unroll") for (int i = 0; i < CB; ++i) HG_DMA1(w_src[i] + (size_t)(KT) * 32, sb_ + (unsigned)(BM * 64 + i * NT * 16)) \
+  }
+  // "at most Y younger slices outstanding"
+#define HP_WAIT(Y)                                                                                            \
+  if constexpr ((Y) * NDMA == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             \
+  else if constexpr ((Y) * NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                        \
+  else if constexpr ((Y) * NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                        \
+  else if constexpr ((Y) * NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                      \
+  else static_assert((Y) * NDMA == 0, "add the vmcnt literal");
+  static_assert(NSTAGE >= 3 && NSTAGE <= 5, "ring depth");
+
+  struct Frag { uint4 a[TM]; uint4 b[TN]; };
+  Frag f0, f1;
+  auto read_frag = [&](Frag& f, int slot, int g) {
+    const unsigned char* st = smem + slot * STAGE;
+    const int co = ((2 * g + hi) ^ sw) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const uint4*>(st + a_row + i * 32 * 64 + co);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const uint4*>(st + b_row + j * 32 * 64 + co);
+  };
+  auto mma = [&](const Frag& f) {
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, f.a[i]), __builtin_bit_cast(T8, f.b[j]), acc[i][j]);
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: NSTAGE - 1 slices in flight, wait for the first one only
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+    if (s0 < nk) HP_DMA(s0, s0)
+  {
+    const int younger = nk - 1 < NSTAGE - 2 ? nk - 1 : NSTAGE - 2;
+    if (younger >= 3) { HP_WAIT(NSTAGE >= 5 ? 3 : 0) }
+    else if (younger == 2) { HP_WAIT(NSTAGE >= 4 ? 2 : 0) }
+    else if (younger == 1) { HP_WAIT(1) }
+    else { HP_WAIT(0) }
+  }
+  __syncthreads();
+  read_frag(f0, 0, 0);
+
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    read_frag(f1, slot, 1);
+    HG_FENCE
+    mma(f0);
+    HG_FENCE
+    int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    if (kt + 1 < nk) {
+      // slice kt+1 must have landed; the slices issued after it (kt+2 .. kt+NSTAGE-2) may stay in flight
+      const int younger = nk - 2 - kt < NSTAGE - 3 ? nk - 2 - kt : NSTAGE - 3;
+      if (younger >= 2) { HP_WAIT(NSTAGE >= 5 ? 2 : 0) }
+      else if (younger == 1) { HP_WAIT(NSTAGE >= 4 ? 1 : 0) }
+      else { HP_WAIT(0) }
+      __syncthreads();      // slice kt+1 visible to every wave; every wave has consumed slice kt-1 -> its stage is free
+      int free_slot = slot - 1; free_slot = free_slot < 0 ? NSTAGE - 1 : free_slot;
+      if (kt + NSTAGE - 1 < nk) HP_DMA(kt + NSTAGE - 1, free_slot)
+      read_frag(f0, nslot, 0);
+      HG_FENCE
+    }
+    mma(f1);
+    HG_FENCE
+    slot = nslot;
+  }
+  static_assert(WM * WN * H16_STG_BYTES <= NSTAGE * STAGE, "staging slabs must fit the operand ring");
+  __syncthreads();
+  gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
+}
+
+template <int EPI, int DT, int WM, int WN, int TM, int NSTAGE, int PRIO>
+static int launch_pipe(hipStream_t stream, const GemmParamsH& p) {
+  constexpr int BM = 32 * TM * WM, BN = 64 * WN;
+  constexpr int LDS = NSTAGE * (BM + BN) * 64;
+  static bool attr_done = false;
+  auto kern = gemm_h16_pipe_kernel<EPI, DT, WM, WN, TM, NSTAGE, PRIO>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      rap_set_last_hip_error((int)hipGetLastError());
+      return RAP_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(((p.M + BM - 1) / BM) * (p.N / BN)), dim3(64 * WM * WN), LDS, stream, p);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
 // tuning knob (rap_set_tuning key 2): 0 = 128x128 tile, 4 waves, two blocks per CU; 1 = 256x256 tile, 8 waves
 // (wave tile 128x64), two 64 KB stages (the default); 2 = 256x128 tile, 8 waves (wave tile 64x64); 3 = 256x256 ring of four 32 KB stages,
 // one block per CU; 4 = 256x128 ring (4 waves of 128x64, three 24 KB stages, TWO blocks per CU: one block's epilogue and
@@ -470,11 +629,15 @@ template <int EPI, int DT>
 static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
   const int v = g_rap_gemm_h16_variant;
   if (v == 4) return launch_ring<EPI, DT, 2, 2, 4, 3>(stream, p);
+  // 6 / 7 / 8 (r02): pipelined ring, 256x256, five 32 KB stages (6), + s_setprio around the MFMA groups (7), four stages (8)
+  if (v == 6 && p.N % 256 == 0) return launch_pipe<EPI, DT, 2, 4, 4, 5, 0>(stream, p);
+  if (v == 7 && p.N % 256 == 0) return launch_pipe<EPI, DT, 2, 4, 4, 5, 1>(stream, p);
+  if (v == 8 && p.N % 256 == 0) return launch_pipe<EPI, DT, 2, 4, 4, 4, 0>(stream, p);
   if (v == 3 && p.N % 256 == 0) return launch_ring<EPI, DT, 2, 4, 4, 4>(stream, p);
   // 5 (opt-in, r01 run 56/57 analysis): 128 x 512 block tile, waves 1 x 8 -- the operand streamed from beyond L2 (A) is the SMALL
   // side of the tile (16 KB per k-tile instead of 32), the L2-hot weights the large one; all 160 KiB of the LDS.
   if (v == 5 && p.N % 512 == 0) return launch_cfg<EPI, DT, 1, 8, 4, 2>(stream, p);
-  if ((v == 1 || v == 3 || v == 5) && p.N % 256 == 0) return launch_cfg<EPI, DT, 2, 4, 4, 2>(stream, p);
+  if ((v == 1 || v == 3 || v >= 5) && p.N % 256 == 0) return launch_cfg<EPI, DT, 2, 4, 4, 2>(stream, p);
   if (v == 2) return launch_cfg<EPI, DT, 4, 2, 2, 2>(stream, p);
   return launch_cfg<EPI, DT, 2, 2, 2, 2>(stream, p);
 }

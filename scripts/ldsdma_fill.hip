@@ -18,6 +18,13 @@
                  : "=&s"(keep_) : "v"(GSRC), "s"(LDSB) : "memory");                                           \
   }
 
+// sharing of the source window (r02): 0 = private window per block; 1 = the blocks of one XCD (blockIdx % 8) share one window and walk it in
+// lockstep (what the GEMM's weight operand looks like: every CU asks its L2 for the same lines at the same time -- do those requests
+// merge in the L2, or does each become a fabric read?); 2 = same, but block j of the XCD starts j batches into the window (staggered).
+__device__ int g_share = 0;
+static int h_share = 0;
+extern "C" void ldsdma_fill_set_share(int s) { h_share = s; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_share), &s, sizeof(int)); }
+
 template <int DEPTH, int MODE>
 __global__ __launch_bounds__(512) void fill_kernel(const char* __restrict__ src, size_t window, int npos, int iters, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -27,11 +34,12 @@ __global__ __launch_bounds__(512) void fill_kernel(const char* __restrict__ src,
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   // every wave owns 2 * DEPTH ring slots of 1 KiB in the LDS
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * (2u * DEPTH * 1024u));
-  const char* base = src + (size_t)blockIdx.x * window;                    // this block's private source window
+  const int share = g_share;
+  const char* base = src + (size_t)(share ? (blockIdx.x & 7) : blockIdx.x) * window;   // private, or one window per XCD
   const size_t stride = (size_t)nwave * DEPTH * 1024;                     // bytes the block consumes per iteration
   const size_t off0 = (size_t)wave * DEPTH * 1024;                        // wave-uniform; the lane adds 16 bytes of its piece
-  size_t off = off0;
-  int pos = 0;                                                            // npos = window / stride batches fit in the window
+  int pos = share == 2 ? (int)((blockIdx.x >> 3) * (unsigned)(npos / 32 > 0 ? npos / 32 : 1)) % npos : 0;   // npos = window / stride batches fit in the window
+  size_t off = off0 + (size_t)pos * stride;
   const char* lbase = base + (size_t)lane * 16;
   if (MODE == 1) {
 #pragma unroll
