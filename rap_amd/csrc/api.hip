@@ -125,7 +125,7 @@ extern int g_rap_attn_h16_variant;   // attn_h16.hip
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32)) { g_rap_gemm_variant = value; return RAP_OK; }
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
-  if (key == 2 && value >= 0 && value <= 8) { g_rap_gemm_h16_variant = value; return RAP_OK; }
+  if (key == 2 && value >= 0 && value <= 15) { g_rap_gemm_h16_variant = value; return RAP_OK; }
   if (key == 3 && value >= 0 && value <= 11) { g_rap_attn_h16_variant = value; return RAP_OK; }
   if (key == 4 && value >= 0 && value <= 2) { g_rap_gemm_stagger = value; return RAP_OK; }
   if (key == 5 && (value == 0 || value == 1)) { g_rap_attn_split = value; return RAP_OK; }

@@ -44,20 +44,21 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
     nblk = (TP + 255) // 256 * 256 // 64
 
     def gemm_case(name, epi, N, K, out_half, Cw=None, heads=0):
-        A = torch.randn(TP, K, device=dev, generator=g).to(tdt)
-        W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(tdt)
+        lda = K + args.pad_lda                     # r02: padded row strides (is the k-tile fetch camping on a few L2 channels?)
+        A = torch.randn(TP, lda, device=dev, generator=g).to(tdt)
+        W = (torch.randn(N, lda, device=dev, generator=g) / K ** 0.5).to(tdt)
         bias = torch.randn(N, device=dev, generator=g)
         Cw = Cw or N
         C = torch.zeros(TP * Cw, device=dev, dtype=tdt if out_half else torch.float32)
         vt = torch.zeros(H * nblk * 64 * 64, device=dev, dtype=tdt) if epi == 4 else None
         resid = C if epi == 1 else None
         def fn():
-            rc = lib.rap_gemm_h16(dt, epi, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(C), Cw, TP, N, K, _lib.ptr(bias),
+            rc = lib.rap_gemm_h16(dt, epi, _lib.ptr(A), lda, _lib.ptr(W), lda, _lib.ptr(C), Cw, TP, N, K, _lib.ptr(bias),
                                   _lib.ptr(resid), Cw if epi == 1 else 0, heads, _lib.ptr(vt), nblk if epi == 4 else 0, st())
             assert rc == 0, rc
         t = timeit(fn)
         fl = 2.0 * TP * N * K
-        rows.append({"kernel": f"gemm_h16[{name}]", "dtype": args.dtype, "variant": args.h16_gemm_variant, "M": TP, "N": N, "K": K,
+        rows.append({"kernel": f"gemm_h16[{name}]", "dtype": args.dtype, "variant": args.h16_gemm_variant, "pad_lda": args.pad_lda, "M": TP, "N": N, "K": K,
                      "ms": t * 1e3, "tflops": fl / t / 1e12, "frac_of_2500TF": fl / t / 1e12 / PEAK})
 
     if args.only in ("", "gemm"):
@@ -114,6 +115,7 @@ def main():
     ap.add_argument("--attn-variant", type=int, default=-1)
     ap.add_argument("--dtype", default="float32", help="float32 | bfloat16 | float16 (16-bit: GEMM / attention / LN / qknorm twins)")
     ap.add_argument("--h16-gemm-variant", type=int, default=-1)
+    ap.add_argument("--pad-lda", type=int, default=0, help="16-bit GEMM: extra elements per row of A and W (row stride K + pad)")
     ap.add_argument("--h16-attn-variant", type=int, default=-1, help="timing-only ablations of the 16-bit attention kernel")
     ap.add_argument("--bounded", type=int, default=1, help="pass per-head logit bounds to the 16-bit attention (bounded-softmax v2, bf16)")
     args = ap.parse_args()

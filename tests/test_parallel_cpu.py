@@ -58,3 +58,32 @@ def test_two_rank_gather_equals_single_process_batch(tmp_path):
         assert (got["final"] - ref["end_point_trajectory"][-1]).abs().max().item() < 1e-5
         assert (got["R"] - ref["R"]).abs().max().item() < 1e-5
         assert (got["t"] - ref["t"]).abs().max().item() < 1e-5
+
+
+def _worker_uneven(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # 3 pairs over 2 ranks (2 + 1) with ragged point counts: per-rank TP and B both differ  (the equal-shape
+        # all_gather_into_tensor would hang or corrupt here)
+        mine = shard_range(3, world, rank)
+        g = torch.Generator().manual_seed(100 + rank)
+        sizes = [[40, 25], [33, 60], [17, 52]]
+        tp = sum(sum(sizes[i]) for i in mine)
+        final = torch.randn(tp, 3, generator=g)
+        R = torch.randn(len(mine), 2, 3, 3, generator=g); t = torch.randn(len(mine), 2, 3, generator=g)
+        gp, gR, gt = gather_registrations(final, R, t)
+        torch.save({"final": final, "R": R, "t": t, "gp": gp, "gR": gR, "gt": gt}, os.path.join(tmpdir, f"u{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_with_uneven_shards(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_uneven, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [torch.load(os.path.join(str(tmp_path), f"u{r}.pt")) for r in range(2)]
+    for key, gkey in (("final", "gp"), ("R", "gR"), ("t", "gt")):
+        want = torch.cat([got[0][key], got[1][key]])
+        for r in range(2):
+            assert torch.equal(got[r][gkey], want), (key, r)
