@@ -257,6 +257,27 @@ int rap_layernorm_affine_h16(int32_t dtype, const float* x, uint16_t* out, int64
 int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t heads, const float* gamma_q, const float* gamma_k,
                    void* stream);
 
+/* ---- input side of the boundary: raw multi-part scans -> the packed batch rap_sample consumes ----
+ * Replaces, in their evaluation-split form (no augmentation), PointCloudDataset._transform
+ * (rectified_point_flow/data/dataset.py:733-900) and variable_collate_fn (data/datamodule.py:169-198) for a whole batch, on the
+ * device: per sample the frame of the largest ("primary" = anchor) part -- centred on its centroid, scaled by 1.5 x its largest
+ * |coordinate| -- then global centring; per part the centred cloud (cond), its pose (R = I, t = centroid; anchor: t = -gt_trans),
+ * the anchor masks, and the collated cu_seqlens.  fp64 arithmetic like numpy, fp32 results.
+ *   points (TP,3) fp32 or fp64 (points_are_f64), parts of a sample contiguous, samples contiguous; points_per_part (B,P) int64 on
+ *   the device, 0 = padding; every sample needs at least one point.
+ *   order: NULL, or (TP,) int64 -- for every output point its source index INSIDE its part (what np.random.permutation returned
+ *   for that part, dataset.py:819); order_flag: NULL or a device int32 the call ORs 1 into when an index is out of range.
+ *   outputs: cond, gt (TP,3) f32; feat_out (TP,F) f32 (feat_in gathered the same way; F may be 0); anchor_indices (TP,) u8;
+ *   part_indices (TP,) i64; rotations (B,P,3,3), translations (B,P,3), scales (B,), anchor_parts (B,P) u8,
+ *   global_translation (B,3) f32 (mean of the raw sample, original units), cu_seqlens (B+1,) i64.
+ *   ws >= rap_collate_workspace_bytes(B, P).  Three launches, no host synchronisation. */
+size_t rap_collate_workspace_bytes(int32_t B, int32_t P);
+int rap_collate_transform(const void* points, int32_t points_are_f64, const int64_t* points_per_part, int32_t B, int32_t P,
+                          int64_t TP, const int64_t* order, const float* feat_in, int32_t F, float* cond, float* gt,
+                          float* feat_out, uint8_t* anchor_indices, int64_t* part_indices, float* rotations, float* translations,
+                          float* scales, uint8_t* anchor_parts, float* global_translation, int64_t* cu_seqlens,
+                          int32_t* order_flag, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg) ----
  * When enabled, every attention and layer-GEMM launch inside rap_dit_forward / rap_sample is bracketed by two
  * hipEvents recorded on the launch stream.  rap_profile_collect synchronises on them and returns, per class

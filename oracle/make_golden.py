@@ -212,6 +212,43 @@ def make_transform_golden():
     print("transform_files", os.path.getsize(path) // 1024, "KiB", len(out["plain_names"]), "files per mode")
 
 
+def collate_samples(seed=3):
+    """Raw multi-part samples for the collate fixture: metric-scale scans (tens of metres, large offsets from the origin like UTM
+    coordinates), ragged part counts, the largest part not first, a tie for the largest part (argmax takes the first)."""
+    g = np.random.RandomState(seed)
+    sizes = [[300, 517, 120], [64, 64], [1000, 31, 257, 400]]
+    samples = []
+    for b, parts in enumerate(sizes):
+        centre = g.uniform(-500, 500, size=3) * (b + 1)
+        ps, fs = [], []
+        for n in parts:
+            ps.append(centre + g.uniform(-1, 1, size=3) * 20 + g.normal(size=(n, 3)) * np.array([8.0, 5.0, 1.5]))
+            f = g.normal(size=(n, 32)).astype(np.float32)
+            fs.append(f / np.linalg.norm(f, axis=1, keepdims=True))
+        samples.append({"parts": ps, "features": fs})
+    return samples
+
+
+def make_collate_golden():
+    """Input side of the boundary: the reference's own PointCloudDataset._transform (evaluation
+    split) + variable_collate_fn on three ragged multi-part samples (ref_loader.reference_transform_and_collate); the fixture keeps
+    the raw parts, the numpy seed that reproduces the within-part shuffles, and every arithmetic key of the collated batch."""
+    samples = collate_samples()
+    max_parts, seed = 5, 11
+    ref = ref_loader.reference_transform_and_collate(samples, max_parts, seed)
+    out = {"max_parts": np.int64(max_parts), "numpy_seed": np.int64(seed), "num_samples": np.int64(len(samples))}
+    for b, smp in enumerate(samples):
+        out[f"raw_counts_{b}"] = np.array([len(p) for p in smp["parts"]], dtype=np.int64)
+        out[f"raw_points_{b}"] = np.concatenate(smp["parts"])
+        out[f"raw_features_{b}"] = np.concatenate(smp["features"])
+    for k in ("cu_seqlens", "pointclouds", "pointclouds_gt", "part_indices", "anchor_indices", "features", "rotations", "translations",
+              "points_per_part", "anchor_parts", "init_rotation", "scales", "global_rotation", "global_translation"):
+        out["ref_" + k] = ref[k].numpy()
+    path = os.path.join(GOLDEN_DIR, "collate_transform.npz")
+    np.savez_compressed(path, **out)
+    print("collate_transform", os.path.getsize(path) // 1024, "KiB", {k: out["ref_" + k].shape for k in ("pointclouds", "translations", "scales")})
+
+
 def _traj_summary(ref, stride):
     """What a full-geometry fixture keeps of a sampling call: the final registered cloud, the last x_t, the poses, the
     per-step max-norms of both trajectories and every `stride`-th point of every step (so error growth over the re-noised
@@ -307,3 +344,5 @@ if __name__ == "__main__":
         make_nn_metrics_golden()
     if not only or "--voxel-only" in only:
         make_voxel_golden()
+    if not only or "--collate-only" in only:
+        make_collate_golden()

@@ -498,3 +498,71 @@ def voxel_down_sample(points, voxel_size):
         if k not in best or cand < best[k]:
             best[k] = cand
     return np.array([best[k][1] for k in sorted(best)], dtype=np.int64)
+
+
+# ---------------------------------------------------------------------------------------------
+# input side of the boundary: PointCloudDataset._transform in its evaluation form (no rotation /
+# scale augmentation; reference data/dataset.py:733-900) + variable_collate_fn (data/datamodule.py:169-198).  float64 like the
+# reference (numpy), cast to float32 at the end.
+# ---------------------------------------------------------------------------------------------
+def transform_sample(parts, features, max_parts, perms):
+    """parts: list of (n_i,3) float64; features: list of (n_i,F); perms: list of within-part permutations (what
+    np.random.permutation returned for every part, dataset.py:819).  Returns the reference's per-sample result dict (the
+    arithmetic keys)."""
+    import numpy as np
+    counts = np.array([len(p) for p in parts])
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    pts_gt = np.concatenate(parts).astype(np.float64)
+    feats = np.concatenate(features)
+    n_parts = len(parts)
+    tran_global = pts_gt.mean(axis=0)                                   # :759
+    primary = int(np.argmax(counts))                                    # :764
+    st, ed = offsets[primary], offsets[primary + 1]
+    primary_trans = pts_gt[st:ed].mean(axis=0)                          # :769 center_pcd
+    scale = np.max(np.abs(pts_gt[st:ed] - primary_trans)) * 1.5         # :783
+    pts_gt = (pts_gt - primary_trans) / scale                           # :791-794 (rot_global = I)
+    gt_trans = pts_gt.mean(axis=0)                                      # :796 center_pcd
+    pts_gt = pts_gt - gt_trans
+    pts = pts_gt.copy()
+    part_indices = np.zeros(len(pts), dtype=np.int64)
+    trans = np.zeros((max_parts, 3), dtype=np.float32); rots = np.zeros((max_parts, 3, 3), dtype=np.float32)
+    feats_out = feats.copy()
+    for i in range(n_parts):                                            # _proc_part :802-830
+        a, b = offsets[i], offsets[i + 1]
+        c = pts_gt[a:b].mean(axis=0)
+        part = pts_gt[a:b] - c
+        o = perms[i]
+        pts[a:b] = part[o]
+        pts_gt[a:b] = pts_gt[a:b][o]
+        feats_out[a:b] = feats[a:b][o]
+        part_indices[a:b] = i
+        trans[i] = c; rots[i] = np.eye(3)
+    anchor = np.zeros(max_parts, bool); anchor[primary] = True          # :841-842
+    anchor_indices = np.zeros(len(pts), bool)
+    anchor_indices[st:ed] = True                                        # :860-870
+    rots[primary] = np.eye(3); trans[primary] = -gt_trans
+    pts[st:ed] = pts_gt[st:ed] + gt_trans
+    ppp = np.zeros(max_parts, dtype=np.int64); ppp[:n_parts] = counts
+    return {"pointclouds": pts.astype(np.float32), "pointclouds_gt": pts_gt.astype(np.float32), "features": feats_out.astype(np.float32),
+            "rotations": rots, "translations": trans, "points_per_part": ppp, "part_indices": part_indices,
+            "scales": np.array(scale, dtype=np.float32), "anchor_parts": anchor, "anchor_indices": anchor_indices,
+            "init_rotation": np.eye(3, dtype=np.float32), "global_rotation": np.eye(3, dtype=np.float32),
+            "global_translation": tran_global.astype(np.float32)}
+
+
+def transform_and_collate(samples, max_parts, seed):
+    """samples: list of {"parts": [...], "features": [...]}; draws the permutations like the reference (np.random.seed(seed), one
+    np.random.permutation per part in order) and collates like variable_collate_fn."""
+    import numpy as np
+    np.random.seed(seed)
+    outs = []
+    for smp in samples:
+        perms = [np.random.permutation(len(p)) for p in smp["parts"]]
+        outs.append(transform_sample(smp["parts"], smp["features"], max_parts, perms))
+    lengths = [o["pointclouds"].shape[0] for o in outs]
+    res = {"cu_seqlens": torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(lengths, dtype=torch.int64).cumsum(0)])}
+    for k in ("pointclouds", "pointclouds_gt", "part_indices", "anchor_indices", "features"):
+        res[k] = torch.from_numpy(np.concatenate([o[k] for o in outs], axis=0))
+    for k in ("rotations", "translations", "points_per_part", "anchor_parts", "init_rotation", "scales", "global_rotation", "global_translation"):
+        res[k] = torch.stack([torch.from_numpy(np.asarray(o[k])) for o in outs], dim=0)
+    return res

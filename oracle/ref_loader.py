@@ -174,6 +174,18 @@ def _install_pytorch3d_import_stub():
     sys.modules.update({"pytorch3d": p3, "pytorch3d.loss": loss, "pytorch3d.loss.chamfer": ch, "pytorch3d.ops": ops})
 
 
+class _PermissiveMeta(type):
+    """Class attributes of an import-only stand-in are again stand-ins (`trimesh.util.log.setLevel(...)` at import time)."""
+    def __getattr__(cls, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _permissive_class(name)
+
+
+def _permissive_class(name):
+    return _PermissiveMeta(name, (), {"__init__": lambda self, *a, **k: None})
+
+
 class _PermissiveModule(types.ModuleType):
     """Import-only stand-in: any attribute is an empty class (for `from x import A, B, C` of render / Lightning helpers that
     are never called on the path)."""
@@ -182,7 +194,7 @@ class _PermissiveModule(types.ModuleType):
     def __getattr__(self, name):
         if name.startswith("__"):
             raise AttributeError(name)
-        return type(name, (), {})
+        return _permissive_class(name)
 
 
 def load_reference_evaluator():
@@ -268,6 +280,58 @@ def load_reference_dataset_utils():
             m = types.ModuleType(name); m.__path__ = [os.path.join(REFERENCE_ROOT, path)]
             sys.modules[name] = m
     return importlib.import_module("dataset_process.utils.dataset_utils")
+
+
+def load_reference_data():
+    """The reference's UNMODIFIED data/dataset.py and data/datamodule.py (PointCloudDataset._transform, dataset.py:733-900;
+    variable_collate_fn, datamodule.py:169-198).  Import-only stand-ins for h5py, trimesh (mesh IO: not touched by _transform) and
+    lightning (the DataModule base class)."""
+    if not reference_available():
+        raise RuntimeError(f"reference not mounted at {REFERENCE_ROOT}")
+    for absent in ("h5py", "trimesh", "trimesh.exchange", "trimesh.exchange.ply", "lightning"):
+        sys.modules.setdefault(absent, _PermissiveModule(absent))
+    pkg_dir = os.path.join(REFERENCE_ROOT, "rectified_point_flow")
+    if "rectified_point_flow" not in sys.modules:
+        pkg = types.ModuleType("rectified_point_flow"); pkg.__path__ = [pkg_dir]
+        sys.modules["rectified_point_flow"] = pkg
+    if "rectified_point_flow.data" not in sys.modules:
+        dpk = types.ModuleType("rectified_point_flow.data"); dpk.__path__ = [os.path.join(pkg_dir, "data")]
+        sys.modules["rectified_point_flow.data"] = dpk
+    ns = types.SimpleNamespace()
+    ns.dataset = importlib.import_module("rectified_point_flow.data.dataset")
+    ns.datamodule = importlib.import_module("rectified_point_flow.data.datamodule")
+    return ns
+
+
+class _SequentialPool:
+    """Stand-in for the dataset's ThreadPoolExecutor: parts are processed in order, so the np.random.permutation draws of
+    _proc_part (dataset.py:819) come in part order and are reproducible from the seed."""
+    def map(self, fn, it):
+        return [fn(x) for x in it]
+
+    def shutdown(self):
+        pass
+
+
+def reference_transform_and_collate(samples, max_parts, seed, dataset_name="synthetic"):
+    """Run the reference's own PointCloudDataset._transform (evaluation split: no augmentation) on every sample and its own
+    variable_collate_fn on the results.  samples: list of {"parts": [ (n_i,3) float64 arrays ], "features": [ (n_i,F) float32 ]}.
+    numpy's global RNG is seeded once; the permutations the reference draws (one per part, in order) are reproduced by
+    `np.random.seed(seed)` + the same sequence of np.random.permutation calls."""
+    import numpy as np
+    ns = load_reference_data()
+    fake = types.SimpleNamespace(split="val", yaw_augmentation=False, roll_pitch_range=None, random_scale_range=None,
+                                 pool=_SequentialPool(), max_parts=max_parts, multi_anchor=False, multi_anchor_random_rate=0.0,
+                                 dataset_name=dataset_name, load_features=True)
+    np.random.seed(seed)
+    outs = []
+    for idx, smp in enumerate(samples):
+        data = {"index": idx, "name": f"sample_{idx}", "num_parts": len(smp["parts"]), "overlap_threshold": 0.05,
+                "pointclouds_gt": [np.array(a, dtype=np.float64) for a in smp["parts"]],
+                "pointclouds_normals_gt": [np.zeros((len(a), 3)) for a in smp["parts"]],
+                "features": [np.array(f, dtype=np.float32) for f in smp["features"]], "is_pre_sampled": True}
+        outs.append(ns.dataset.PointCloudDataset._transform(fake, data))
+    return ns.datamodule.variable_collate_fn(outs)
 
 
 _LOADED = None

@@ -1096,3 +1096,27 @@ extern "C" int rap_voxel_downsample(const float* points, int64_t N, float voxel_
                                  dist_max > 0.f ? dist_max : 1.f, table, (long)slots, block_cnt, (unsigned int*)count_out,
                                  (long long*)indices_out);
 }
+
+// ---------------------------------------------------------------------------------------------
+// input side of the boundary: raw parts -> the packed batch
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t rap_collate_workspace_bytes(int32_t B, int32_t P) {
+  if (B <= 0 || P <= 0) return 0;
+  return collate_workspace_bytes(B, P);
+}
+
+extern "C" int rap_collate_transform(const void* points, int32_t points_are_f64, const int64_t* points_per_part, int32_t B, int32_t P,
+                                     int64_t TP, const int64_t* order, const float* feat_in, int32_t F, float* cond, float* gt,
+                                     float* feat_out, uint8_t* anchor_indices, int64_t* part_indices, float* rotations,
+                                     float* translations, float* scales, uint8_t* anchor_parts, float* global_translation,
+                                     int64_t* cu_seqlens, int32_t* order_flag, void* ws, size_t ws_bytes, void* stream) {
+  if (!points || !points_per_part || !cond || !gt || !anchor_indices || !part_indices || !rotations || !translations || !scales ||
+      !anchor_parts || !global_translation || !cu_seqlens)
+    return RAP_ERR_INVALID;
+  if (B <= 0 || P <= 0 || P > 256 || (int64_t)B * P > 65535 || TP < 0 || TP > 0x7fffffffLL / 8 || F < 0) return RAP_ERR_INVALID;
+  if (F > 0 && (!feat_in || !feat_out)) return RAP_ERR_INVALID;
+  if (!ws || ws_bytes < collate_workspace_bytes(B, P)) return RAP_ERR_WORKSPACE;
+  return launch_collate_transform((hipStream_t)stream, points, points_are_f64 ? 1 : 0, points_per_part, B, P, (long)TP, order, feat_in, F,
+                                  cond, gt, feat_out, anchor_indices, part_indices, rotations, translations, scales, anchor_parts,
+                                  global_translation, cu_seqlens, order_flag, ws);
+}

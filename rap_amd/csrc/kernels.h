@@ -182,3 +182,12 @@ int launch_fps(hipStream_t stream, const float* pts, const int32_t* cloud_start,
 int launch_voxel_bounds(hipStream_t stream, const float* pts, long N, float vs, long long* bounds6, unsigned int* dmax_bits);
 int launch_voxel_downsample(hipStream_t stream, const float* pts, long N, float vs, const long long* h_bounds6, float dmax,
                             unsigned long long* table, long slots, unsigned int* block_cnt, unsigned int* total, long long* idx_out);
+
+// ---------------------------------------------------------------------------------------------
+// input side of the boundary (collate.hip; reference data/dataset.py:733-900 evaluation split, data/datamodule.py:169-198)
+// ---------------------------------------------------------------------------------------------
+size_t collate_workspace_bytes(int B, int P);
+int launch_collate_transform(hipStream_t stream, const void* pts, int f64, const int64_t* points_per_part, int B, int P, long TP,
+                             const int64_t* order, const float* feat_in, int F, float* cond, float* gt, float* feat_out,
+                             uint8_t* anchor_idx, int64_t* part_idx, float* rotations, float* translations, float* scales,
+                             uint8_t* anchor_parts, float* global_translation, int64_t* cu_seqlens, int32_t* order_flag, void* ws);

@@ -442,3 +442,63 @@ def test_attention_large_scan_geometry_one_head(lib, dev):
                 worst = max(worst, (out[r0:r0 + 4096].double() - ref).abs().max().item())
         print(f"large-scan attention {cu_list}: max abs err vs fp64 {worst:.2e}")
         assert worst < 5e-6, worst
+
+
+# ---------------------------------------------------------------------------------------------
+# input side of the boundary: device-side _transform + collate
+# ---------------------------------------------------------------------------------------------
+def _collate_fixture():
+    import numpy as np
+    from test_oracle import COLLATE_KEYS, load_collate_golden
+    z, samples = load_collate_golden()
+    return z, samples, COLLATE_KEYS
+
+
+def test_transform_and_collate_matches_reference_golden(dev):
+    """rap_collate_transform vs the reference's own PointCloudDataset._transform + variable_collate_fn (fixture written by the
+    unmodified modules): same numpy seed -> same within-part shuffles -> every key of the collated batch."""
+    import numpy as np
+    import rap_amd
+    z, samples, keys = _collate_fixture()
+    np.random.seed(int(z["numpy_seed"]))
+    got = rap_amd.transform_and_collate(samples, int(z["max_parts"]), device=dev)
+    for k in keys:
+        ref = torch.from_numpy(z["ref_" + k])
+        g = got[k].cpu()
+        assert g.shape == ref.shape and g.dtype == ref.dtype, (k, g.shape, ref.shape, g.dtype, ref.dtype)
+        if ref.dtype.is_floating_point:
+            err = (g - ref).abs().max().item()
+            assert err <= 2e-7 * max(1.0, ref.abs().max().item()), (k, err)      # fp64 arithmetic on both sides, one fp32 rounding
+        else:
+            assert torch.equal(g, ref), k
+    assert got["num_parts"] == [3, 2, 4]
+
+
+def test_transform_and_collate_fp32_input_large_batch_properties(dev):
+    """BASELINE-size batch (32 pairs x 2 x 4096) from fp32 scans: the reference's own invariant (dataset.py:927-932:
+    cond @ R^T + t == gt for non-anchor parts, anchor cond == gt + gt_trans), unit extent of the anchor, the collated offsets; and
+    the output drives the sampler unchanged (keys of the boundary dict)."""
+    import rap_amd
+    g = torch.Generator().manual_seed(3)
+    samples = []
+    for b in range(32):
+        c = torch.randn(3, generator=g) * 300
+        samples.append({"parts": [(c + torch.randn(4096, 3, generator=g) * torch.tensor([9.0, 6.0, 2.0])).to(dev),
+                                  (c + 5 + torch.randn(4096, 3, generator=g) * torch.tensor([9.0, 6.0, 2.0])).to(dev)],
+                        "features": [torch.nn.functional.normalize(torch.randn(4096, 32, generator=g), dim=1).to(dev) for _ in range(2)]})
+    out = rap_amd.transform_and_collate(samples, 2, shuffle=False)
+    TP = 32 * 8192
+    assert out["pointclouds"].shape == (TP, 3) and out["cu_seqlens"].tolist() == list(range(0, TP + 1, 8192))
+    cond, gt = out["pointclouds"].view(32, 2, 4096, 3), out["pointclouds_gt"].view(32, 2, 4096, 3)
+    t = out["translations"]
+    anchor = out["anchor_parts"]
+    assert anchor.sum(1).tolist() == [1] * 32 and bool(anchor[:, 0].all())                 # equal counts: the first part is the anchor
+    rec = cond[:, 1] + t[:, 1, None, :]                                                      # R = I
+    assert (rec - gt[:, 1]).abs().max().item() < 2e-6
+    assert (cond[:, 0] - (gt[:, 0] - t[:, 0, None, :])).abs().max().item() < 2e-6          # anchor: t = -gt_trans
+    assert (cond[:, 0].abs().amax(dim=(1, 2)) * 1.5 - 1.0).abs().max().item() < 1e-5       # anchor extent: max |coord| * 1.5 = 1
+    assert cond[:, 0].mean(1).abs().max().item() < 1e-5 and cond[:, 1].mean(1).abs().max().item() < 1e-5
+    assert gt.reshape(32, -1, 3).mean(1).abs().max().item() < 1e-5
+    assert torch.equal(out["anchor_indices"].view(32, 2, 4096)[:, 0], torch.ones(32, 4096, dtype=torch.bool, device=dev))
+    with pytest.raises(ValueError):
+        rap_amd.transform_and_collate(samples[:2], 2, order=torch.full((2 * 8192,), 5000, dtype=torch.int64))

@@ -282,3 +282,57 @@ def test_oracle_voxel_downsample_matches_live_reference():
         if n == 1:
             p = p + 0.01                       # a point exactly on its voxel centre makes the reference divide 0 / 0
         assert np.array_equal(O.voxel_down_sample(p.numpy(), vs), du.voxel_down_sample_torch(p, vs).numpy()), (n, vs)
+
+
+# ---------------------------------------------------------------------------------------------
+# input side of the boundary: _transform (evaluation split) + variable_collate_fn
+# ---------------------------------------------------------------------------------------------
+COLLATE_KEYS = ("cu_seqlens", "pointclouds", "pointclouds_gt", "part_indices", "anchor_indices", "features", "rotations", "translations",
+                "points_per_part", "anchor_parts", "init_rotation", "scales", "global_rotation", "global_translation")
+
+
+def load_collate_golden():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collate_transform.npz"))
+    samples = []
+    for b in range(int(z["num_samples"])):
+        counts = z[f"raw_counts_{b}"]; off = np.concatenate([[0], np.cumsum(counts)])
+        pts, fe = z[f"raw_points_{b}"], z[f"raw_features_{b}"]
+        samples.append({"parts": [pts[off[i]:off[i + 1]] for i in range(len(counts))],
+                        "features": [fe[off[i]:off[i + 1]] for i in range(len(counts))]})
+    return z, samples
+
+
+def test_oracle_transform_and_collate_matches_reference_golden():
+    z, samples = load_collate_golden()
+    got = O.transform_and_collate(samples, int(z["max_parts"]), int(z["numpy_seed"]))
+    for k in COLLATE_KEYS:
+        ref = z["ref_" + k]
+        g = got[k].numpy()
+        assert g.shape == ref.shape and g.dtype == ref.dtype, (k, g.shape, ref.shape, g.dtype, ref.dtype)
+        if ref.dtype.kind == "f":
+            assert np.abs(g - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (k, np.abs(g - ref).max())
+        else:
+            assert np.array_equal(g, ref), k
+    # the invariant the reference asserts in its own __main__ (dataset.py:927-932): cond @ R^T + t recovers gt for non-anchor parts
+    ppp = got["points_per_part"][0]; st = 0
+    for i in range(int((ppp > 0).sum())):
+        ed = st + int(ppp[i])
+        if not bool(got["anchor_parts"][0, i]):
+            rec = got["pointclouds"][st:ed] @ got["rotations"][0, i].T + got["translations"][0, i]
+            assert (rec - got["pointclouds_gt"][st:ed]).abs().max() < 1e-6
+        st = ed
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
+def test_oracle_transform_and_collate_matches_live_reference():
+    from oracle.make_golden import collate_samples
+    samples = collate_samples(seed=9)
+    ref = ref_loader.reference_transform_and_collate(samples, 6, 4)
+    got = O.transform_and_collate(samples, 6, 4)
+    for k in COLLATE_KEYS:
+        r, g = ref[k], got[k]
+        assert r.shape == g.shape and r.dtype == g.dtype, k
+        if r.dtype.is_floating_point:
+            assert (r - g).abs().max().item() <= 1e-6 * max(1.0, r.abs().max().item()), k
+        else:
+            assert torch.equal(r, g), k
