@@ -278,6 +278,24 @@ int rap_collate_transform(const void* points, int32_t points_are_f64, const int6
                           float* scales, uint8_t* anchor_parts, float* global_translation, int64_t* cu_seqlens,
                           int32_t* order_flag, void* ws, size_t ws_bytes, void* stream);
 
+/* Statistical outlier removal in front of FPS / MiniSpinNet: Open3D's PointCloud.remove_statistical_outlier(nb_neighbors, std_ratio)
+ * as dataset_process/extract_sample_features.py:378-385 calls it (20, 2.5).  Open3D is not in the reference mount; the kernel follows
+ * its published rule (mean distance to the nb_neighbors nearest points INCLUDING the point itself; threshold = mean + std_ratio *
+ * Bessel-corrected std over the cloud; inlier = 0 < d < threshold): parity unpinned.  points (N,3) f32; nb_neighbors <= 32;
+ * inlier_indices (>= N int64, ascending), count_out (device int32), stats_out NULL or 3 device doubles {mean, std, threshold};
+ * ws >= rap_outlier_workspace_bytes(N).  Brute-force k-NN through the LDS (N^2 pair distances), no host synchronisation. */
+size_t rap_outlier_workspace_bytes(int64_t N);
+int rap_statistical_outliers(const float* points, int64_t N, int32_t nb_neighbors, double std_ratio, int64_t* inlier_indices,
+                             int32_t* count_out, double* stats_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Consistency of a packed batch -- what the reference asserts in split_parts (utils/point_clouds.py:33-52).  rap_sample and the
+ * Procrustes entry points REQUIRE sum(points_per_part) == TP and, per sample, sum_p points_per_part[b][p] == cu_seqlens[b+1] -
+ * cu_seqlens[b]; they do not read anything back to check it (rap_sample clamps the part table to TP, so a malformed batch gives
+ * wrong poses, not an out-of-bounds access).  This entry point writes the verdict to a device int32: 0 = consistent; bit 0 sum
+ * != TP, bit 1 cu_seqlens ends, bit 2 cu_seqlens decreasing, bit 3 a sample's parts vs its span, bit 4 a negative size. */
+int rap_check_batch(const int64_t* points_per_part, const int32_t* cu_batch, int32_t B, int32_t P, int64_t TP, int32_t* flag_out,
+                    void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg) ----
  * When enabled, every attention and layer-GEMM launch inside rap_dit_forward / rap_sample is bracketed by two
  * hipEvents recorded on the launch stream.  rap_profile_collect synchronises on them and returns, per class
@@ -285,9 +303,9 @@ int rap_collate_transform(const void* points, int32_t points_are_f64, const int6
  * into HOST arrays of 3 entries.  Not thread-safe; off by default. */
 int rap_profile_enable(int on);
 /* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py): key 0 = fp32 GEMM {0: 128x128 v1, 2: pipelined
- * 128x128, 4: pipelined 128x256, 8: 256x128 8-wave, 16: LDS-DMA staged 128x128 (default), 32: LDS-DMA staged 256x256 8-wave}, key 1 = fp32 attention
+ * 128x128, 4: pipelined 128x256, 8: 256x128 8-wave, 16: LDS-DMA staged 128x128, 32: LDS-DMA staged 256x256 8-wave, 48: per shape (default)}, key 1 = fp32 attention
  * {1: 4-wave v1 (default), 3: pipelined, 5: 8-wave v1}, key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave (default),
- * 2: 256x128 8-wave, 3/4: ring-buffered}, key 3 = 16-bit attention schedule (0 default, see attn_h16.hip), key 4 = fp32 GEMM
+ * 2: 256x128 8-wave, 3/4: ring-buffered, 5: 128x512, 6-8: pipelined rings, 9-12: interleaved issue, 13-15: phase-split}, key 3 = 16-bit attention schedule (0 default, see attn_h16.hip), key 4 = fp32 GEMM
  * phase stagger {0 off, 1 by block index (default), 2 by CU id}, key 5 = split-KV attention for few-token calls {0 off, 1 on
  * (default)}, key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}.
  * All variants compute the same function. */

@@ -566,3 +566,46 @@ def transform_and_collate(samples, max_parts, seed):
     for k in ("rotations", "translations", "points_per_part", "anchor_parts", "init_rotation", "scales", "global_rotation", "global_translation"):
         res[k] = torch.stack([torch.from_numpy(np.asarray(o[k])) for o in outs], dim=0)
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# preprocessing in front of FPS / MiniSpinNet
+# ---------------------------------------------------------------------------------------------
+def remove_statistical_outlier(points, nb_neighbors=20, std_ratio=2.5):
+    """Open3D 0.18 PointCloud::RemoveStatisticalOutliers restated from its published source (the wheel is absent: PARITY UNPINNED;
+    call site dataset_process/extract_sample_features.py:378-385): KNN of every point in its own cloud (the point itself is the
+    first hit), mean of the sqrt distances; cloud mean over the positive ones divided by N; Bessel-corrected std; keep
+    0 < d < mean + std_ratio * std.  Returns (inlier indices ascending, mean distances float64)."""
+    import numpy as np
+    from scipy.spatial import cKDTree
+    p = np.asarray(points, dtype=np.float64)
+    n = len(p)
+    k = min(nb_neighbors, n)
+    d, _ = cKDTree(p).query(p, k=k)
+    d = d.reshape(n, k)
+    avg = d.sum(axis=1) / k
+    pos = avg > 0
+    mean = avg[pos].sum() / n
+    std = np.sqrt(((avg[pos] - mean) ** 2).sum() / (n - 1)) if n > 1 else 0.0
+    thr = mean + std_ratio * std
+    return np.nonzero(pos & (avg < thr))[0], avg
+
+
+def calculate_voxel_coverage(points, voxel_size):
+    """dataset_process/utils/point_sampling_utils.py:11-31 (numpy, float64 division like the reference)."""
+    import numpy as np
+    if len(points) == 0:
+        return 0
+    return len(np.unique(np.floor(np.asarray(points) / voxel_size).astype(int), axis=0))
+
+
+def calculate_adaptive_sample_count_per_part(parts_points, voxel_size, voxel_ratio, min_points_per_part, max_sample_points):
+    """point_sampling_utils.py:33-84."""
+    out = []
+    for pts in parts_points:
+        if len(pts) == 0:
+            out.append(0)
+            continue
+        c = int(calculate_voxel_coverage(pts, voxel_size) * voxel_ratio)
+        out.append(min(max_sample_points, min(len(pts), max(min_points_per_part, c))))
+    return out

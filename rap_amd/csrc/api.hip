@@ -21,7 +21,7 @@ static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
 static size_t g_prof_pool_used = 0;
-static const size_t RAP_PROF_MAX_EVENTS = 32768;
+static const size_t RAP_PROF_MAX_EVENTS = 1u << 19;   // 20 sample calls of rap_12 at 20 flow steps = 38 400 scopes = 76 800 events (r01: 32768 truncated the log)
 
 static hipEvent_t prof_event() {
   if (g_prof_pool_used < g_prof_pool.size()) return g_prof_pool[g_prof_pool_used++];
@@ -123,10 +123,16 @@ extern int g_rap_attn_split;     // attn_f32.hip
 extern int g_rap_gemm_h16_variant;   // gemm_h16.hip
 extern int g_rap_attn_h16_variant;   // attn_h16.hip
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
-  if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32)) { g_rap_gemm_variant = value; return RAP_OK; }
+  if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 48)) { g_rap_gemm_variant = value; return RAP_OK; }
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
   if (key == 2 && value >= 0 && value <= 15) { g_rap_gemm_h16_variant = value; return RAP_OK; }
-  if (key == 3 && value >= 0 && value <= 11) { g_rap_attn_h16_variant = value; return RAP_OK; }
+  if (key == 3 && value >= 0 && value <= 11) {
+#ifndef RAP_ABLATION_BUILD
+    // 1-3, 6, 7 are timing-only ablations ("NOT attention"): compiled out of the shipped library, refused here
+    if (value == 1 || value == 2 || value == 3 || value == 6 || value == 7) return RAP_ERR_INVALID;
+#endif
+    g_rap_attn_h16_variant = value; return RAP_OK;
+  }
   if (key == 4 && value >= 0 && value <= 2) { g_rap_gemm_stagger = value; return RAP_OK; }
   if (key == 5 && (value == 0 || value == 1)) { g_rap_attn_split = value; return RAP_OK; }
   if (key == 6 && (value == 0 || value == 1)) { g_rap_gemm_splitk = value; return RAP_OK; }
@@ -614,7 +620,7 @@ extern "C" int rap_sample(const rap_model* m, const float* cond, const float* fe
   const int T = (int)TP;
   const long n3 = (long)TP * 3;
   int rc;
-  if ((rc = launch_part_offsets(stream, points_per_part, np, w.part_offsets))) return rc;
+  if ((rc = launch_part_offsets(stream, points_per_part, np, w.part_offsets, (long)TP))) return rc;
   if ((rc = prepare_static(m, w, stream, cond, feat, scales, anchor, cu_batch, w.part_offsets, B, np, T))) return rc;
   // t is uniform over the batch inside the sampler (modeling.py:674), so the adaLN table is computed once for
   // ALL flow steps (row s = step s) instead of per sample per step.
@@ -1119,4 +1125,24 @@ extern "C" int rap_collate_transform(const void* points, int32_t points_are_f64,
   return launch_collate_transform((hipStream_t)stream, points, points_are_f64 ? 1 : 0, points_per_part, B, P, (long)TP, order, feat_in, F,
                                   cond, gt, feat_out, anchor_indices, part_indices, rotations, translations, scales, anchor_parts,
                                   global_translation, cu_seqlens, order_flag, ws);
+}
+
+// Consistency of a packed batch: see check_batch_kernel.  flag_out: device int32 (0 = consistent).
+extern "C" int rap_check_batch(const int64_t* points_per_part, const int32_t* cu_batch, int32_t B, int32_t P, int64_t TP,
+                               int32_t* flag_out, void* stream) {
+  if (!points_per_part || !cu_batch || !flag_out || B <= 0 || P <= 0 || TP < 0) return RAP_ERR_INVALID;
+  return launch_check_batch((hipStream_t)stream, points_per_part, cu_batch, B, P, (long)TP, flag_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// statistical outlier removal (preprocessing)
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t rap_outlier_workspace_bytes(int64_t N) { return N <= 0 ? 0 : outlier_workspace_bytes((long)N); }
+
+extern "C" int rap_statistical_outliers(const float* points, int64_t N, int32_t nb_neighbors, double std_ratio, int64_t* inlier_indices,
+                                        int32_t* count_out, double* stats_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!points || !inlier_indices || !count_out || N <= 0 || N > 0x7fffffffLL / 8 || nb_neighbors < 1 || nb_neighbors > 32 || !(std_ratio > 0.0))
+    return RAP_ERR_INVALID;
+  if (!ws || ws_bytes < outlier_workspace_bytes((long)N)) return RAP_ERR_WORKSPACE;
+  return launch_statistical_outliers((hipStream_t)stream, points, (long)N, nb_neighbors, std_ratio, inlier_indices, count_out, stats_out, ws);
 }

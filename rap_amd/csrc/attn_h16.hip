@@ -481,13 +481,15 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
   hipLaunchKernelGGL((attention_h16_kernel<DTV, ABLV, OPTV>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound)
   if (dtype == RAP_DT_BF16) {
     switch (g_rap_attn_h16_variant) {
+#ifdef RAP_ABLATION_BUILD      // timing-only kernels whose output is NOT attention: never part of the shipped library
       case 1: HATT_LAUNCH(RAP_DT_BF16, 1, 0); break;
       case 2: HATT_LAUNCH(RAP_DT_BF16, 2, 0); break;
       case 3: HATT_LAUNCH(RAP_DT_BF16, 3, 0); break;
-      case 4: HATT_LAUNCH(RAP_DT_BF16, 0, 7); break;     // + s_setprio(1) around the MFMA clusters
-      case 5: HATT_LAUNCH(RAP_DT_BF16, 0, 3); break;     // max3 + deferred rescale
       case 6: HATT_LAUNCH(RAP_DT_BF16, 8, 3); break;     // ... without transcendentals
       case 7: HATT_LAUNCH(RAP_DT_BF16, 32, 3); break;    // ... without the max chain
+#endif
+      case 4: HATT_LAUNCH(RAP_DT_BF16, 0, 7); break;     // + s_setprio(1) around the MFMA clusters
+      case 5: HATT_LAUNCH(RAP_DT_BF16, 0, 3); break;     // max3 + deferred rescale
       case 8: HATT_LAUNCH(RAP_DT_BF16, 0, 0); break;     // v1: fmaxf chain, rescale every tile
       default:
         if (bound && q_prescaled) HATT_LAUNCH(RAP_DT_BF16, 0, 24);

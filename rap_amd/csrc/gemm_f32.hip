@@ -828,8 +828,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(GemmParams p, 
 // tuning knob (rap_set_tuning key 0): 0 = v1 128x128, 2 = pipelined 128x128 (two 4-wave blocks per CU),
 // 4 = pipelined 128x256 (one 4-wave block per CU; N % 256 == 0, else falls back to 2),
 // 8 = pipelined 256x128, one 8-wave block per CU with a static priority split per SIMD pair,
-// 16 = LDS-DMA staged 128x128 (default).
-int g_rap_gemm_variant = 16;
+// 16 = LDS-DMA staged 128x128, 32 = LDS-DMA staged 256x256 (8 waves, one block per CU),
+// 48 = per shape (default, r02): the 256x256 kernel where r01 run 54 measured it faster -- wide outputs at K <= 512 (qkv 111 -> 115 TF,
+// ff1 123 -> 126) -- and the 128x128 kernel elsewhere (out-projection 105 vs 91, ff2 132 vs 127, embedding, head).
+int g_rap_gemm_variant = 48;
 
 template <int EPI>
 static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int variant) {
@@ -864,7 +866,8 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
   if (p.M <= 0) return RAP_OK;
   if (p.N % GBN != 0 || p.K % GBK != 0 || p.K <= 0) return RAP_ERR_INVALID;
   if ((p.lda & 3) || (p.ldw & 3)) return RAP_ERR_INVALID;
-  const int v = g_rap_gemm_variant;
+  int v = g_rap_gemm_variant;
+  if (v == 48) v = (p.N >= 1536 && p.N % 256 == 0 && p.K <= 512 && (long)((p.M + 255) / 256) * (p.N / 256) >= 512) ? 32 : 16;
   if (epilogue == EPI_BIAS_RESID && (v == 16 || v == 32) && p.splitk_ws && g_rap_gemm_splitk && p.K >= 1024 && (p.ldr & 3) == 0 && (p.ldc & 3) == 0 &&
       (long)((p.M + GBM - 1) / GBM) * (p.N / GBN) <= 128) {
     const int splits = 4;

@@ -164,6 +164,61 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
   }
 }
 
+// ---------------- fused q / k epilogue of EPI_H_QKV_NORM (swapped product) ----------------
+// acc[i][j][r] = C[mw + 32 i + l31][nw + 32 j + crow(r, hi)]: the lane owns token row mw + 32 i + l31 and, of the head's 64 columns,
+// those with bit 2 equal to hi.  MultiHeadRMSNorm (flow_model/norm.py:28-33: F.normalize(x, dim=-1) * gamma * sqrt(64)) needs the
+// row's sum of squares: 32 lane-local terms + the partner lane's (lane ^ 32, one v_permlane32_swap).  q additionally carries
+// q_mul / 8 (the attention kernel's pre-scaled form, see launch_qknorm_h16).  Output plane [c][h][m][64]: register groups 2t and
+// 2t+1 of the two half-waves are exchanged (v_permlane32_swap) so that a lane holds 8 CONSECUTIVE columns = one 16-byte store;
+// the four stores of a row tile cover whole 128-byte rows -- no LDS transpose.
+template <int DT, int TM>
+__device__ __forceinline__ void gemm_h16_qknorm_epilogue(const GemmParamsH& p, f32x16 (&acc)[TM][2], int mw, int nw, int lane) {
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int dmodel = p.heads * 64;
+  const int c = nw / dmodel;                      // 0 = q, 1 = k (wave-uniform)
+  const int h = (nw - c * dmodel) >> 6;
+  const float* gam = (c == 0 ? p.gamma_q : p.gamma_k) + h * 64;
+  const float mul = c == 0 ? p.q_mul : 8.0f;
+  float g[2][16];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[j][r] = gam[32 * j + mfma32_crow(r, hi)] * mul;
+  u16* plane = reinterpret_cast<u16*>(p.C) + ((size_t)(c * p.heads + h) * p.M) * 64;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ss = __builtin_fmaf(acc[i][j][r], acc[i][j][r], ss);
+    {
+      const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+      ss = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    const int m = mw + 32 * i + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float x[4], y[4];                          // groups 2t and 2t+1: columns 16t + 4hi + {0..3} and 16t + 8 + 4hi + {0..3}
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float vx = acc[i][j][8 * t + e] * inv * g[j][8 * t + e];
+          const float vy = acc[i][j][8 * t + 4 + e] * inv * g[j][8 * t + 4 + e];
+          const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(vx), __float_as_uint(vy), false, false);
+          x[e] = __uint_as_float(s2[0]); y[e] = __uint_as_float(s2[1]);
+        }
+        // hi = 0: x = own group 2t (cols 16t + 0..3), y = partner's group 2t (cols 16t + 4..7)      -> columns 16t + 0..7
+        // hi = 1: x = partner's group 2t+1 (cols 16t + 8..11), y = own group 2t+1 (cols 16t + 12..15) -> columns 16t + 8..15
+        const typename H16<DT>::T8 o8 = h16_pack8<DT>(x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]);
+        if (m < p.M) *reinterpret_cast<uint4*>(plane + (size_t)m * 64 + 32 * j + 16 * t + 8 * hi) = __builtin_bit_cast(uint4, o8);
+      }
+    }
+  }
+}
+
 template <int EPI, int DT, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16_kernel(GemmParamsH p) {
   typedef typename H16<DT>::T8 T8;
@@ -840,12 +895,24 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
     for (int ks = 0; ks < 4; ++ks)
       fb[ks] = *reinterpret_cast<const uint4*>(smem + buf * STAGE + ABYTES + (g * 128 + wc * 32 + l31) * 128 + (((2 * ks + hi) ^ sw) * 16));
   };
+  // EPI_H_QKV_NORM: the q and k column tiles run the SWAPPED product C^T = W A^T (the MFMA's A operand is the weight fragment): a lane
+  // then owns one token row and 16 of every 32 columns, so the row norm of a head is lane-local up to one lane^32 exchange and the
+  // 16-bit results leave as 16-byte row pieces without an LDS transpose.  The v tiles keep the normal order (the V^T image wants a
+  // lane to own a column).  Wave-uniform choice: a 64-column wave tile is one head of q, k or v.
+  const bool swp = EPI == EPI_H_QKV_NORM && (n0 + wc * 64) < 2 * p.heads * 64;
 #define PH_MMA(H, G, FB)                                                                                      \
   __builtin_amdgcn_sched_barrier(0);                                                                          \
   if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                    \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                          \
-    acc[2 * (H)][G] = H16<DT>::mfma(__builtin_bit_cast(T8, fa[0][ks]), __builtin_bit_cast(T8, FB[ks]), acc[2 * (H)][G]);         \
-    acc[2 * (H) + 1][G] = H16<DT>::mfma(__builtin_bit_cast(T8, fa[1][ks]), __builtin_bit_cast(T8, FB[ks]), acc[2 * (H) + 1][G]); \
+  if (swp) {                                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                        \
+      acc[2 * (H)][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[ks]), __builtin_bit_cast(T8, fa[0][ks]), acc[2 * (H)][G]);         \
+      acc[2 * (H) + 1][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[ks]), __builtin_bit_cast(T8, fa[1][ks]), acc[2 * (H) + 1][G]); \
+    }                                                                                                         \
+  } else {                                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                        \
+      acc[2 * (H)][G] = H16<DT>::mfma(__builtin_bit_cast(T8, fa[0][ks]), __builtin_bit_cast(T8, FB[ks]), acc[2 * (H)][G]);         \
+      acc[2 * (H) + 1][G] = H16<DT>::mfma(__builtin_bit_cast(T8, fa[1][ks]), __builtin_bit_cast(T8, FB[ks]), acc[2 * (H) + 1][G]); \
+    }                                                                                                         \
   }                                                                                                           \
   if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                    \
   __builtin_amdgcn_sched_barrier(0);
@@ -893,7 +960,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   static_assert(8 * H16_STG_BYTES <= 2 * STAGE, "staging slabs must fit the operand buffers");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
+  if constexpr (EPI == EPI_H_QKV_NORM) {
+    if (swp) gemm_h16_qknorm_epilogue<DT, TM>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+    else gemm_h16_epilogue<EPI_H_QKV, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
+  } else {
+    gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
+  }
 }
 
 template <int EPI, int DT, int PRIO, int STAG>
@@ -988,6 +1060,9 @@ static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
     case EPI_H_BIAS: return launch_variant<EPI_H_BIAS, DT>(stream, p);
     case EPI_H_BIAS_RESID_F32: return launch_variant<EPI_H_BIAS_RESID_F32, DT>(stream, p);
     case EPI_H_GEGLU: return launch_variant<EPI_H_GEGLU, DT>(stream, p);
+    case EPI_H_QKV_NORM:
+      if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256 || !p.gamma_q || !p.gamma_k || p.K < 128) return RAP_ERR_INVALID;
+      return launch_ph<EPI_H_QKV_NORM, DT, 0, 1>(stream, p);
     case EPI_H_QKV:
       if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256) return RAP_ERR_INVALID;
       return launch_variant<EPI_H_QKV, DT>(stream, p);

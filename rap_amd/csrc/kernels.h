@@ -87,7 +87,8 @@ int launch_rigid_apply(hipStream_t stream, const float* src, const float* R, con
                        float* traj_slot_or_null, int blend);
 // segment tables
 int launch_token_sample(hipStream_t stream, const int32_t* cu_batch, int B, int32_t* token_sample);
-int launch_part_offsets(hipStream_t stream, const int64_t* points_per_part, int nparts, int32_t* part_offsets);
+int launch_part_offsets(hipStream_t stream, const int64_t* points_per_part, int nparts, int32_t* part_offsets, long limit = -1);
+int launch_check_batch(hipStream_t stream, const int64_t* points_per_part, const int32_t* cu_batch, int B, int P, long TP, int32_t* flag);
 // weight packing helpers (model creation)
 int launch_copy_cols(hipStream_t stream, const float* src, int src_ld, int src_col0, float* dst, int dst_ld,
                      int dst_col0, int rows, int cols);
@@ -104,6 +105,8 @@ enum GemmEpilogueH {
   EPI_H_BIAS_RESID_F32 = 1,  // C fp32 (M,N) = (resid +) acc (+ bias[n])      (resid may alias C)
   EPI_H_GEGLU = 3,           // W rows pre-interleaved [32 value | 32 gate]: C half (M,N/2) = (h + bh) * gelu_erf(g + bg)
   EPI_H_QKV = 4,             // N = 3*H*64: q,k -> C half [2][H][M][64]; v -> vt half [H][vt_nblk][64 d][64 pos] (half.h vt_pos)
+  EPI_H_QKV_NORM = 5,        // EPI_H_QKV with MultiHeadRMSNorm (norm.py:28-33) fused: q,k rows are normalised from the fp32 accumulators,
+                             // multiplied by gamma and by q_mul / 8 before the single rounding to 16 bit (phase-split kernel only)
 };
 struct GemmParamsH {
   const uint16_t* A; int lda;
@@ -114,6 +117,7 @@ struct GemmParamsH {
   const float* resid; int ldr;
   int heads;
   uint16_t* vt; int vt_nblk;
+  const float* gamma_q = nullptr; const float* gamma_k = nullptr; float q_mul = 8.0f;   // EPI_H_QKV_NORM
 };
 int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p);
 int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t* dst, size_t n);
@@ -191,3 +195,8 @@ int launch_collate_transform(hipStream_t stream, const void* pts, int f64, const
                              const int64_t* order, const float* feat_in, int F, float* cond, float* gt, float* feat_out,
                              uint8_t* anchor_idx, int64_t* part_idx, float* rotations, float* translations, float* scales,
                              uint8_t* anchor_parts, float* global_translation, int64_t* cu_seqlens, int32_t* order_flag, void* ws);
+
+// statistical outlier removal (outlier.hip; Open3D remove_statistical_outlier as extract_sample_features.py:378-385 calls it)
+size_t outlier_workspace_bytes(long N);
+int launch_statistical_outliers(hipStream_t stream, const float* pts, long N, int nb_neighbors, double std_ratio, int64_t* idx_out,
+                                int32_t* count_out, double* stats_out, void* ws);

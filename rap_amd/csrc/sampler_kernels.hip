@@ -93,15 +93,48 @@ int launch_token_sample(hipStream_t stream, const int32_t* cu_batch, int B, int3
 
 // part_offsets[i] = sum_{i' < i} points_per_part.flat[i']   (B*P+1 entries; empty parts have zero length --
 // the reference drops them, modeling.py:219-222; zero-length segments are no-ops for every kernel here).
-__global__ void part_offsets_kernel(const int64_t* __restrict__ ppp, int nparts, int32_t* __restrict__ off) {
+__global__ void part_offsets_kernel(const int64_t* __restrict__ ppp, int nparts, int32_t* __restrict__ off, long limit) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int acc = 0;
+  // limit >= 0: no offset may pass the end of the point arrays (an inconsistent points_per_part then yields short / empty
+  // trailing segments -- wrong poses for a malformed batch, but never an out-of-bounds access; rap_check_batch names the defect)
+  long acc = 0;
   off[0] = 0;
-  for (int i = 0; i < nparts; ++i) { acc += (int)ppp[i]; off[i + 1] = acc; }
+  for (int i = 0; i < nparts; ++i) {
+    const long n = (long)ppp[i];
+    acc += n > 0 ? n : 0;
+    if (limit >= 0 && acc > limit) acc = limit;
+    off[i + 1] = (int)acc;
+  }
 }
 
-int launch_part_offsets(hipStream_t stream, const int64_t* points_per_part, int nparts, int32_t* part_offsets) {
-  hipLaunchKernelGGL(part_offsets_kernel, dim3(1), dim3(64), 0, stream, points_per_part, nparts, part_offsets);
+int launch_part_offsets(hipStream_t stream, const int64_t* points_per_part, int nparts, int32_t* part_offsets, long limit) {
+  hipLaunchKernelGGL(part_offsets_kernel, dim3(1), dim3(64), 0, stream, points_per_part, nparts, part_offsets, limit);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
+// Consistency of a packed batch (what the reference asserts in split_parts, utils/point_clouds.py:33-52): bit 0 sum(points_per_part)
+// != TP, bit 1 cu_seqlens[0] != 0 or cu_seqlens[B] != TP, bit 2 cu_seqlens not non-decreasing, bit 3 a sample's parts do not add
+// up to its cu_seqlens span, bit 4 a negative part size.
+__global__ void check_batch_kernel(const int64_t* __restrict__ ppp, const int32_t* __restrict__ cu, int B, int P, long TP,
+                                   int32_t* __restrict__ flag) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int f = 0;
+  long total = 0;
+  if (cu[0] != 0 || cu[B] != TP) f |= 2;
+  for (int b = 0; b < B; ++b) {
+    long s = 0;
+    for (int p = 0; p < P; ++p) { const long n = (long)ppp[(size_t)b * P + p]; if (n < 0) f |= 16; s += n; }
+    total += s;
+    if (cu[b + 1] < cu[b]) f |= 4;
+    if (s != (long)cu[b + 1] - (long)cu[b]) f |= 8;
+  }
+  if (total != TP) f |= 1;
+  *flag = f;
+}
+
+int launch_check_batch(hipStream_t stream, const int64_t* points_per_part, const int32_t* cu_batch, int B, int P, long TP, int32_t* flag) {
+  hipLaunchKernelGGL(check_batch_kernel, dim3(1), dim3(64), 0, stream, points_per_part, cu_batch, B, P, TP, flag);
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }

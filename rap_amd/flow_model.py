@@ -8,6 +8,7 @@ PyTorch is used for device memory and the current stream only.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 
 import torch
@@ -37,6 +38,9 @@ def _require_cuda(t: torch.Tensor, name: str) -> None:
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.float32).contiguous()
+
+
+_IncompatibleKeys = collections.namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])   # torch.nn.Module's return type
 
 
 class PointCloudDiT:
@@ -91,22 +95,27 @@ class PointCloudDiT:
         return dict(self._sd)
 
     def load_state_dict(self, state_dict: dict, strict: bool = True):
-        """Same key/shape contract as the reference module; ``strict`` as in nn.Module."""
+        """nn.Module contract (the reference's load_checkpoint_for_module relies on it, utils/checkpoint.py:13-61): returns
+        ``(missing_keys, unexpected_keys)``; with ``strict=True`` any missing or unexpected key raises, with ``strict=False``
+        missing tensors keep their previous value (the model cannot be used until every tensor has been supplied once)."""
         names = [n for n, _ in self._spec]
+        known = set(names)
         missing = [n for n in names if n not in state_dict]
-        unexpected = [k for k in state_dict if k not in set(names)]
-        if missing or (strict and unexpected):
+        unexpected = [k for k in state_dict if k not in known]
+        if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for PointCloudDiT: missing {missing[:4]}..., "
                                f"unexpected {unexpected[:4]}...")
-        sd = {}
+        sd = dict(self._sd) if self._sd is not None else {}
         for n, shape in self._spec:
+            if n not in state_dict:
+                continue
             t = state_dict[n]
             if tuple(t.shape) != tuple(shape):
                 raise RuntimeError(f"size mismatch for {n}: {tuple(t.shape)} vs {shape}")
             sd[n] = t.detach().to(torch.float32)
         self._sd = sd
         self._release()
-        return self
+        return _IncompatibleKeys(missing, unexpected)
 
     def to(self, device):
         device = torch.device(device)
@@ -138,6 +147,9 @@ class PointCloudDiT:
             return
         if self._sd is None:
             raise _lib.RapError("load_state_dict() must be called before the model is used")
+        absent = [n for n, _ in self._spec if n not in self._sd]
+        if absent:
+            raise _lib.RapError(f"weights never loaded for {absent[:4]}... ({len(absent)} tensors): load_state_dict(strict=False) left them out")
         self._release()
         lib = _lib.load()
         with torch.cuda.device(device):

@@ -9,6 +9,8 @@ the path syncs with the host.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -20,7 +22,8 @@ class RectifiedPointFlow:
 
     def __init__(self, flow_model: PointCloudDiT = None, inference_sampling_steps: int = 20,
                  inference_sampler: str = "euler", n_generations: int = 1, rigidity_forcing: bool = False,
-                 return_end_point_trajectory: bool = True, encoder_on: bool = False, **_ignored):
+                 return_end_point_trajectory: bool = True, encoder_on: bool = False, validate_inputs: bool | None = None,
+                 **_ignored):
         if flow_model is None:
             raise ValueError("flow_model is required")            # modeling.py:80-81
         if encoder_on:
@@ -34,6 +37,9 @@ class RectifiedPointFlow:
         self.rigidity_forcing = rigidity_forcing
         self.return_end_point_trajectory = return_end_point_trajectory
         self.last_poses = None
+        # the reference asserts the batch layout in split_parts (utils/point_clouds.py:33-52) -- with a host sync per call; here
+        # the check is a device kernel + one 4-byte read, off by default (RAP_VALIDATE_INPUTS=1 or validate_inputs=True turns it on)
+        self.validate_inputs = (os.environ.get("RAP_VALIDATE_INPUTS") == "1") if validate_inputs is None else bool(validate_inputs)
 
     # modeling.py:203-231 without the boolean-mask compaction (which syncs): empty parts stay in the table as
     # zero-length segments, which every kernel treats as a no-op and which yields the same zero R,t rows.
@@ -62,6 +68,14 @@ class RectifiedPointFlow:
         model = self.flow_model
         model._activate(device)
         lib = _lib.load()
+        if self.validate_inputs:
+            flag = torch.zeros(1, dtype=torch.int32, device=device)
+            _lib.check(lib.rap_check_batch(_lib.ptr(d["ppp"]), _lib.ptr(d["cu_batch"]), B, P, TP, _lib.ptr(flag),
+                                           _lib.current_stream(device)), "rap_check_batch")
+            bits = int(flag.item())
+            if bits:
+                raise ValueError(f"inconsistent batch (flags {bits:#x}): sum(points_per_part) must equal the number of points and "
+                                 "match cu_seqlens per sample (reference: split_parts, utils/point_clouds.py:33-52)")
         traj_x0 = torch.empty((S, TP, 3), dtype=torch.float32, device=device)     # sampler.py:47-49
         traj_xt = torch.empty((S, TP, 3), dtype=torch.float32, device=device)
         R = torch.empty((B, P, 3, 3), dtype=torch.float32, device=device)

@@ -79,3 +79,49 @@ def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float) -> torch.Te
                                       _lib.ptr(ws), ws.numel(), stream)
     _lib.check(rc, "rap_voxel_downsample")
     return idx[: int(count.cpu())]
+
+
+def remove_statistical_outlier(points: torch.Tensor, nb_neighbors: int = 20, std_ratio: float = 2.5):
+    """Open3D ``PointCloud.remove_statistical_outlier(nb_neighbors, std_ratio)`` as extract_sample_features.py:378-385 calls it:
+    returns ``(points[inlier_indices], inlier_indices)`` -- the filtered cloud and the ascending int64 indices of the kept points.
+    Rule (Open3D's published algorithm; the wheel is not in the reference mount: parity unpinned): a point is kept iff the mean
+    distance d to its ``nb_neighbors`` nearest points (itself included) satisfies 0 < d < mean(d) + std_ratio * std(d)."""
+    _require_cuda(points, "points")
+    device = points.device
+    pts = _f32c(points)
+    N = pts.shape[0]
+    if N == 0:
+        return pts, torch.zeros(0, dtype=torch.int64, device=device)
+    lib = _lib.load()
+    idx = torch.empty(N, dtype=torch.int64, device=device)
+    count = torch.empty(1, dtype=torch.int32, device=device)
+    ws = torch.empty(lib.rap_outlier_workspace_bytes(N), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        rc = lib.rap_statistical_outliers(_lib.ptr(pts), N, int(nb_neighbors), float(std_ratio), _lib.ptr(idx), _lib.ptr(count), _lib.ptr(None),
+                                          _lib.ptr(ws), ws.numel(), _lib.current_stream(device))
+    _lib.check(rc, "rap_statistical_outliers")
+    idx = idx[: int(count.cpu())]                       # the caller needs the size (Open3D returns a list)
+    return pts[idx], idx
+
+
+def calculate_voxel_coverage(points: torch.Tensor, voxel_size: float) -> int:
+    """point_sampling_utils.py:11-31: number of distinct voxels floor(p / voxel_size) the cloud occupies -- the size of the index list
+    the voxel down-sampling kernel returns (one kept point per occupied voxel)."""
+    if points.shape[0] == 0:
+        return 0
+    return int(voxel_down_sample_torch(points, voxel_size).numel())
+
+
+def calculate_adaptive_sample_count_per_part(parts_points, voxel_size: float, voxel_ratio: float, min_points_per_part: int,
+                                             max_sample_points: int) -> list[int]:
+    """point_sampling_utils.py:33-84: per part min(max(min_points_per_part, int(occupied_voxels * voxel_ratio)), n_points,
+    max_sample_points); 0 for an empty part."""
+    out = []
+    for p in parts_points:
+        n = int(p.shape[0])
+        if n == 0:
+            out.append(0)
+            continue
+        c = int(calculate_voxel_coverage(p, voxel_size) * voxel_ratio)
+        out.append(min(max_sample_points, min(n, max(min_points_per_part, c))))
+    return out

@@ -75,17 +75,23 @@ class MiniSpinNet:
         self._device = None
 
     def load_state_dict(self, state_dict: dict, strict: bool = True):
+        """nn.Module contract: returns (missing_keys, unexpected_keys); strict=False keeps previous values of missing tensors."""
+        from .flow_model import _IncompatibleKeys
         names = [n for n, _ in self._spec]
         missing = [n for n in names if n not in state_dict]
         unexpected = [k for k in state_dict if k not in set(names) and not k.endswith("num_batches_tracked")]
-        if missing or (strict and unexpected):
+        if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for MiniSpinNet: missing {missing[:4]}, unexpected {unexpected[:4]}")
+        sd = dict(self._sd) if getattr(self, "_sd", None) else {}
         for n, shape in self._spec:
+            if n not in state_dict:
+                continue
             if tuple(state_dict[n].shape) != tuple(shape):
                 raise RuntimeError(f"size mismatch for {n}: {tuple(state_dict[n].shape)} vs {shape}")
-        self._sd = {n: state_dict[n].detach().to(torch.float32) for n in names}
+            sd[n] = state_dict[n].detach().to(torch.float32)
+        self._sd = sd
         self._release()
-        return self
+        return _IncompatibleKeys(missing, unexpected)
 
     def eval(self):
         return self
@@ -115,7 +121,7 @@ class MiniSpinNet:
     def _ensure(self, device):
         if self._handle and self._device == device:
             return
-        if self._sd is None:
+        if self._sd is None or any(n not in self._sd for n, _ in self._spec):
             raise _lib.RapError("load_state_dict() must be called before the model is used")
         self._release()
         lib = _lib.load()

@@ -336,3 +336,44 @@ def test_oracle_transform_and_collate_matches_live_reference():
             assert (r - g).abs().max().item() <= 1e-6 * max(1.0, r.abs().max().item()), k
         else:
             assert torch.equal(r, g), k
+
+
+# ---------------------------------------------------------------------------------------------
+# preprocessing in front of FPS / MiniSpinNet: voxel-adaptive sample counts (pinned), statistical outlier removal (unpinned)
+# ---------------------------------------------------------------------------------------------
+def adaptive_parts():
+    g = np.random.RandomState(5)
+    return [g.rand(4000, 3) * np.array([20, 15, 3.0]), g.rand(37, 3), np.zeros((0, 3)), g.rand(900, 3) * np.array([4, 4, 1.0]) - 2.0]
+
+
+ADAPTIVE_EXPECTED = ([1500, 37, 0, 309], [3856, 30, 0, 618])     # counts / occupied voxels printed by the reference's own functions
+
+
+def test_oracle_adaptive_sample_count_matches_reference_values():
+    parts = adaptive_parts()
+    assert O.calculate_adaptive_sample_count_per_part(parts, 0.25, 0.5, 50, 1500) == ADAPTIVE_EXPECTED[0]
+    assert [O.calculate_voxel_coverage(p, 0.25) for p in parts] == ADAPTIVE_EXPECTED[1]
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
+def test_oracle_adaptive_sample_count_matches_live_reference():
+    import importlib, sys
+    ref_loader.load_reference_dataset_utils(); ref_loader._install_pytorch3d_import_stub()
+    sys.modules["pytorch3d.ops"].sample_farthest_points = None
+    m = importlib.import_module("dataset_process.utils.point_sampling_utils")
+    parts = adaptive_parts()
+    for vs, ratio, mn, mx in ((0.25, 0.5, 50, 1500), (1.0, 2.0, 10, 100), (0.05, 0.1, 5, 5000)):
+        assert O.calculate_adaptive_sample_count_per_part(parts, vs, ratio, mn, mx) == m.calculate_adaptive_sample_count_per_part(parts, vs, ratio, mn, mx)
+
+
+def test_oracle_statistical_outlier_rule_on_a_known_case():
+    """Analytic check of the restated Open3D rule: a regular 10 x 10 x 1 grid (spacing 1) plus one far point -- only the far point
+    has a mean neighbour distance beyond mean + 2.5 std, and duplicated points (d = 0 with k = 2) are dropped by the d > 0 test."""
+    xs, ys = np.meshgrid(np.arange(10.0), np.arange(10.0))
+    grid = np.stack([xs.ravel(), ys.ravel(), np.zeros(100)], axis=1)
+    pts = np.concatenate([grid, [[50.0, 50.0, 0.0]]])
+    idx, avg = O.remove_statistical_outlier(pts, nb_neighbors=5, std_ratio=2.5)
+    assert list(idx) == list(range(100)) and avg[100] > 40
+    dup = np.concatenate([grid, grid[:1]])                       # point 0 twice: with k = 2 both copies see only each other -> d = 0
+    idx2, avg2 = O.remove_statistical_outlier(dup, nb_neighbors=2, std_ratio=10.0)
+    assert avg2[0] == 0 and avg2[100] == 0 and 0 not in idx2 and 100 not in idx2

@@ -444,3 +444,24 @@ def test_few_token_split_attention_matches_unsplit(dev):
     assert not torch.equal(out["trajectory"], ref["trajectory"])        # the split path really ran (different summation order)
     gold = O.sample(sd, cfg, inp, 3, True)
     assert (out["end_point_trajectory"].cpu() - gold["end_point_trajectory"]).abs().max().item() < 5e-5
+
+
+def test_inconsistent_batch_is_reported_and_never_reads_out_of_bounds(dev):
+    """sum(points_per_part) != TP used to give out-of-bounds part offsets.  rap_sample now clamps the part table to TP
+    and rap_check_batch (validate_inputs=True) names the defect like the reference's split_parts assert does."""
+    cfg, sd, model = get_model(2, 0, dev)
+    inp = S.make_inputs([[64, 96], [128, 40]], seed=3)
+    d = to_dev(inp, dev)
+    bad = dict(d); bad["points_per_part"] = d["points_per_part"].clone(); bad["points_per_part"][1, 1] += 50      # 50 points too many
+    strict = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=2, rigidity_forcing=True, validate_inputs=True)
+    with pytest.raises(ValueError, match="inconsistent batch"):
+        strict.sample_and_register(bad, x_1=d["x_1"])
+    out = strict.sample_and_register(d, x_1=d["x_1"])                       # the consistent batch passes the check
+    assert torch.isfinite(out["end_point_trajectory"]).all()
+    lax = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=2, rigidity_forcing=True)
+    out_bad = lax.sample_and_register(bad, x_1=d["x_1"])                    # unchecked: runs on the clamped table, no fault
+    torch.cuda.synchronize()
+    assert out_bad["end_point_trajectory"].shape == out["end_point_trajectory"].shape
+    # the parts before the defect are untouched by it
+    n0 = 64 + 96
+    assert torch.equal(out_bad["end_point_trajectory"][:, :n0], out["end_point_trajectory"][:, :n0])

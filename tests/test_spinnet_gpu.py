@@ -136,3 +136,39 @@ def test_voxel_downsample_matches_reference_golden_and_oracle(dev):
     assert (key[idx][1:] > key[idx][:-1]).all()                                     # ascending voxel keys, one per voxel
     with pytest.raises(ValueError):
         voxel_down_sample_torch(torch.tensor([[0.0, 0.0, 0.0], [1e4, 1e4, 1e4]], device=dev), 1e-3)      # 1e7^3 slots
+
+
+# ---------------------------------------------------------------------------------------------
+# preprocessing in front of the descriptor: statistical outlier removal and the voxel-adaptive per-part sample count
+# ---------------------------------------------------------------------------------------------
+def test_statistical_outlier_removal_matches_the_restated_open3d_rule():
+    import numpy as np
+    from oracle import rap_oracle as O
+    from rap_amd.point_sampling import remove_statistical_outlier
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    surf = torch.rand(6000, 3, generator=g) * torch.tensor([12.0, 9.0, 0.0]); surf[:, 2] = 0.4 * torch.sin(surf[:, 0])
+    noise = torch.rand(150, 3, generator=g) * torch.tensor([12.0, 9.0, 6.0]) + torch.tensor([0.0, 0.0, 1.0])      # floating outliers
+    pts = torch.cat([surf, noise])[torch.randperm(6150, generator=g)]
+    for k, ratio in ((20, 2.5), (8, 1.0), (32, 3.0)):
+        filt, idx = remove_statistical_outlier(pts.to(dev), nb_neighbors=k, std_ratio=ratio)
+        ref_idx, avg = O.remove_statistical_outlier(pts.numpy(), k, ratio)
+        mean = avg[avg > 0].sum() / len(avg); std = np.sqrt(((avg[avg > 0] - mean) ** 2).sum() / (len(avg) - 1)); thr = mean + ratio * std
+        got = set(idx.cpu().tolist()); want = set(ref_idx.tolist())
+        # fp32 pair distances on the device vs float64 in the restated rule: only points within 1e-4 (relative) of the threshold may differ
+        edge = set(np.nonzero(np.abs(avg - thr) < 1e-4 * thr)[0].tolist())
+        assert (got ^ want) <= edge, (k, ratio, sorted(got ^ want)[:5])
+        assert torch.equal(filt.cpu(), pts[idx.cpu()])
+        assert idx.cpu().tolist() == sorted(idx.cpu().tolist())
+        assert 0 < len(got) < 6150 and len(want - got) <= len(edge)
+    few, idx_few = remove_statistical_outlier(pts[:5].to(dev), nb_neighbors=20)       # fewer points than neighbours: k = N
+    assert idx_few.numel() <= 5
+
+
+def test_adaptive_sample_count_matches_the_reference_values():
+    from test_oracle import ADAPTIVE_EXPECTED, adaptive_parts
+    from rap_amd.point_sampling import calculate_adaptive_sample_count_per_part, calculate_voxel_coverage
+    dev = torch.device("cuda:0")
+    parts = [torch.from_numpy(p).float().to(dev) for p in adaptive_parts()]
+    assert [calculate_voxel_coverage(p, 0.25) for p in parts] == ADAPTIVE_EXPECTED[1]
+    assert calculate_adaptive_sample_count_per_part(parts, 0.25, 0.5, 50, 1500) == ADAPTIVE_EXPECTED[0]
