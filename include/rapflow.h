@@ -247,6 +247,13 @@ int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda
  * (p = exp(s - B), no running maximum; bf16 only -- other dtypes ignore it).  Same softmax, different evaluation order.
  * (Inside rap_sample / rap_dit_forward the bf16 path additionally has qk-norm write q pre-scaled by log2(e)/8 and drops the
  * offset: p = exp2(q'.k); this entry point keeps the un-scaled q convention.) */
+/* The QKV projection with the reference's MultiHeadRMSNorm (flow_model/norm.py:28-33) fused into its epilogue -- what rap_sample /
+ * rap_dit_forward run in the 16-bit modes (tuning key 7 = 0 restores GEMM + rap_qknorm_h16): q, k rows are normalised from the fp32
+ * accumulators, multiplied by gamma and by q_mul (q) or 8 (k), then rounded ONCE to 16 bit into qk_out [2][H][M][64]; v goes to the
+ * transposed image vt exactly as epilogue 4 of rap_gemm_h16.  N = 3 * heads * 64, K % 64 == 0, K >= 128. */
+int rap_gemm_h16_qkvnorm(int32_t dtype, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, uint16_t* qk_out, int32_t M,
+                         int32_t K, int32_t heads, const float* gamma_q, const float* gamma_k, float q_mul, uint16_t* vt,
+                         int32_t vt_nblk, void* stream);
 int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk, const int32_t* cu_seqlens,
                       int32_t nseg, uint16_t* out, int64_t TP, int32_t heads, const float* logit_bound, void* ws,
                       size_t ws_bytes, void* stream);
@@ -307,7 +314,8 @@ int rap_profile_enable(int on);
  * {1: 4-wave v1 (default), 3: pipelined, 5: 8-wave v1}, key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave (default),
  * 2: 256x128 8-wave, 3/4: ring-buffered, 5: 128x512, 6-8: pipelined rings, 9-12: interleaved issue, 13-15: phase-split}, key 3 = 16-bit attention schedule (0 default, see attn_h16.hip), key 4 = fp32 GEMM
  * phase stagger {0 off, 1 by block index (default), 2 by CU id}, key 5 = split-KV attention for few-token calls {0 off, 1 on
- * (default)}, key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}.
+ * (default)}, key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}, key 7 = 16-bit path: qk-norm fused
+ * into the QKV GEMM epilogue {1 (default)} or as its own kernel {0}.
  * All variants compute the same function. */
 int rap_set_tuning(int32_t key, int32_t value);
 int rap_profile_reset(void);

@@ -122,11 +122,12 @@ extern int g_rap_attn_variant;   // attn_f32.hip
 extern int g_rap_attn_split;     // attn_f32.hip
 extern int g_rap_gemm_h16_variant;   // gemm_h16.hip
 extern int g_rap_attn_h16_variant;   // attn_h16.hip
+int g_rap_fuse_qknorm = 1;            // tuning key 7: 16-bit path, qk-norm fused into the QKV GEMM epilogue (1, default) or as its own kernel (0)
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 48)) { g_rap_gemm_variant = value; return RAP_OK; }
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
   if (key == 2 && value >= 0 && value <= 15) { g_rap_gemm_h16_variant = value; return RAP_OK; }
-  if (key == 3 && value >= 0 && value <= 11) {
+  if (key == 3 && value >= 0 && value <= 12) {
 #ifndef RAP_ABLATION_BUILD
     // 1-3, 6, 7 are timing-only ablations ("NOT attention"): compiled out of the shipped library, refused here
     if (value == 1 || value == 2 || value == 3 || value == 6 || value == 7) return RAP_ERR_INVALID;
@@ -136,6 +137,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 4 && value >= 0 && value <= 2) { g_rap_gemm_stagger = value; return RAP_OK; }
   if (key == 5 && (value == 0 || value == 1)) { g_rap_attn_split = value; return RAP_OK; }
   if (key == 6 && (value == 0 || value == 1)) { g_rap_gemm_splitk = value; return RAP_OK; }
+  if (key == 7 && (value == 0 || value == 1)) { g_rap_fuse_qknorm = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 
@@ -423,10 +425,17 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         GemmParamsH g{};
         g.A = w.xnh; g.lda = d; g.W = lh.Wqkv[a]; g.ldw = d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
         g.vt = w.vth; g.vt_nblk = w.vt_nblk;
-        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV, g); }
-        if (rc) return rc;
         const bool prescale = attention_h16_wants_prescaled_q(dt, m->bounded_ok) && g_rap_attn_h16_variant != 9;
-        if ((rc = launch_qknorm_h16(stream, dt, w.qkh, TP, H, lw.gq[a], lw.gk[a], prescale ? RAP_QMUL_PRESCALED : 8.0f))) return rc;
+        if (g_rap_fuse_qknorm) {
+          // qk-norm in the QKV epilogue: one kernel, q / k normalised from the fp32 accumulators (no 16-bit round trip through HBM)
+          g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; g.q_mul = prescale ? RAP_QMUL_PRESCALED : 8.0f;
+          { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV_NORM, g); }
+          if (rc) return rc;
+        } else {
+          { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV, g); }
+          if (rc) return rc;
+          if ((rc = launch_qknorm_h16(stream, dt, w.qkh, TP, H, lw.gq[a], lw.gk[a], prescale ? RAP_QMUL_PRESCALED : 8.0f))) return rc;
+        }
         {
           ProfScope ps(stream, a);
           const float* bound = m->bounded_ok ? m->logit_bound + (size_t)j * H : nullptr;
@@ -1145,4 +1154,15 @@ extern "C" int rap_statistical_outliers(const float* points, int64_t N, int32_t 
     return RAP_ERR_INVALID;
   if (!ws || ws_bytes < outlier_workspace_bytes((long)N)) return RAP_ERR_WORKSPACE;
   return launch_statistical_outliers((hipStream_t)stream, points, (long)N, nb_neighbors, std_ratio, inlier_indices, count_out, stats_out, ws);
+}
+
+// QKV projection with MultiHeadRMSNorm fused into the epilogue (EPI_H_QKV_NORM): see rapflow.h
+extern "C" int rap_gemm_h16_qkvnorm(int32_t dtype, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, uint16_t* qk_out,
+                                    int32_t M, int32_t K, int32_t heads, const float* gamma_q, const float* gamma_k, float q_mul,
+                                    uint16_t* vt, int32_t vt_nblk, void* stream) {
+  if (!A || !W || !qk_out || !gamma_q || !gamma_k || !vt || heads <= 0) return RAP_ERR_INVALID;
+  GemmParamsH g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = qk_out; g.M = M; g.N = 3 * heads * 64; g.K = K; g.heads = heads;
+  g.vt = vt; g.vt_nblk = vt_nblk; g.gamma_q = gamma_q; g.gamma_k = gamma_k; g.q_mul = q_mul;
+  return launch_gemm_h16((hipStream_t)stream, dtype, EPI_H_QKV_NORM, g);
 }

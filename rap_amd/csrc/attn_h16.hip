@@ -451,6 +451,178 @@ __global__ __launch_bounds__(512, 4) void attention_h16_pp_kernel(const u16* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined bounded-softmax kernel (r02; rap_set_tuning(3, 12), NOT the default).  MEASURED (r02 calls 12 / 13): 817 / 922 TF vs
+// 866 / 970 for the r01 kernel -- per WAVE it is 1.65x more efficient (SQ_WAVE_CYCLES 7.7e9 vs 12.7e9 for the same two launches), but its
+// 194 VGPRs (two score sets + prefetched fragments) allow one 8-wave block per CU where the r01 kernel (122 VGPRs) runs two, and four
+// waves per SIMD hide more than the in-wave overlap buys.  The counters say what bounds both: 7.3 VALU + 1 LDS + ~1 scalar instruction
+// per MFMA against the ~5 that fit into the shadow of a 32-cycle MFMA (matrix pipe 44 % busy, VALU issue 52 %, LDS 10 %).  Kept as the
+// A/B evidence for that statement and as the base for a 64-query-per-wave version (half the fragment reads per MFMA).
+// PMC on the r01 kernel: 43 % of the matrix peak with the VALU softmax and the two MFMA groups of a key tile strictly
+// one after the other inside a wave -- and both waves of a SIMD in the same phase after every barrier.  Here a wave overlaps them
+// itself: while the matrix pipe works on S(i+1) = K(i+1) Q^T and O += V(i)^T P(i), the wave issues the exponentials / conversions /
+// row sums of tile i in the shadow of those MFMAs.  One key tile = four QUARTERS, each
+//     2 MFMAs of S(i+1) (d-chunk ks)  |  8 v_exp_f32 + 4 v_cvt_pk + adds of P(i) columns 16 ks .. 16 ks + 15  |  2 MFMAs of O += V(i) P(i)
+// pinned with sched_barrier(0); the fragment reads of a quarter are issued one quarter ahead.  S lives in two register sets that swap
+// roles every tile (the loop body is instantiated twice).  LDS: K(i+1), V(i) being read while K(i+2), V(i+1) are parked for the next
+// iteration (both double-buffered, one barrier per tile as before).  Bounded softmax only: p = exp2(score) (PRE: q pre-scaled by
+// log2(e)/8, no offset) or p = exp2((s - 8 B) c); no running maximum, no rescale, so nothing in the tile depends on the previous one
+// except O and the row sum.
+// ---------------------------------------------------------------------------------------------
+template <int DT, int PRE>
+__global__ __launch_bounds__(512, 2) void attention_h16_sp_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
+                                                                  int vt_nblk, u16* __restrict__ out, int TP, int heads,
+                                                                  const AttnWorkItem* __restrict__ items,
+                                                                  const float* __restrict__ bound) {
+  typedef typename H16<DT>::T8 T8;
+  __shared__ __attribute__((aligned(16))) u16 smem[4 * HKV * HLD];
+  u16* Ks = smem;                    // [2][64 keys][72]
+  u16* Vs = smem + 2 * HKV * HLD;    // [2][64 d][72]
+
+  const int head = blockIdx.x % heads;
+  const AttnWorkItem it = items[blockIdx.x / heads];
+  const int len = it.seg_len;
+  if (len <= 0) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int seg0 = it.seg_start, seg1 = it.seg_start + len;
+
+  const u16* Qg = qk + (size_t)head * TP * 64;
+  const u16* Kg = qk + (size_t)(heads + head) * TP * 64;
+  const u16* Vg = vt + (size_t)head * vt_nblk * (64 * 64);
+
+  const int qw0 = it.q0 + wave * 32;
+  const bool wave_active = qw0 < len;
+
+  T8 qf[4];
+  {
+    int q = qw0 + l31;
+    q = q < len ? q : len - 1;
+    const u16* qp = Qg + (size_t)(seg0 + q) * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(qp + 16 * s));
+  }
+  f32x16 o0, o1, sa0, sa1, sb0, sb1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; sa0[r] = 0.f; sa1[r] = 0.f; sb0[r] = 0.f; sb1[r] = 0.f; }
+  const float c = 0.125f * 1.44269504088896340736f;
+  const float nmc = PRE ? 0.f : -bound[head] * 8.0f * c;
+  f32x2 psq[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+  const int srow = tid >> 3, sch = (tid & 7) * 8;
+  const int b_first = seg0 >> 6;
+  const int ntile = ((seg1 - 1) >> 6) - b_first + 1;
+  const int soff = srow * HLD + sch;
+  uint4 rk, rv;
+  // prologue: K(0), K(1), V(0) into the LDS
+  {
+    int tok = b_first * 64 + srow; tok = tok < TP ? tok : TP - 1;
+    *reinterpret_cast<uint4*>(Ks + soff) = *reinterpret_cast<const uint4*>(Kg + (size_t)tok * 64 + sch);
+    tok = (b_first + 1) * 64 + srow; tok = tok < TP ? tok : TP - 1;
+    *reinterpret_cast<uint4*>(Ks + HKV * HLD + soff) = *reinterpret_cast<const uint4*>(Kg + (size_t)tok * 64 + sch);
+    *reinterpret_cast<uint4*>(Vs + soff) = *reinterpret_cast<const uint4*>(Vg + ((size_t)b_first * 64 + srow) * 64 + sch);
+  }
+  __syncthreads();
+  const int lrow = l31 * HLD + 8 * hi;
+  if (wave_active) {                          // S(0) = K(0) Q^T (not overlapped: once per block)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const T8 k0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(Ks + lrow + 16 * s));
+      const T8 k1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(Ks + lrow + 32 * HLD + 16 * s));
+      sa0 = H16<DT>::mfma(k0, qf[s], sa0);
+      sa1 = H16<DT>::mfma(k1, qf[s], sa1);
+    }
+  }
+#define SP_SB __builtin_amdgcn_sched_barrier(0);
+  // exponentials of 8 scores (registers RB .. RB+7 of SC) -> the 16-bit B operand of one P*V step; row sum into ps2
+#define SP_EXP8(SC, RB, PB, PS)                                                                          \
+  {                                                                                                  \
+    float e_[8];                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                  \
+      const float a_ = PRE ? SC[(RB) + u] : __builtin_fmaf(SC[(RB) + u], c, nmc);                    \
+      e_[u] = __builtin_amdgcn_exp2f(a_);                                                            \
+    }                                                                                                \
+    PB = h16_pack8<DT>(e_[0], e_[1], e_[2], e_[3], e_[4], e_[5], e_[6], e_[7]);                      \
+    PS += (f32x2{e_[0], e_[1]} + f32x2{e_[2], e_[3]}) + (f32x2{e_[4], e_[5]} + f32x2{e_[6], e_[7]});   /* one accumulator per quarter: no chain */ \
+  }
+  // one key tile: SC = scores of tile T (complete), SN = accumulators of tile T+1 (zeroed here, complete afterwards)
+#define SP_TILE(T, SC0, SC1, SN0, SN1)                                                               \
+  {                                                                                                  \
+    const int t_ = (T);                                                                              \
+    const bool more_ = t_ + 1 < ntile;                    /* tile t+1 exists: its scores are computed here */                  \
+    const bool stage_ = t_ + 2 < ntile;                   /* K(t+2) */                                                        \
+    if (more_) {                                                                                     \
+      const int blk_ = b_first + t_ + 1;                                                             \
+      rv = *reinterpret_cast<const uint4*>(Vg + ((size_t)blk_ * 64 + srow) * 64 + sch);              \
+      int tok_ = (blk_ + 1) * 64 + srow; tok_ = tok_ < TP ? tok_ : TP - 1;                           \
+      rk = *reinterpret_cast<const uint4*>(Kg + (size_t)tok_ * 64 + sch);                            \
+    }                                                                                                \
+    if (wave_active) {                                                                               \
+      const int tile0_ = (b_first + t_) * 64;                                                        \
+      if (tile0_ < seg0 || tile0_ + 64 > seg1) {                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+          const int kg_ = tile0_ + mfma32_crow(r, hi);                                               \
+          SC0[r] = (kg_ >= seg0 && kg_ < seg1) ? SC0[r] : -1e30f;                                    \
+          SC1[r] = (kg_ + 32 >= seg0 && kg_ + 32 < seg1) ? SC1[r] : -1e30f;                          \
+        }                                                                                            \
+      }                                                                                              \
+      const u16* kp_ = Ks + ((t_ + 1) & 1) * (HKV * HLD) + lrow;                                     \
+      const u16* vp_ = Vs + (t_ & 1) * (HKV * HLD) + lrow;                                           \
+      uint4 fk0_ = *reinterpret_cast<const uint4*>(kp_), fk1_ = *reinterpret_cast<const uint4*>(kp_ + 32 * HLD);               \
+      uint4 fv0_ = *reinterpret_cast<const uint4*>(vp_), fv1_ = *reinterpret_cast<const uint4*>(vp_ + 32 * HLD);               \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                             \
+        uint4 nk0_ = fk0_, nk1_ = fk1_, nv0_ = fv0_, nv1_ = fv1_;                                    \
+        if (ks < 3) {                                     /* fragments of the next quarter */                                  \
+          nk0_ = *reinterpret_cast<const uint4*>(kp_ + 16 * (ks + 1)); nk1_ = *reinterpret_cast<const uint4*>(kp_ + 32 * HLD + 16 * (ks + 1)); \
+          nv0_ = *reinterpret_cast<const uint4*>(vp_ + 16 * (ks + 1)); nv1_ = *reinterpret_cast<const uint4*>(vp_ + 32 * HLD + 16 * (ks + 1)); \
+        }                                                                                            \
+        SP_SB                                                                                        \
+        if (more_) {                                                                                 \
+          SN0 = H16<DT>::mfma(__builtin_bit_cast(T8, fk0_), qf[ks], ks == 0 ? zero16 : SN0);        /* C = 0: an inline constant, no v_mov */ \
+          SN1 = H16<DT>::mfma(__builtin_bit_cast(T8, fk1_), qf[ks], ks == 0 ? zero16 : SN1);         \
+        }                                                                                            \
+        SP_SB                                                                                        \
+        T8 pb_;                                                                                      \
+        if ((ks >> 1) == 0) SP_EXP8(SC0, 8 * (ks & 1), pb_, psq[ks]) else SP_EXP8(SC1, 8 * (ks & 1), pb_, psq[ks])     \
+        SP_SB                                                                                        \
+        o0 = H16<DT>::mfma(__builtin_bit_cast(T8, fv0_), pb_, o0);                                   \
+        o1 = H16<DT>::mfma(__builtin_bit_cast(T8, fv1_), pb_, o1);                                   \
+        SP_SB                                                                                        \
+        fk0_ = nk0_; fk1_ = nk1_; fv0_ = nv0_; fv1_ = nv1_;                                          \
+      }                                                                                              \
+    }                                                                                                \
+    if (more_) {                                                                                     \
+      *reinterpret_cast<uint4*>(Vs + ((t_ + 1) & 1) * (HKV * HLD) + soff) = rv;                      \
+      if (stage_) *reinterpret_cast<uint4*>(Ks + (t_ & 1) * (HKV * HLD) + soff) = rk;                \
+    }                                                                                                \
+    __syncthreads();                                                                                 \
+  }
+
+  for (int t = 0; t < ntile; t += 2) {
+    SP_TILE(t, sa0, sa1, sb0, sb1)
+    if (t + 1 < ntile) SP_TILE(t + 1, sb0, sb1, sa0, sa1)
+  }
+
+  if (!wave_active) return;
+  const int q = qw0 + l31;
+  const f32x2 pst = (psq[0] + psq[1]) + (psq[2] + psq[3]);
+  const float inv = 1.0f / h_xhalf_sum(pst.x + pst.y);
+  if (q < len) {
+    u16* op = out + (size_t)(seg0 + q) * (heads * 64) + head * 64 + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<uint2*>(op + 8 * g) =
+          h16_pack4<DT>(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+      *reinterpret_cast<uint2*>(op + 32 + 8 * g) =
+          h16_pack4<DT>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+  }
+}
+
 // tuning knob (rap_set_tuning key 3): 0 = v1 (bounded softmax when per-head logit bounds are supplied -- bf16 only -- else
 // v_max3 row maximum + deferred rescale); 5 = v1 online softmax even with bounds; 11 = ping-pong schedule (slower, see above); 8 = first v1 (fmaxf chain, rescale
 // every tile); 4 = max3 only; 1..3, 6, 7 = timing-only ablations (bf16 only), see ABL above.
@@ -460,7 +632,7 @@ int g_rap_attn_h16_variant = 0;
 // the model path asks before it runs qk-norm: pre-scaled q only feeds the default bounded bf16 kernel
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {
   const int v = g_rap_attn_h16_variant;
-  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10);
+  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10 || v == 12);
 }
 
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
@@ -491,6 +663,13 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
       case 4: HATT_LAUNCH(RAP_DT_BF16, 0, 7); break;     // + s_setprio(1) around the MFMA clusters
       case 5: HATT_LAUNCH(RAP_DT_BF16, 0, 3); break;     // max3 + deferred rescale
       case 8: HATT_LAUNCH(RAP_DT_BF16, 0, 0); break;     // v1: fmaxf chain, rescale every tile
+      case 12:                                            // software-pipelined bounded kernel (r02: measured 5 % slower, see its header)
+        if (bound && q_prescaled)
+          hipLaunchKernelGGL((attention_h16_sp_kernel<RAP_DT_BF16, 1>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound);
+        else if (bound)
+          hipLaunchKernelGGL((attention_h16_sp_kernel<RAP_DT_BF16, 0>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound);
+        else HATT_LAUNCH(RAP_DT_BF16, 0, 3);
+        break;
       default:
         if (bound && q_prescaled) HATT_LAUNCH(RAP_DT_BF16, 0, 24);
         else if (bound) HATT_LAUNCH(RAP_DT_BF16, 0, 8);

@@ -167,6 +167,42 @@ def test_gemm_h16_qkv_split_and_transposed_v(lib, dev, dt, tile_variant, M):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("M,K,q_mul", [(256, 128, 8.0), (1000, 512, 1.4426950408889634), (37, 192, 8.0)])
+def test_gemm_h16_qkv_with_fused_qknorm(lib, dev, dt, M, K, q_mul):
+    """EPI_H_QKV_NORM: q and k = MultiHeadRMSNorm(x W^T) (norm.py:28-33: normalize * gamma * 8; q times q_mul / 8 instead) from the fp32
+    accumulators, rounded once; v exactly as the un-fused epilogue.  Reference: fp64 on the same rounded operands."""
+    g = torch.Generator().manual_seed(15)
+    H = 4
+    N = 3 * H * 64
+    A = to_h(torch.randn(M, K, generator=g), dt); W = to_h(torch.randn(N, K, generator=g) / K ** 0.5, dt)
+    gq, gk = torch.rand(H, 64, generator=g) + 0.5, torch.rand(H, 64, generator=g) + 0.5
+    x = (A.double() @ W.double().T).reshape(M, 3, H, 64).permute(1, 2, 0, 3)        # [3][H][M][64]
+    nrm = x[:2].norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    mul = torch.tensor([q_mul, 8.0], dtype=torch.float64)[:, None, None, None]
+    ref_qk = x[:2] / nrm * torch.stack([gq, gk])[:, :, None, :].double() * mul
+    nblk = (M + 255) // 256 * 256 // 64
+    qk = torch.full((2, H, M, 64), float("nan"), dtype=TORCH_DT[dt], device=dev)
+    vt = torch.full((H, nblk, 64, 64), float("nan"), dtype=TORCH_DT[dt], device=dev)
+    Ad, Wd, gqd, gkd = A.to(dev), W.to(dev), gq.to(dev), gk.to(dev)
+    rc = lib.rap_gemm_h16_qkvnorm(dt, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(qk), M, K, H, _lib.ptr(gqd), _lib.ptr(gkd), float(q_mul),
+                                  _lib.ptr(vt), nblk, stream(dev))
+    _lib.check(rc, "rap_gemm_h16_qkvnorm")
+    torch.cuda.synchronize()
+    err = (qk.cpu().double() - ref_qk).abs() / (ref_qk.abs() + 1e-2)
+    assert err.max().item() < 1.01 * ULP[dt] + 1e-4, err.max().item()            # one rounding of the normalised value
+    vtc = vt.cpu().double()
+    t = torch.arange(M)
+    got = vtc[:, t >> 6, :, vt_pos(t & 63)]
+    want = x[2].permute(1, 0, 2)
+    errv = (got - want).abs() / (want.abs() + 1e-2)
+    assert errv.max().item() < 1.01 * ULP[dt], errv.max().item()
+    tp = torch.arange(M, (M + 255) // 256 * 256)
+    if tp.numel():
+        pad = vtc[:, tp >> 6, :, vt_pos(tp & 63)]
+        assert torch.equal(pad, torch.zeros_like(pad))
+
+
+@pytest.mark.parametrize("dt", [1, 2])
 def test_gemm_h16_full_size_linearity_property(lib, dev, dt):
     """BASELINE configs[1]/[2] row count: C(A1 + A2) == C(A1) + C(A2) when A1, A2 have disjoint supports (exact in any
     arithmetic: every product is either x*w or 0*w), plus agreement with the exact-fp32 GEMM on the same rounded data."""
@@ -492,3 +528,29 @@ def test_attention_h16_schedule_variants_agree(lib, dev, dt, variant):
     ref = attention_ref64(q, k, v, cu, dt)
     assert (alt.double() - ref).abs().max().item() < 8 * ULP[dt]
     assert (alt.float() - base.float()).abs().max().item() < 4 * ULP[dt]
+
+
+
+def test_fused_qknorm_model_path_agrees_with_the_unfused_one(dev):
+    """rap_set_tuning(7, .): the whole velocity network with qk-norm inside the QKV epilogue vs as its own kernel (the r01 path) --
+    same function, one 16-bit rounding fewer on q and k."""
+    lib = _lib.load()
+    g, inp = load_golden("l12_small_rigid")
+    outs = {}
+    try:
+        for fused in (1, 0):
+            assert lib.rap_set_tuning(7, fused) == 0
+            cfg, sd, model = get_model(12, int(g["weight_seed"]), dev, "bfloat16")
+            cu_b, cu_p = O.prepare_cu_seqlens(inp)
+            d = {k: v.to(dev) for k, v in inp.items()}
+            outs[fused] = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
+                                local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                                cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev)).cpu()
+    finally:
+        assert lib.rap_set_tuning(7, 1) == 0
+    v_ref = torch.from_numpy(g["fwd_velocity"])
+    vmax = v_ref.abs().max().item()
+    e_fused, e_unfused = (outs[1] - v_ref).abs().max().item() / vmax, (outs[0] - v_ref).abs().max().item() / vmax
+    print(f"bf16 forward vs fp32 golden: fused {e_fused:.2e}, unfused {e_unfused:.2e}")
+    assert e_fused < FWD_REL_BOUND["bfloat16"] and e_unfused < FWD_REL_BOUND["bfloat16"]
+    assert (outs[1] - outs[0]).abs().max().item() / vmax < FWD_REL_BOUND["bfloat16"]
