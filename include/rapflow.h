@@ -174,6 +174,10 @@ int64_t rap_spinnet_weight_count(void);
 int rap_spinnet_create(const float* d_weights, int64_t n_floats, void* stream, rap_spinnet** out);
 void rap_spinnet_destroy(rap_spinnet* m);
 size_t rap_spinnet_workspace_bytes(int32_t keypoints_per_chunk);
+/* Patch alignment of MiniSpinNet.forward (patch_embedder.py:141-166): 1 (default) = is_aligned_to_global_z, the shipped demo setting
+ * (R = I); 0 = every patch is rotated so that its own normal -- the singular vector of the smallest singular value of the patch
+ * covariance, oriented towards the origin (cal_Z_axis, utils/common.py:539-557) -- becomes +z (RodsRotatFormula, :472-496). */
+int rap_spinnet_set_alignment(rap_spinnet* m, int32_t aligned_to_global_z);
 int rap_spinnet_describe(const rap_spinnet* m, const float* pts, const int32_t* perm, int64_t N, const float* kpts, int32_t K,
                          float des_r, float* desc_out, int32_t keypoints_per_chunk, void* ws, size_t ws_bytes, void* stream);
 

@@ -141,6 +141,12 @@ def make_spinnet_golden():
                         desc=ref["desc"].numpy(), patches_first=ref["patches"][:, :4].numpy(), patches_last=ref["patches"][:, -1].numpy(),
                         ball_counts=counts.numpy())
     print("spinnet_k16", os.path.getsize(path) // 1024, "KiB; points per ball:", counts.tolist())
+    # the same cloud with every patch aligned to its own normal (is_aligned_to_global_z = False: cal_Z_axis + RodsRotatFormula)
+    ref2 = ref_loader.reference_spinnet_forward(sd, pts, kpts, des_r, seed, is_aligned_to_global_z=False)
+    path2 = os.path.join(GOLDEN_DIR, "spinnet_k16_lrf.npz")
+    np.savez_compressed(path2, pts=pts.numpy(), kpts=kpts.numpy(), perm=ref2["perm"], des_r=np.float64(des_r), weight_seed=np.int64(0),
+                        desc=ref2["desc"].numpy(), R=ref2["R"].numpy(), patches_first=ref2["patches"][:, :4].numpy())
+    print("spinnet_k16_lrf", os.path.getsize(path2) // 1024, "KiB")
 
 
 def make_nn_metrics_golden():

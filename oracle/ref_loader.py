@@ -227,7 +227,7 @@ def reference_transformation_files(data, sample_dir, dataset_name, sample_indice
     return {p.name: np.loadtxt(p) for p in sorted(sample_dir.glob("*_transform.txt"))}
 
 
-def reference_spinnet_forward(sd, pts, kpts, des_r, perm_seed):
+def reference_spinnet_forward(sd, pts, kpts, des_r, perm_seed, is_aligned_to_global_z=True):
     """Run the reference's UNMODIFIED MiniSpinNet (dataset_process/utils/spinnet/*) on CPU.  Test-only shims: pytorch3d.ops.
     ball_query is the restatement of oracle/spinnet_oracle.py (the wheel is absent); `Tensor.cuda` is a no-op for the duration
     of the call (SPT hard-codes `.cuda()`, patch_embedder.py:176); numpy's global RNG is seeded so that the shuffle of
@@ -261,10 +261,10 @@ def reference_spinnet_forward(sd, pts, kpts, des_r, perm_seed):
     torch.Tensor.cuda = lambda self, *a, **k: self
     try:
         with torch.no_grad():
-            out = net(pts[None], kpts[None], des_r, True)
+            out = net(pts[None], kpts[None], des_r, is_aligned_to_global_z)
     finally:
         torch.Tensor.cuda = orig_cuda
-    return {"desc": out["desc"], "patches": out["patches"], "perm": perm}
+    return {"desc": out["desc"], "patches": out["patches"], "perm": perm, "R": out["R"]}
 
 
 def load_reference_dataset_utils():

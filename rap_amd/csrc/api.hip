@@ -890,6 +890,7 @@ struct rap_spinnet {
   const float* vox;           // (420,3)
   const void* pool_w;         // SpinPoolW on the device
   SpinLayer layers[8];
+  int lrf = 0;                // 1: patches are aligned to their own normal (is_aligned_to_global_z = False)
 };
 static const int kSpinCin[8] = {16, 64, 64, 128, 128, 64, 64, 32};
 static const int kSpinCout[8] = {64, 64, 128, 128, 64, 64, 32, 32};
@@ -1002,6 +1003,12 @@ extern "C" size_t rap_spinnet_workspace_bytes(int32_t keypoints_per_chunk) {
   return keypoints_per_chunk <= 0 ? 0 : carve_spin(keypoints_per_chunk, nullptr).total;
 }
 
+extern "C" int rap_spinnet_set_alignment(rap_spinnet* m, int32_t aligned_to_global_z) {
+  if (!m) return RAP_ERR_INVALID;
+  m->lrf = aligned_to_global_z ? 0 : 1;
+  return RAP_OK;
+}
+
 extern "C" int rap_spinnet_describe(const rap_spinnet* m, const float* pts, const int32_t* perm, int64_t N, const float* kpts,
                                     int32_t K, float des_r, float* desc_out, int32_t keypoints_per_chunk, void* ws, size_t ws_bytes,
                                     void* stream_) {
@@ -1015,7 +1022,7 @@ extern "C" int rap_spinnet_describe(const rap_spinnet* m, const float* pts, cons
   for (int k0 = 0; k0 < K; k0 += keypoints_per_chunk) {
     const int Kc = K - k0 < keypoints_per_chunk ? K - k0 : keypoints_per_chunk;
     const int M = Kc * 140;
-    if ((rc = launch_spin_patch(stream, pts, perm, (long)N, kpts + (size_t)k0 * 3, Kc, des_r, m->vox, m->h_w1, m->h_b1, w.x0))) return rc;
+    if ((rc = launch_spin_patch(stream, pts, perm, (long)N, kpts + (size_t)k0 * 3, Kc, des_r, m->vox, m->h_w1, m->h_b1, w.x0, m->lrf))) return rc;
     float* yin = nullptr;
     float* yout = w.Y0;
     for (int i = 0; i < 8; ++i) {

@@ -164,7 +164,7 @@ int launch_overlap_ratio(hipStream_t stream, const float* pts, const int32_t* cu
 int launch_spin_fold(hipStream_t stream, const float* W, const float* b, const float* gamma, const float* beta, const float* rm,
                      const float* rv, int Cout, int Kd, float* Wout, int ldw, int Npad, float* bout);
 int launch_spin_patch(hipStream_t stream, const float* pts, const int32_t* perm, long N, const float* kpts, int K, float des_r,
-                      const float* vox, const float* h_w1, const float* h_b1, float* x0);
+                      const float* vox, const float* h_w1, const float* h_b1, float* x0, int lrf = 0);
 int launch_spin_im2col3d(hipStream_t stream, const float* x0, int K, float* A, int ldA);
 int launch_spin_im2col2d(hipStream_t stream, const float* y, int ldy, int Cin, int K, float* A);
 int launch_spin_pool(hipStream_t stream, const float* x, int ldx, int K, const void* d_pool_w, float* desc);

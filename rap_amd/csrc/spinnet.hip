@@ -19,6 +19,7 @@
 //  3. spin_pool_kernel (one wave per keypoint): the 1x1 attention pool 32->16->1 with folded BatchNorm + ReLU, weighted mean over
 //     the 7x20 map, L2 normalisation (patch_embedder.py:81-83).
 #include "kernels.h"
+#include "kabsch.h"
 
 #define SP_PATCH 512
 #define SP_VOX 420
@@ -37,10 +38,12 @@ struct SpinConsts {
 __global__ __launch_bounds__(256) void spin_patch_kernel(const float* __restrict__ pts, const int32_t* __restrict__ perm, long N,
                                                          const float* __restrict__ kpts, int K, float des_r,
                                                          const float* __restrict__ vox /* (420,3) */, SpinConsts cw,
-                                                         float* __restrict__ x0 /* (K,420,16) */) {
+                                                         float* __restrict__ x0 /* (K,420,16) */, int lrf) {
   __shared__ float patch[SP_PATCH * 3];
   __shared__ int wave_cnt[4];
   __shared__ int total_s;
+  __shared__ double cov_sh[4][6];
+  __shared__ float rot_sh[9];
   const int k = blockIdx.x;
   if (k >= K) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -77,10 +80,62 @@ __global__ __launch_bounds__(256) void spin_patch_kernel(const float* __restrict
   // ---- centre on the LAST slot and normalise by the descriptor radius (axis_align global-z mode + normalize)
   const float cx = patch[(SP_PATCH - 1) * 3 + 0], cy = patch[(SP_PATCH - 1) * 3 + 1], cz = patch[(SP_PATCH - 1) * 3 + 2];
   __syncthreads();
+  if (lrf) {
+    // ---- local reference axis (is_aligned_to_global_z = False; patch_embedder.py:145-151, common.py:472-496, 539-557): z = the
+    // singular vector of the smallest singular value of the patch covariance, oriented so that -z . centre >= 0 (the
+    // 'normal' disambiguation: towards the sensor at the origin), then the Rodrigues rotation that takes z to (0,0,1).
+    double c6[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < SP_PATCH; i += 256) {
+      const double dx = (double)(patch[i * 3 + 0] - cx), dy = (double)(patch[i * 3 + 1] - cy), dz = (double)(patch[i * 3 + 2] - cz);
+      c6[0] += dx * dx; c6[1] += dx * dy; c6[2] += dx * dz; c6[3] += dy * dy; c6[4] += dy * dz; c6[5] += dz * dz;
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { c6[e] = wave_sum_d(c6[e]); if (lane == 0) cov_sh[wave][e] = c6[e]; }
+    __syncthreads();
+    if (tid == 0) {
+      double C[6];
+      for (int e = 0; e < 6; ++e) C[e] = cov_sh[0][e] + cov_sh[1][e] + cov_sh[2][e] + cov_sh[3][e];
+      double A[3][3] = {{C[0], C[1], C[2]}, {C[1], C[3], C[4]}, {C[2], C[4], C[5]}}, V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+      for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = rap_jacobi_pair(A, V, 0, 1);
+        off = fmax(off, rap_jacobi_pair(A, V, 0, 2));
+        off = fmax(off, rap_jacobi_pair(A, V, 1, 2));
+        if (off < 1e-15) break;
+      }
+      double sg[3];
+      for (int j = 0; j < 3; ++j) sg[j] = A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j];
+      int jm = 2;                                     // LAPACK orders singular values descending: ties resolve to the last column
+      if (sg[1] < sg[jm]) jm = 1;
+      if (sg[0] < sg[jm]) jm = 0;
+      double zx = V[0][jm], zy = V[1][jm], zz = V[2][jm];        // right singular vector: unit length also when sigma = 0
+      if (C[0] + C[3] + C[5] == 0.0) { zx = 0; zy = 0; zz = 1; }  // empty ball (512 copies of the keypoint): svd(0) = I
+      if (-(zx * (double)cx + zy * (double)cy + zz * (double)cz) < 0.0) { zx = -zx; zy = -zy; zz = -zz; }
+      const double zn = sqrt(zx * zx + zy * zy + zz * zz); zx /= zn; zy /= zn; zz /= zn;
+      // c = z x e_z, theta = acos(z . e_z); R = (I + sin K + (1 - cos) K^2) with K = skew(c / |c|); p' = R p
+      double ax = zy, ay = -zx, az = 0.0;
+      const double an = sqrt(ax * ax + ay * ay);
+      if (an > 1e-12) { ax /= an; ay /= an; } else { ax = 0; ay = 0; }      // F.normalize of a zero vector is zero: R = I
+      const double ct = fmin(1.0, fmax(-1.0, zz)), st = sqrt(fmax(0.0, 1.0 - ct * ct));
+      const double K[3][3] = {{0, -az, ay}, {az, 0, -ax}, {-ay, ax, 0}};
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          double k2 = 0; for (int m = 0; m < 3; ++m) k2 += K[i][m] * K[m][j];
+          rot_sh[3 * i + j] = (float)((i == j ? 1.0 : 0.0) + st * K[i][j] + (1.0 - ct) * k2);
+        }
+    }
+    __syncthreads();
+  }
   for (int i = tid; i < SP_PATCH; i += 256) {
-    patch[i * 3 + 0] = (patch[i * 3 + 0] - cx) / des_r;
-    patch[i * 3 + 1] = (patch[i * 3 + 1] - cy) / des_r;
-    patch[i * 3 + 2] = (patch[i * 3 + 2] - cz) / des_r;
+    float dx = patch[i * 3 + 0] - cx, dy = patch[i * 3 + 1] - cy, dz = patch[i * 3 + 2] - cz;
+    if (lrf) {
+      const float rx = rot_sh[0] * dx + rot_sh[1] * dy + rot_sh[2] * dz;
+      const float ry = rot_sh[3] * dx + rot_sh[4] * dy + rot_sh[5] * dz;
+      const float rz = rot_sh[6] * dx + rot_sh[7] * dy + rot_sh[8] * dz;
+      dx = rx; dy = ry; dz = rz;
+    }
+    patch[i * 3 + 0] = dx / des_r;
+    patch[i * 3 + 1] = dy / des_r;
+    patch[i * 3 + 2] = dz / des_r;
   }
   __syncthreads();
   // ---- spatial point transformer + point MLP + max-pool: voxel centres v = tid, tid + 256
@@ -245,11 +300,11 @@ int launch_spin_fold(hipStream_t stream, const float* W, const float* b, const f
   return RAP_OK;
 }
 int launch_spin_patch(hipStream_t stream, const float* pts, const int32_t* perm, long N, const float* kpts, int K, float des_r,
-                      const float* vox, const float* h_w1 /*16x3*/, const float* h_b1 /*16*/, float* x0) {
+                      const float* vox, const float* h_w1 /*16x3*/, const float* h_b1 /*16*/, float* x0, int lrf) {
   if (K <= 0) return RAP_OK;
   SpinConsts cw;
   for (int c = 0; c < 16; ++c) { cw.b1[c] = h_b1[c]; for (int d = 0; d < 3; ++d) cw.w1[c][d] = h_w1[c * 3 + d]; }
-  hipLaunchKernelGGL(spin_patch_kernel, dim3(K), dim3(256), 0, stream, pts, perm, N, kpts, K, des_r, vox, cw, x0);
+  hipLaunchKernelGGL(spin_patch_kernel, dim3(K), dim3(256), 0, stream, pts, perm, N, kpts, K, des_r, vox, cw, x0, lrf);
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }

@@ -65,8 +65,7 @@ class MiniSpinNet:
                  delta: float = 0.8, voxel_sample: int = 10, is_aligned_to_global_z: bool = True, keypoints_per_chunk: int = 2048):
         if (num_points_per_patch, rad_n, azi_n, ele_n, voxel_sample) != (512, 3, 20, 7, 10) or abs(delta - 0.8) > 1e-12:
             raise NotImplementedError("only the shipped configuration (512 pts, 3x7x20 voxels, 10 samples, delta 0.8) is built")
-        if not is_aligned_to_global_z:
-            raise NotImplementedError("only is_aligned_to_global_z=True (demo.py:547) is built")
+        self.is_aligned_to_global_z = bool(is_aligned_to_global_z)
         self.des_r, self.patch_sample = des_r, num_points_per_patch
         self.keypoints_per_chunk = int(keypoints_per_chunk)
         self._spec = spinnet_weight_spec()
@@ -139,8 +138,8 @@ class MiniSpinNet:
         """pts (1,N,3), kpts (1,K,3) -> {'desc': (K,32)}.  ``perm`` (N,) overrides the shuffle the reference draws with
         ``np.random.choice(N, N, replace=False)`` (patch_embedder.py:99) -- by default the same call is made here, so the same
         numpy seed gives the same patches."""
-        if not is_aligned_to_global_z or z_axis is not None or is_aug:
-            raise NotImplementedError("only the global-z, no-augmentation inference path is built")
+        if z_axis is not None or is_aug:
+            raise NotImplementedError("caller-supplied z axes and SO(2) augmentation are training-time options and are not built")
         _require_cuda(pts, "pts")
         device = pts.device
         self._ensure(device)
@@ -153,6 +152,7 @@ class MiniSpinNet:
         lib = _lib.load()
         chunk = max(1, min(self.keypoints_per_chunk, K))
         ws = workspace(device, lib.rap_spinnet_workspace_bytes(chunk))
+        _lib.check(lib.rap_spinnet_set_alignment(self._handle, 1 if is_aligned_to_global_z else 0), "rap_spinnet_set_alignment")
         with torch.cuda.device(device):
             rc = lib.rap_spinnet_describe(self._handle, _lib.ptr(p), _lib.ptr(perm_d), N, _lib.ptr(kp), K, float(des_r), _lib.ptr(desc),
                                           chunk, _lib.ptr(ws), ws.numel(), _lib.current_stream(device))

@@ -41,7 +41,7 @@ def lib():
         assert lib.rap_set_tuning(2, int(v)) == 0
     yield lib
     if v is not None:
-        assert lib.rap_set_tuning(2, 1) == 0
+        assert lib.rap_set_tuning(2, 14) == 0
 
 
 def stream(dev):
@@ -65,11 +65,16 @@ def gemm_h(lib, dev, dt, epi, A, W, C, M, N, K, bias=None, resid=None, heads=0, 
     torch.cuda.synchronize()
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["tile128x128", "tile256x256", "tile256x128", "ring256x256", "ring256x128"])
+DEFAULT_GEMM_H16_VARIANT = 14      # phase-split 256x256 (r02)
+
+
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 9, 11, 14],
+                ids=["tile128x128", "tile256x256", "tile256x128", "ring256x256", "ring256x128", "tile128x512", "pipe5stage", "interleaved",
+                     "interleaved_staggered", "phase_split"])
 def tile_variant(request, lib):
     assert lib.rap_set_tuning(2, request.param) == 0
     yield request.param
-    assert lib.rap_set_tuning(2, 1) == 0
+    assert lib.rap_set_tuning(2, DEFAULT_GEMM_H16_VARIANT) == 0
 
 
 # ---------------------------------------------------------------------------------------------
@@ -159,7 +164,7 @@ def test_gemm_h16_qkv_split_and_transposed_v(lib, dev, dt, tile_variant, M):
     want = ref[2].permute(1, 0, 2)                     # (M, H, 64)
     errv = (got - want).abs() / (want.abs() + 1e-2)
     assert errv.max().item() < 1.01 * ULP[dt], errv.max().item()
-    m_tiles = {0: 128, 1: 256, 2: 256, 3: 256, 4: 256}[tile_variant]
+    m_tiles = {0: 128, 2: 256, 4: 256, 5: 128}.get(tile_variant, 256)
     tp = torch.arange(M, (M + m_tiles - 1) // m_tiles * m_tiles)
     if tp.numel():
         pad = vtc[:, tp >> 6, :, vt_pos(tp & 63)]
