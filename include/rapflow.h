@@ -202,6 +202,12 @@ int rap_farthest_point_sampling(const float* points, const int32_t* cloud_start,
 int rap_voxel_bounds(const float* points, int64_t N, float voxel_size, int64_t* bounds6_out, float* dist_max_out, void* stream);
 int64_t rap_voxel_table_slots(const int64_t* h_bounds6);
 size_t rap_voxel_workspace_bytes(const int64_t* h_bounds6);
+/* Exact number of occupied voxels = distinct rows of floor(points / voxel_size) (calculate_voxel_coverage,
+ * dataset_process/utils/point_sampling_utils.py:11-31; the down-sampling table above keeps the reference's colliding key and cannot
+ * count).  h_bounds6 from rap_voxel_bounds (HOST); count_out: device int64; ws >= rap_voxel_coverage_workspace_bytes(h_bounds6). */
+size_t rap_voxel_coverage_workspace_bytes(const int64_t* h_bounds6);
+int rap_voxel_coverage(const float* points, int64_t N, float voxel_size, const int64_t* h_bounds6, int64_t* count_out, void* ws,
+                       size_t ws_bytes, void* stream);
 int rap_voxel_downsample(const float* points, int64_t N, float voxel_size, const int64_t* h_bounds6, float dist_max,
                          int64_t* indices_out, int32_t* count_out, void* ws, size_t ws_bytes, void* stream);
 
@@ -258,6 +264,15 @@ int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda
 int rap_gemm_h16_qkvnorm(int32_t dtype, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, uint16_t* qk_out, int32_t M,
                          int32_t K, int32_t heads, const float* gamma_q, const float* gamma_k, float q_mul, uint16_t* vt,
                          int32_t vt_nblk, void* stream);
+/* A residual GEMM with the NEXT LayerNorm fused into its epilogue -- what rap_sample / rap_dit_forward run for the out-projections
+ * and the FFN down-projection in the 16-bit modes when tuning key 8 = 1 (default 0 = GEMM + rap_layernorm_*_h16, measured faster):
+ *   h (M,512) fp32 += A (M,K) W (512,K)^T + bias          (in place: the residual stream)
+ *   xn_out (M,512) half = LayerNorm(h_new, eps 1e-5) * (add_one + gain[row]) + shift[row]
+ * gain / shift rows as in rap_layernorm_mod_h16 (row = token_row[m] * row_stride, or 0) -- adaLN (norm.py:74-76, add_one = 1) or the
+ * affine ff_norm (layer.py:163, add_one = 0).  N is fixed at 512 (one 128 x 512 tile holds whole rows); K % 64 == 0. */
+int rap_gemm_h16_resid_ln(int32_t dtype, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, float* h, int32_t ldh, int32_t M,
+                          int32_t K, const float* bias, uint16_t* xn_out, const float* gain, const float* shift, int64_t row_stride,
+                          const int32_t* token_row, int32_t add_one, void* stream);
 int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk, const int32_t* cu_seqlens,
                       int32_t nseg, uint16_t* out, int64_t TP, int32_t heads, const float* logit_bound, void* ws,
                       size_t ws_bytes, void* stream);
@@ -319,7 +334,8 @@ int rap_profile_enable(int on);
  * 2: 256x128 8-wave, 3/4: ring-buffered, 5: 128x512, 6-8: pipelined rings, 9-12: interleaved issue, 13-15: phase-split}, key 3 = 16-bit attention schedule (0 default, see attn_h16.hip), key 4 = fp32 GEMM
  * phase stagger {0 off, 1 by block index (default), 2 by CU id}, key 5 = split-KV attention for few-token calls {0 off, 1 on
  * (default)}, key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}, key 7 = 16-bit path: qk-norm fused
- * into the QKV GEMM epilogue {1 (default)} or as its own kernel {0}.
+ * into the QKV GEMM epilogue {1 (default)} or as its own kernel {0}, key 8 = 16-bit path: the next LayerNorm fused into the epilogue of
+ * the residual GEMMs (out-projection, FFN down-projection) {1} or as its own kernel {0 (default: measured faster)}.
  * All variants compute the same function. */
 int rap_set_tuning(int32_t key, int32_t value);
 int rap_profile_reset(void);

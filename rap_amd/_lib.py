@@ -58,6 +58,8 @@ SIGNATURES = {
     "rap_voxel_bounds": (c_int32, [_P, c_int64, c_float, _P, _P, _P]),
     "rap_voxel_table_slots": (c_int64, [_P]),
     "rap_voxel_workspace_bytes": (c_size_t, [_P]),
+    "rap_voxel_coverage_workspace_bytes": (c_size_t, [_P]),
+    "rap_voxel_coverage": (c_int32, [_P, c_int64, c_float, _P, _P, _P, c_size_t, _P]),
     "rap_voxel_downsample": (c_int32, [_P, c_int64, c_float, _P, c_float, _P, _P, _P, c_size_t, _P]),
     "rap_farthest_point_sampling": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P]),
     "rap_spinnet_weight_count": (c_int64, []),
@@ -88,6 +90,7 @@ SIGNATURES = {
     "rap_gemm_h16": (c_int32, [c_int32, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P,
                                c_int32, c_int32, _P, c_int32, _P]),
     "rap_gemm_h16_qkvnorm": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, c_float, _P, c_int32, _P]),
+    "rap_gemm_h16_resid_ln": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int64, _P, c_int32, _P]),
     "rap_attention_h16": (c_int32, [c_int32, _P, _P, c_int32, _P, c_int32, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "rap_layernorm_mod_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P]),
     "rap_layernorm_affine_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, _P, _P]),

@@ -122,6 +122,9 @@ extern int g_rap_attn_variant;   // attn_f32.hip
 extern int g_rap_attn_split;     // attn_f32.hip
 extern int g_rap_gemm_h16_variant;   // gemm_h16.hip
 extern int g_rap_attn_h16_variant;   // attn_h16.hip
+int g_rap_fuse_ln = 0;                // tuning key 8: 16-bit path, the next LayerNorm fused into the residual GEMMs' epilogue (1) or as its own kernel (0, default:
+                                      // r02 call 16 -- fused, the 128x512 kernel's epilogue with its three block-wide reductions per row tile costs more (GEMM class
+                                      // 918 -> 1057 ms per sample call) than the three HBM-bound LayerNorm launches it removes (100 ms): 106.3k -> 101.6k points/s)
 int g_rap_fuse_qknorm = 1;            // tuning key 7: 16-bit path, qk-norm fused into the QKV GEMM epilogue (1, default) or as its own kernel (0)
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 48)) { g_rap_gemm_variant = value; return RAP_OK; }
@@ -138,6 +141,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 5 && (value == 0 || value == 1)) { g_rap_attn_split = value; return RAP_OK; }
   if (key == 6 && (value == 0 || value == 1)) { g_rap_gemm_splitk = value; return RAP_OK; }
   if (key == 7 && (value == 0 || value == 1)) { g_rap_fuse_qknorm = value; return RAP_OK; }
+  if (key == 8 && (value == 0 || value == 1)) { g_rap_fuse_ln = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 
@@ -419,9 +423,13 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
     if (dt != RAP_DT_F32) {
       // ---- reduced-precision block: 16-bit MFMA operands, fp32 accumulate, fp32 residual stream / LN / softmax
       const LayerWH& lh = m->half[dt].layers[i];
+      // r02: with g_rap_fuse_ln every residual GEMM (N = d = 512: full rows per 128 x 512 tile) also writes the NEXT LayerNorm's
+      // 16-bit output, so only the very first LayerNorm of the forward runs as its own kernel.
+      const bool fuse_ln = g_rap_fuse_ln && d == 512;
       for (int a = 0; a < 2; ++a) {
         const int j = 2 * i + a;
-        if ((rc = launch_layernorm_mod_h16(stream, dt, w.h, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
+        if (!fuse_ln || (i == 0 && a == 0))
+          if ((rc = launch_layernorm_mod_h16(stream, dt, w.h, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
         GemmParamsH g{};
         g.A = w.xnh; g.lda = d; g.W = lh.Wqkv[a]; g.ldw = d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
         g.vt = w.vth; g.vt_nblk = w.vt_nblk;
@@ -446,10 +454,19 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         GemmParamsH o{};
         o.A = w.atth; o.lda = d; o.W = lh.Wout[a]; o.ldw = d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = d;
         o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d;
-        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, o); }
+        if (fuse_ln) {
+          // next LayerNorm: a = 0 -> the global branch's adaLN (j + 1), a = 1 -> the feed-forward's affine LayerNorm
+          o.xn = w.xnh;
+          if (a == 0) { o.ln_gain = mod + (size_t)(j + 1) * 2 * d; o.ln_shift = o.ln_gain + d; o.ln_row_stride = mod_stride; o.ln_token_row = token_row; o.ln_add_one = 1; }
+          else { o.ln_gain = lw.ffn_g; o.ln_shift = lw.ffn_b; o.ln_row_stride = 0; o.ln_token_row = nullptr; o.ln_add_one = 0; }
+          { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_RESID_LN, o); }
+        } else {
+          { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, o); }
+        }
         if (rc) return rc;
       }
-      if ((rc = launch_layernorm_affine_h16(stream, dt, w.h, w.xnh, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
+      if (!fuse_ln)
+        if ((rc = launch_layernorm_affine_h16(stream, dt, w.h, w.xnh, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
       GemmParamsH f1{};
       f1.A = w.xnh; f1.lda = d; f1.W = lh.Wff1p; f1.ldw = d; f1.C = w.ffmidh; f1.ldc = 4 * d; f1.M = TP; f1.N = 8 * d; f1.K = d;
       f1.bias = lw.bff1p;
@@ -458,7 +475,14 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       GemmParamsH f2{};
       f2.A = w.ffmidh; f2.lda = 4 * d; f2.W = lh.Wff2; f2.ldw = 4 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 4 * d;
       f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d;
-      { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, f2); }
+      if (fuse_ln && i + 1 < m->L) {
+        // next LayerNorm: the self branch's adaLN of layer i + 1
+        f2.xn = w.xnh; f2.ln_gain = mod + (size_t)(2 * (i + 1)) * 2 * d; f2.ln_shift = f2.ln_gain + d; f2.ln_row_stride = mod_stride;
+        f2.ln_token_row = token_row; f2.ln_add_one = 1;
+        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_RESID_LN, f2); }
+      } else {
+        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, f2); }
+      }
       if (rc) return rc;
       continue;
     }
@@ -1119,6 +1143,25 @@ extern "C" int rap_voxel_downsample(const float* points, int64_t N, float voxel_
                                  (long long*)indices_out);
 }
 
+// exact number of occupied voxels (calculate_voxel_coverage, point_sampling_utils.py:11-31): h_bounds6 from rap_voxel_bounds
+static int64_t coverage_slots(const int64_t* b) {
+  const __int128 s = (__int128)(b[3] - b[0] + 1) * (b[4] - b[1] + 1) * (b[5] - b[2] + 1);
+  return (s <= 0 || s > ((__int128)1 << 36)) ? -1 : (int64_t)s;          // 64 GiB of one-byte slots
+}
+extern "C" size_t rap_voxel_coverage_workspace_bytes(const int64_t* h_bounds6) {
+  const int64_t s = h_bounds6 ? coverage_slots(h_bounds6) : -1;
+  return s < 0 ? 0 : align_up((size_t)s, 256) + 256;
+}
+extern "C" int rap_voxel_coverage(const float* points, int64_t N, float voxel_size, const int64_t* h_bounds6, int64_t* count_out, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  if (!points || !h_bounds6 || !count_out || N <= 0 || !(voxel_size > 0.f)) return RAP_ERR_INVALID;
+  const int64_t slots = coverage_slots(h_bounds6);
+  if (slots < 0) return RAP_ERR_INVALID;
+  if (!ws || ws_bytes < rap_voxel_coverage_workspace_bytes(h_bounds6)) return RAP_ERR_WORKSPACE;
+  return launch_voxel_coverage((hipStream_t)stream, points, (long)N, voxel_size, (const long long*)h_bounds6, (unsigned char*)ws, (long)slots,
+                               (unsigned long long*)count_out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // input side of the boundary: raw parts -> the packed batch
 // ---------------------------------------------------------------------------------------------
@@ -1172,4 +1215,15 @@ extern "C" int rap_gemm_h16_qkvnorm(int32_t dtype, const uint16_t* A, int32_t ld
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = qk_out; g.M = M; g.N = 3 * heads * 64; g.K = K; g.heads = heads;
   g.vt = vt; g.vt_nblk = vt_nblk; g.gamma_q = gamma_q; g.gamma_k = gamma_k; g.q_mul = q_mul;
   return launch_gemm_h16((hipStream_t)stream, dtype, EPI_H_QKV_NORM, g);
+}
+
+// residual GEMM (N = 512) with the next LayerNorm fused into its epilogue (EPI_H_RESID_LN): see rapflow.h
+extern "C" int rap_gemm_h16_resid_ln(int32_t dtype, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, float* h, int32_t ldh,
+                                     int32_t M, int32_t K, const float* bias, uint16_t* xn_out, const float* gain, const float* shift,
+                                     int64_t row_stride, const int32_t* token_row, int32_t add_one, void* stream) {
+  if (!A || !W || !h || !xn_out || !gain || !shift) return RAP_ERR_INVALID;
+  GemmParamsH g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = h; g.ldc = ldh; g.M = M; g.N = 512; g.K = K; g.bias = bias; g.resid = h; g.ldr = ldh;
+  g.xn = xn_out; g.ln_gain = gain; g.ln_shift = shift; g.ln_row_stride = (long)row_stride; g.ln_token_row = token_row; g.ln_add_one = add_one;
+  return launch_gemm_h16((hipStream_t)stream, dtype, EPI_H_RESID_LN, g);
 }

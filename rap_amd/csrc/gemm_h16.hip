@@ -69,6 +69,91 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
     }
     return;
   }
+  if constexpr (EPI == EPI_H_RESID_LN) {
+    // Full rows: the block tile is 128 x 512 = N, waves 1 x 8, this wave owns columns nw .. nw + 63 of rows mw .. mw + 127.
+    // Per 32-row tile: h = acc + bias + resid through the wave's LDS slab (whole 16-byte row pieces, as EPI_H_BIAS_RESID_F32), then
+    // the LayerNorm of the NEW rows: two block-wide reductions over the 8 waves (mean, then the centred sum of squares -- the
+    // two-pass form of layernorm_h16_kernel) and xn = (h - mean) rstd (add_one + gain) + shift rounded to 16 bit.
+    // Saves the LayerNorm kernel (a 2 KiB read per token) and its launch; reference: norm.py:74-76, layer.py:163.
+    float* C = reinterpret_cast<float*>(p.C);
+    u16* XN = p.xn;
+    float* sf = reinterpret_cast<float*>(stg);                      // [32 rows][64 columns]
+    const int wv = (nw & 511) >> 6;                                 // = the wave index (waves 1 x 8, one tile spans N)
+    float* stats = reinterpret_cast<float*>(stg - (size_t)wv * H16_STG_BYTES + 8 * H16_STG_BYTES);   // behind the 8 slabs: [8 waves][32 rows]
+    const float b0 = p.bias ? p.bias[nw + l31] : 0.f;
+    const float b1 = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+    const int col = (lane & 15) * 4;
+    const float one = p.ln_add_one ? 1.0f : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {                                  // fully unrolled: acc[i] must stay a register index
+      float4 v[8];                                                  // residual rows first (their latency hides behind the LDS transpose)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        int m = mw + i * 32 + it * 4 + (lane >> 4);
+        m = m < p.M ? m : p.M - 1;
+        v[it] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + nw + col);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sf[mfma32_crow(r, hi) * 64 + l31] = acc[i][0][r] + b0;
+        sf[mfma32_crow(r, hi) * 64 + 32 + l31] = acc[i][1][r] + b1;
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const float4 a4 = *reinterpret_cast<const float4*>(sf + row * 64 + col);
+        v[it].x += a4.x; v[it].y += a4.y; v[it].z += a4.z; v[it].w += a4.w;
+        const int m = mw + i * 32 + row;
+        if (m < p.M) *reinterpret_cast<float4*>(C + (size_t)m * p.ldc + nw + col) = v[it];
+        float s = (v[it].x + v[it].y) + (v[it].z + v[it].w);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((lane & 15) == 0) stats[wv * 32 + row] = s;
+      }
+      __syncthreads();
+      float mean[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        float s = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) s += stats[w8 * 32 + row];
+        mean[it] = s * (1.0f / 512.0f);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const float a = v[it].x - mean[it], b = v[it].y - mean[it], c = v[it].z - mean[it], e = v[it].w - mean[it];
+        float q = (a * a + b * b) + (c * c + e * e);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        if ((lane & 15) == 0) stats[wv * 32 + row] = q;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        float q = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) q += stats[w8 * 32 + row];
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 512.0f) + 1e-5f);
+        int m = mw + i * 32 + row;
+        const bool live = m < p.M;
+        m = live ? m : p.M - 1;
+        const long mrow = p.ln_token_row ? (long)p.ln_token_row[m] : 0;
+        const float4 gg = *reinterpret_cast<const float4*>(p.ln_gain + mrow * p.ln_row_stride + nw + col);
+        const float4 bb = *reinterpret_cast<const float4*>(p.ln_shift + mrow * p.ln_row_stride + nw + col);
+        const float ox = (v[it].x - mean[it]) * rstd * (one + gg.x) + bb.x;
+        const float oy = (v[it].y - mean[it]) * rstd * (one + gg.y) + bb.y;
+        const float oz = (v[it].z - mean[it]) * rstd * (one + gg.z) + bb.z;
+        const float ow = (v[it].w - mean[it]) * rstd * (one + gg.w) + bb.w;
+        if (live) *reinterpret_cast<uint2*>(XN + (size_t)m * 512 + nw + col) = h16_pack4<DT>(ox, oy, oz, ow);
+      }
+      __syncthreads();
+    }
+    return;
+  }
   if constexpr (EPI == EPI_H_BIAS_RESID_F32) {
     float* C = reinterpret_cast<float*>(p.C);
     float* sf = reinterpret_cast<float*>(stg);   // [32 rows][64 columns]
@@ -356,7 +441,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
 
   // ---------------- epilogue ----------------
   static_assert(TN == 2, "wave tiles are 64 columns wide: one head / one GEGLU value+gate group");
-  static_assert(WM * WN * H16_STG_BYTES <= 2 * (BM + BN) * 128, "staging slabs must fit the operand buffers");
+  static_assert(WM * WN * H16_STG_BYTES + 1024 <= 2 * (BM + BN) * 128, "staging slabs (+ the LN statistics) must fit the operand buffers");
   __syncthreads();
   gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
 }
@@ -1060,6 +1145,9 @@ static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
     case EPI_H_BIAS: return launch_variant<EPI_H_BIAS, DT>(stream, p);
     case EPI_H_BIAS_RESID_F32: return launch_variant<EPI_H_BIAS_RESID_F32, DT>(stream, p);
     case EPI_H_GEGLU: return launch_variant<EPI_H_GEGLU, DT>(stream, p);
+    case EPI_H_RESID_LN:
+      if (p.N != 512 || !p.resid || !p.xn || !p.ln_gain || !p.ln_shift || (p.ldc & 3) || (p.ldr & 3)) return RAP_ERR_INVALID;
+      return launch_cfg<EPI_H_RESID_LN, DT, 1, 8, 4, 2>(stream, p);
     case EPI_H_QKV_NORM:
       if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256 || !p.gamma_q || !p.gamma_k || p.K < 128) return RAP_ERR_INVALID;
       return launch_ph<EPI_H_QKV_NORM, DT, 0, 1>(stream, p);

@@ -148,3 +148,37 @@ int launch_voxel_downsample(hipStream_t stream, const float* pts, long N, float 
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// exact voxel coverage (calculate_voxel_coverage, dataset_process/utils/point_sampling_utils.py:11-31: the number of DISTINCT rows of
+// floor(points / voxel_size)).  The down-sampling key above reproduces the reference's cubic stride incl. its wrap-around
+// collisions, so it cannot count; here the key is exact -- per-axis extents as strides -- into a byte table, then a reduction.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void voxel_mark_kernel(const float* __restrict__ pts, long N, float vs, long long ox, long long oy,
+                                                         long long oz, long long ex, long long ey, unsigned char* __restrict__ table) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
+    const float* p = pts + i * 3;
+    const long long gx = (long long)floorf(p[0] / vs) - ox, gy = (long long)floorf(p[1] / vs) - oy, gz = (long long)floorf(p[2] / vs) - oz;
+    table[gx + ex * (gy + ey * gz)] = 1;                    // benign race: every writer stores the same value
+  }
+}
+__global__ __launch_bounds__(256) void voxel_popcount_kernel(const unsigned char* __restrict__ table, long slots, unsigned long long* __restrict__ total) {
+  unsigned int c = 0;
+  for (long s = (long)blockIdx.x * 256 + threadIdx.x; s < slots; s += (long)gridDim.x * 256) c += table[s];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, (unsigned long long)c);
+}
+int launch_voxel_coverage(hipStream_t stream, const float* pts, long N, float vs, const long long* h_bounds6, unsigned char* table, long slots,
+                          unsigned long long* total) {
+  const long long ex = h_bounds6[3] - h_bounds6[0] + 1, ey = h_bounds6[4] - h_bounds6[1] + 1;
+  RAP_HIP_CHECK(hipMemsetAsync(table, 0, (size_t)slots, stream));
+  RAP_HIP_CHECK(hipMemsetAsync(total, 0, 8, stream));
+  const unsigned grid = (unsigned)((N + 255) / 256 < 4096 ? (N + 255) / 256 : 4096);
+  hipLaunchKernelGGL(voxel_mark_kernel, dim3(grid), dim3(256), 0, stream, pts, N, vs, h_bounds6[0], h_bounds6[1], h_bounds6[2], ex, ey, table);
+  RAP_LAUNCH_CHECK();
+  const unsigned g2 = (unsigned)((slots + 255) / 256 < 8192 ? (slots + 255) / 256 : 8192);
+  hipLaunchKernelGGL(voxel_popcount_kernel, dim3(g2), dim3(256), 0, stream, table, slots, total);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}

@@ -105,11 +105,29 @@ def remove_statistical_outlier(points: torch.Tensor, nb_neighbors: int = 20, std
 
 
 def calculate_voxel_coverage(points: torch.Tensor, voxel_size: float) -> int:
-    """point_sampling_utils.py:11-31: number of distinct voxels floor(p / voxel_size) the cloud occupies -- the size of the index list
-    the voxel down-sampling kernel returns (one kept point per occupied voxel)."""
+    """point_sampling_utils.py:11-31: number of distinct voxels floor(p / voxel_size) the cloud occupies (exact key: the
+    down-sampling table reproduces the reference's colliding cubic key and cannot be used to count)."""
     if points.shape[0] == 0:
         return 0
-    return int(voxel_down_sample_torch(points, voxel_size).numel())
+    _require_cuda(points, "points")
+    device = points.device
+    pts = _f32c(points)
+    N = pts.shape[0]
+    lib = _lib.load()
+    bounds = torch.empty(6, dtype=torch.int64, device=device)
+    dmax = torch.empty(1, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        stream = _lib.current_stream(device)
+        _lib.check(lib.rap_voxel_bounds(_lib.ptr(pts), N, float(voxel_size), _lib.ptr(bounds), _lib.ptr(dmax), stream), "rap_voxel_bounds")
+        h_bounds = bounds.cpu()
+        nbytes = lib.rap_voxel_coverage_workspace_bytes(h_bounds.data_ptr())
+        if nbytes == 0:
+            raise ValueError(f"voxel grid {tuple((h_bounds[3:] - h_bounds[:3] + 1).tolist())} is too large for the coverage table")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        count = torch.empty(1, dtype=torch.int64, device=device)
+        rc = lib.rap_voxel_coverage(_lib.ptr(pts), N, float(voxel_size), h_bounds.data_ptr(), _lib.ptr(count), _lib.ptr(ws), ws.numel(), stream)
+    _lib.check(rc, "rap_voxel_coverage")
+    return int(count.cpu())
 
 
 def calculate_adaptive_sample_count_per_part(parts_points, voxel_size: float, voxel_ratio: float, min_points_per_part: int,

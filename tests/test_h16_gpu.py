@@ -9,6 +9,8 @@ What is compared with what:
     MEASURED deviation for the bf16 path, not a fixed bar -- the asserted bounds below are
     what was measured on MI355X with margin, and the measured values are printed.
 """
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -205,6 +207,44 @@ def test_gemm_h16_qkv_with_fused_qknorm(lib, dev, dt, M, K, q_mul):
     if tp.numel():
         pad = vtc[:, tp >> 6, :, vt_pos(tp & 63)]
         assert torch.equal(pad, torch.zeros_like(pad))
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("M,K,adaln", [(128, 512, True), (1000, 2048, True), (333, 512, False)])
+def test_gemm_h16_residual_with_fused_layernorm(lib, dev, dt, M, K, adaln):
+    """EPI_H_RESID_LN: h += A W^T + bias in place (fp32) and xn = LN(h_new) * (1 + scale[sample]) + shift[sample] (adaLN, per-token
+    sample rows) or * gain + shift (affine) in 16 bit.  Reference: fp64 on the same rounded operands."""
+    g = torch.Generator().manual_seed(31)
+    N = 512
+    A = to_h(torch.randn(M, K, generator=g), dt); W = to_h(torch.randn(N, K, generator=g) / K ** 0.5, dt)
+    bias = torch.randn(N, generator=g); h0 = torch.randn(M, N, generator=g) * 3
+    rows = 3
+    mod = torch.randn(rows, 2 * N, generator=g) * 0.5
+    token_row = torch.randint(0, rows, (M,), generator=g, dtype=torch.int32)
+    gain_aff, shift_aff = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    h_ref = h0.double() + A.double() @ W.double().T + bias.double()
+    mu = h_ref.mean(1, keepdim=True); var = ((h_ref - mu) ** 2).mean(1, keepdim=True)
+    nrm = (h_ref - mu) / torch.sqrt(var + 1e-5)
+    if adaln:
+        xn_ref = nrm * (1 + mod[token_row.long(), :N].double()) + mod[token_row.long(), N:].double()
+    else:
+        xn_ref = nrm * gain_aff.double() + shift_aff.double()
+    hd = h0.to(dev).clone(); xn = torch.full((M, N), float("nan"), dtype=TORCH_DT[dt], device=dev)
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    modd, trd, gd, sd_ = mod.to(dev), token_row.to(dev), gain_aff.to(dev), shift_aff.to(dev)
+    if adaln:
+        shift_ptr = ctypes.c_void_p(modd.data_ptr() + N * 4)
+        rc = lib.rap_gemm_h16_resid_ln(dt, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(hd), N, M, K, _lib.ptr(bd), _lib.ptr(xn), _lib.ptr(modd),
+                                       shift_ptr, 2 * N, _lib.ptr(trd), 1, stream(dev))
+    else:
+        rc = lib.rap_gemm_h16_resid_ln(dt, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(hd), N, M, K, _lib.ptr(bd), _lib.ptr(xn), _lib.ptr(gd),
+                                       _lib.ptr(sd_), 0, _lib.ptr(None), 0, stream(dev))
+    _lib.check(rc, "rap_gemm_h16_resid_ln")
+    torch.cuda.synchronize()
+    eh = (hd.cpu().double() - h_ref).abs().max().item()
+    assert eh < 5e-5 * max(1.0, K / 512), eh                             # fp32 accumulation of exact 16-bit products
+    ex = (xn.cpu().double() - xn_ref).abs() / (xn_ref.abs() + 1e-1)
+    assert ex.max().item() < 1.01 * ULP[dt] + 2e-4, ex.max().item()      # one rounding of the normalised value
 
 
 @pytest.mark.parametrize("dt", [1, 2])
@@ -557,5 +597,30 @@ def test_fused_qknorm_model_path_agrees_with_the_unfused_one(dev):
     vmax = v_ref.abs().max().item()
     e_fused, e_unfused = (outs[1] - v_ref).abs().max().item() / vmax, (outs[0] - v_ref).abs().max().item() / vmax
     print(f"bf16 forward vs fp32 golden: fused {e_fused:.2e}, unfused {e_unfused:.2e}")
+    assert e_fused < FWD_REL_BOUND["bfloat16"] and e_unfused < FWD_REL_BOUND["bfloat16"]
+    assert (outs[1] - outs[0]).abs().max().item() / vmax < FWD_REL_BOUND["bfloat16"]
+
+
+def test_fused_layernorm_model_path_agrees_with_the_unfused_one(dev):
+    """rap_set_tuning(8, .): the next LayerNorm inside the residual GEMMs' epilogue vs as its own kernel -- the same function (fp32
+    statistics on the fp32 residual stream in both), only the summation order of the row statistics differs."""
+    lib = _lib.load()
+    g, inp = load_golden("l12_small_rigid")
+    outs = {}
+    try:
+        for fused in (1, 0):
+            assert lib.rap_set_tuning(8, fused) == 0
+            cfg, sd, model = get_model(12, int(g["weight_seed"]), dev, "bfloat16")
+            cu_b, cu_p = O.prepare_cu_seqlens(inp)
+            d = {k: v.to(dev) for k, v in inp.items()}
+            outs[fused] = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
+                                local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                                cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev)).cpu()
+    finally:
+        assert lib.rap_set_tuning(8, 0) == 0
+    v_ref = torch.from_numpy(g["fwd_velocity"])
+    vmax = v_ref.abs().max().item()
+    e_fused, e_unfused = (outs[1] - v_ref).abs().max().item() / vmax, (outs[0] - v_ref).abs().max().item() / vmax
+    print(f"bf16 forward vs fp32 golden: LN fused {e_fused:.2e}, unfused {e_unfused:.2e}")
     assert e_fused < FWD_REL_BOUND["bfloat16"] and e_unfused < FWD_REL_BOUND["bfloat16"]
     assert (outs[1] - outs[0]).abs().max().item() / vmax < FWD_REL_BOUND["bfloat16"]
