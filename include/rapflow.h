@@ -333,8 +333,8 @@ int rap_profile_enable(int on);
  * {1: 4-wave v1 (default), 3: pipelined, 5: 8-wave v1}, key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave (default),
  * 2: 256x128 8-wave, 3/4: ring-buffered, 5: 128x512, 6-8: pipelined rings, 9-12: interleaved issue, 13-15: phase-split}, key 3 = 16-bit attention schedule (0 default, see attn_h16.hip), key 4 = fp32 GEMM
  * phase stagger {0 off, 1 by block index (default), 2 by CU id}, key 5 = split-KV attention for few-token calls {0 off, 1 on
- * (default)}, key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}, key 7 = 16-bit path: qk-norm fused
- * into the QKV GEMM epilogue {1 (default)} or as its own kernel {0}, key 8 = 16-bit path: the next LayerNorm fused into the epilogue of
+ * (default)}, key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}, key 7 = qk-norm fused
+ * into the QKV GEMM epilogue {1 (default)} or as its own kernel {0} (both precisions), key 8 = 16-bit path: the next LayerNorm fused into the epilogue of
  * the residual GEMMs (out-projection, FFN down-projection) {1} or as its own kernel {0 (default: measured faster)}.
  * All variants compute the same function. */
 int rap_set_tuning(int32_t key, int32_t value);

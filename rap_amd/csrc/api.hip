@@ -125,7 +125,7 @@ extern int g_rap_attn_h16_variant;   // attn_h16.hip
 int g_rap_fuse_ln = 0;                // tuning key 8: 16-bit path, the next LayerNorm fused into the residual GEMMs' epilogue (1) or as its own kernel (0, default:
                                       // r02 call 16 -- fused, the 128x512 kernel's epilogue with its three block-wide reductions per row tile costs more (GEMM class
                                       // 918 -> 1057 ms per sample call) than the three HBM-bound LayerNorm launches it removes (100 ms): 106.3k -> 101.6k points/s)
-int g_rap_fuse_qknorm = 1;            // tuning key 7: 16-bit path, qk-norm fused into the QKV GEMM epilogue (1, default) or as its own kernel (0)
+int g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 48)) { g_rap_gemm_variant = value; return RAP_OK; }
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
@@ -491,9 +491,11 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       if ((rc = launch_layernorm_mod(stream, w.h, w.xn, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
       GemmParams g{};
       g.A = w.xn; g.lda = d; g.W = lw.Wqkv[a]; g.ldw = d; g.C = w.qkv; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
+      const bool fuse_qk = g_rap_fuse_qknorm && (g_rap_gemm_variant == 16 || g_rap_gemm_variant == 32 || g_rap_gemm_variant == 48);
+      if (fuse_qk) { g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; }        // qk-norm in the QKV epilogue (tuning key 7)
       { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_QKV_HEADMAJOR, g); }
       if (rc) return rc;
-      if ((rc = launch_qknorm(stream, w.qkv, TP, H, lw.gq[a], lw.gk[a]))) return rc;
+      if (!fuse_qk && (rc = launch_qknorm(stream, w.qkv, TP, H, lw.gq[a], lw.gk[a]))) return rc;
       {
         ProfScope ps(stream, a);
         const float* bound = m->bounded_ok ? m->logit_bound + (size_t)j * H : nullptr;

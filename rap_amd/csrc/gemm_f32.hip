@@ -24,6 +24,35 @@
 #define GBK 32
 #define GLD 36  // LDS row stride in floats
 
+// Fused MultiHeadRMSNorm for one 64-column wave tile (= one head of q or k) of the QKV projection: acc[mi][ni][r] is row
+// m = mw + 32 mi + crow(r, hi), column 32 ni + l31.  The row norm is a sum over the 32 lanes of a half-wave and the two column
+// tiles (5 xor-shuffles per row); the scaling repeats qknorm_kernel's operation order (x / nrm * gamma * 8), so the result differs
+// from GEMM + qknorm only through the summation order of the 64 squares.
+template <int TMI>
+__device__ __forceinline__ void qkv_store_normalised(const GemmParams& p, f32x16 (&acc)[TMI][2], int mw, int nw, int hi, int l31) {
+  const int dmodel = p.heads * 64;
+  const int c = nw / dmodel;
+  const int h = (nw - c * dmodel) >> 6;
+  const float* gam = (c == 0 ? p.gamma_q : p.gamma_k) + h * 64;
+  const float g0 = gam[l31], g1 = gam[32 + l31];
+  float* plane = p.C + ((size_t)c * p.heads + h) * p.M * 64;
+#pragma unroll
+  for (int mi = 0; mi < TMI; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s = acc[mi][0][r] * acc[mi][0][r] + acc[mi][1][r] * acc[mi][1][r];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float nrm = fmaxf(sqrtf(s), 1e-12f);
+      const int m = mw + mi * 32 + mfma32_crow(r, hi);
+      if (m < p.M) {
+        plane[(size_t)m * 64 + l31] = acc[mi][0][r] / nrm * g0 * 8.0f;
+        plane[(size_t)m * 64 + 32 + l31] = acc[mi][1][r] / nrm * g1 * 8.0f;
+      }
+    }
+  }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * GBM * GLD];
@@ -563,6 +592,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
   // ---------------- epilogue (same as the other variants) ----------------
   const int mw = m0 + wm * 64;
   const int nw = n0 + wn * 64;
+  if (EPI == EPI_QKV_HEADMAJOR && p.gamma_q && nw < 2 * p.heads * 64) { qkv_store_normalised<2>(p, acc, mw, nw, hi, l31); return; }
   if (EPI == EPI_GEGLU) {
     const int nout = (nw >> 1) + l31;
     const float bh = p.bias ? p.bias[nw + l31] : 0.f;
@@ -753,6 +783,7 @@ __global__ __launch_bounds__(512) void gemm_f32_dma256_kernel(GemmParams p) {
   // ---------------- epilogue: as the 128x128 kernels, over 4 x 2 MFMA tiles ----------------
   const int mw = m0 + wm * TM * 32;
   const int nw = n0 + wn * TN * 32;
+  if (EPI == EPI_QKV_HEADMAJOR && p.gamma_q && nw < 2 * p.heads * 64) { qkv_store_normalised<TM>(p, acc, mw, nw, hi, l31); return; }
   if (EPI == EPI_GEGLU) {
     const int nout = (nw >> 1) + l31;
     const float bh = p.bias ? p.bias[nw + l31] : 0.f;
@@ -884,6 +915,7 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
     case EPI_GEGLU: launch_gemm_variant<EPI_GEGLU>(stream, p, v); break;
     case EPI_QKV_HEADMAJOR:
       if (p.N != 3 * p.heads * 64) return RAP_ERR_INVALID;
+      if (p.gamma_q && (!p.gamma_k || !(v == 16 || v == 32))) return RAP_ERR_INVALID;      // fused qk-norm lives in the LDS-DMA kernels
       launch_gemm_variant<EPI_QKV_HEADMAJOR>(stream, p, v);
       break;
     case EPI_BIAS_ANCHOR: launch_gemm_variant<EPI_BIAS_ANCHOR>(stream, p, v); break;

@@ -31,6 +31,9 @@ struct GemmParams {
   // splitk_ws (>= 4 * M * N floats) is given and the tile grid would cover under a quarter of the block slots, K is split over 4
   // blocks per tile writing partial tiles to splitk_ws, and a combine pass adds residual + bias + partials (deterministic order)
   float* splitk_ws;
+  // EPI_QKV_HEADMAJOR with gamma_q / gamma_k set: MultiHeadRMSNorm (norm.py:28-33) fused -- q and k leave the GEMM normalised
+  // (x / max(|x|, 1e-12) * gamma * 8 per head row), v unchanged; NULL = plain projection
+  const float* gamma_q; const float* gamma_k;
   int stagger;     // set by launch_gemm_f32 (tuning key 4): 0 off, 1 first-wave blocks [256,512) start half a tile late, 2 by CU slot
 };
 int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p);

@@ -465,3 +465,26 @@ def test_inconsistent_batch_is_reported_and_never_reads_out_of_bounds(dev):
     # the parts before the defect are untouched by it
     n0 = 64 + 96
     assert torch.equal(out_bad["end_point_trajectory"][:, :n0], out["end_point_trajectory"][:, :n0])
+
+
+def test_fp32_fused_qknorm_agrees_with_the_unfused_path(dev):
+    """rap_set_tuning(7, .) in fp32: MultiHeadRMSNorm inside the QKV GEMM epilogue vs the qknorm kernel -- identical inputs (the fp32
+    accumulators), identical operation order except the summation order of the 64 squares of a head row."""
+    from rap_amd import _lib
+    lib = _lib.load()
+    g, inp = load_golden("l12_small_rigid")
+    cfg, sd, model = get_model(12, int(g["weight_seed"]), dev)
+    cu_b, cu_p = O.prepare_cu_seqlens(inp)
+    d = to_dev(inp, dev)
+    outs = {}
+    try:
+        for fused in (1, 0):
+            assert lib.rap_set_tuning(7, fused) == 0
+            outs[fused] = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
+                                local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                                cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev)).cpu()
+    finally:
+        assert lib.rap_set_tuning(7, 1) == 0
+    v_ref = torch.from_numpy(g["fwd_velocity"])
+    assert (outs[1] - outs[0]).abs().max().item() < 2e-6
+    assert (outs[1] - v_ref).abs().max().item() < 2e-5 and (outs[0] - v_ref).abs().max().item() < 2e-5
