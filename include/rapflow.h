@@ -178,6 +178,9 @@ size_t rap_spinnet_workspace_bytes(int32_t keypoints_per_chunk);
  * (R = I); 0 = every patch is rotated so that its own normal -- the singular vector of the smallest singular value of the patch
  * covariance, oriented towards the origin (cal_Z_axis, utils/common.py:539-557) -- becomes +z (RodsRotatFormula, :472-496). */
 int rap_spinnet_set_alignment(rap_spinnet* m, int32_t aligned_to_global_z);
+/* A/B knob: 1 (default) = the seven 3x3 cylindrical convolutions as implicit GEMMs (spin_conv3x3_kernel: the im2col gather happens in the
+ * LDS-DMA source addresses, 32- / 64- / 128-column tiles); 0 = the round-1 path (materialised im2col + the fp32 GEMM at 128 padded columns). */
+int rap_spinnet_set_conv_path(rap_spinnet* m, int32_t implicit_gemm);
 int rap_spinnet_describe(const rap_spinnet* m, const float* pts, const int32_t* perm, int64_t N, const float* kpts, int32_t K,
                          float des_r, float* desc_out, int32_t keypoints_per_chunk, void* ws, size_t ws_bytes, void* stream);
 

@@ -908,7 +908,7 @@ extern "C" int rap_overlap_ratio(const float* pointclouds_pred, const int64_t* p
 // MiniSpinNet local feature extractor
 // ---------------------------------------------------------------------------------------------
 #include <cmath>
-struct SpinLayer { int Cin, Cout, Kd, ldw; bool bn_relu; const float* W; const float* b; };
+struct SpinLayer { int Cin, Cout, Kd, ldw; bool bn_relu; const float* W; const float* b; const float* Wt; const float* bt; };   // Wt / bt: tap-major (implicit GEMM)
 struct rap_spinnet {
   float* raw = nullptr;       // the caller's blob (MiniSpinNet.state_dict() float tensors, registration order)
   float* derived = nullptr;   // folded + padded conv weights / biases, voxel table, pool weights
@@ -916,6 +916,8 @@ struct rap_spinnet {
   const float* vox;           // (420,3)
   const void* pool_w;         // SpinPoolW on the device
   SpinLayer layers[8];
+  const float* zeros = nullptr;   // 256 bytes of zeros: the elevation pad of the implicit-GEMM convolutions
+  int implicit = 1;           // 1 (default): layers 1-7 as implicit GEMMs (spin_conv3x3_kernel); 0: the r01 im2col + GEMM path
   int lrf = 0;                // 1: patches are aligned to their own normal (is_aligned_to_global_z = False)
 };
 static const int kSpinCin[8] = {16, 64, 64, 128, 128, 64, 64, 32};
@@ -947,7 +949,8 @@ extern "C" int rap_spinnet_create(const float* d_weights, int64_t n_floats, void
   auto fail = [&](int code) { rap_spinnet_destroy(m); return code; };
   if (hipMalloc((void**)&m->raw, (size_t)n_floats * 4) != hipSuccess) { delete m; return RAP_ERR_ALLOC; }
   size_t n_der = 420 * 3 + 1024;      // voxel table + pool struct (613 floats used)
-  for (int i = 0; i < 8; ++i) n_der += (size_t)128 * (i == 0 ? 448 : kSpinCin[i] * 9) + 128;
+  for (int i = 0; i < 8; ++i) n_der += (size_t)128 * (i == 0 ? 448 : kSpinCin[i] * 9) + 128 + (i ? (size_t)kSpinCout[i] * kSpinCin[i] * 9 + 128 : (size_t)64 * 448 + 128);
+  n_der += 64;      // zero page
   if (hipMalloc((void**)&m->derived, n_der * 4) != hipSuccess) return fail(RAP_ERR_ALLOC);
   if (hipMemcpyAsync(m->raw, d_weights, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail(RAP_ERR_HIP);
   // ---- small heads on the host: point MLP (128 floats) and attention pool (613 floats)
@@ -1007,8 +1010,17 @@ extern "C" int rap_spinnet_create(const float* d_weights, int64_t n_floats, void
     float* bd = q; q += 128;
     int rc;
     if ((rc = launch_spin_fold(stream, W, b, nullptr, nullptr, rm, rv, L.Cout, L.Kd, Wd, L.ldw, 128, bd))) return fail(rc);
-    L.W = Wd; L.b = bd;
+    L.W = Wd; L.b = bd; L.Wt = nullptr; L.bt = nullptr;
+    {
+      const int ldt = i == 0 ? 448 : L.Kd;
+      float* Wt = q; q += (size_t)L.Cout * ldt;
+      float* bt = q; q += 128;
+      if ((rc = launch_spin_fold_tapmajor(stream, W, b, rm, rv, L.Cin, L.Cout, i == 0 ? 27 : 9, ldt, Wt, bt))) return fail(rc);
+      L.Wt = Wt; L.bt = bt;
+    }
   }
+  if (hipMemsetAsync(q, 0, 256, stream) != hipSuccess) return fail(RAP_ERR_HIP);
+  m->zeros = q; q += 64;
   if ((int64_t)(p - m->raw) != n_floats) return fail(RAP_ERR_INVALID);
   *out = m;
   return RAP_OK;
@@ -1027,6 +1039,12 @@ static SpinWs carve_spin(int Kc, char* basep) {
 }
 extern "C" size_t rap_spinnet_workspace_bytes(int32_t keypoints_per_chunk) {
   return keypoints_per_chunk <= 0 ? 0 : carve_spin(keypoints_per_chunk, nullptr).total;
+}
+
+extern "C" int rap_spinnet_set_conv_path(rap_spinnet* m, int32_t implicit_gemm) {
+  if (!m) return RAP_ERR_INVALID;
+  m->implicit = implicit_gemm ? 1 : 0;
+  return RAP_OK;
 }
 
 extern "C" int rap_spinnet_set_alignment(rap_spinnet* m, int32_t aligned_to_global_z) {
@@ -1051,17 +1069,27 @@ extern "C" int rap_spinnet_describe(const rap_spinnet* m, const float* pts, cons
     if ((rc = launch_spin_patch(stream, pts, perm, (long)N, kpts + (size_t)k0 * 3, Kc, des_r, m->vox, m->h_w1, m->h_b1, w.x0, m->lrf))) return rc;
     float* yin = nullptr;
     float* yout = w.Y0;
+    int ld_in = 128;
     for (int i = 0; i < 8; ++i) {
       const SpinLayer& L = m->layers[i];
-      if (i == 0) rc = launch_spin_im2col3d(stream, w.x0, Kc, w.A, L.ldw);
-      else rc = launch_spin_im2col2d(stream, yin, 128, L.Cin, Kc, w.A);
-      if (rc) return rc;
-      GemmParams g{};
-      g.A = w.A; g.lda = L.ldw; g.W = L.W; g.ldw = L.ldw; g.C = yout; g.ldc = 128; g.M = M; g.N = 128; g.K = L.ldw; g.bias = L.b;
-      if ((rc = launch_gemm_f32(stream, L.bn_relu ? EPI_BIAS_RELU : EPI_BIAS, g))) return rc;
+      if (m->implicit) {
+        // implicit GEMM: the gather of the 3x3(x3) cylindrical neighbourhood happens in the DMA source addresses, output is dense (M, Cout)
+        if (i == 0) rc = launch_spin_conv3d(stream, w.x0, L.Wt, L.bt, m->zeros, yout, M);
+        else rc = launch_spin_conv3x3(stream, yin, ld_in, L.Cin, L.Wt, L.bt, m->zeros, yout, L.Cout, M, L.bn_relu);
+        if (rc) return rc;
+        ld_in = L.Cout;
+      } else {
+        if (i == 0) rc = launch_spin_im2col3d(stream, w.x0, Kc, w.A, L.ldw);
+        else rc = launch_spin_im2col2d(stream, yin, 128, L.Cin, Kc, w.A);
+        if (rc) return rc;
+        GemmParams g{};
+        g.A = w.A; g.lda = L.ldw; g.W = L.W; g.ldw = L.ldw; g.C = yout; g.ldc = 128; g.M = M; g.N = 128; g.K = L.ldw; g.bias = L.b;
+        if ((rc = launch_gemm_f32(stream, L.bn_relu ? EPI_BIAS_RELU : EPI_BIAS, g))) return rc;
+        ld_in = 128;
+      }
       yin = yout; yout = (yout == w.Y0) ? w.Y1 : w.Y0;
     }
-    if ((rc = launch_spin_pool(stream, yin, 128, Kc, m->pool_w, desc_out + (size_t)k0 * 32))) return rc;
+    if ((rc = launch_spin_pool(stream, yin, ld_in, Kc, m->pool_w, desc_out + (size_t)k0 * 32))) return rc;
   }
   return RAP_OK;
 }

@@ -209,3 +209,8 @@ int launch_statistical_outliers(hipStream_t stream, const float* pts, long N, in
                                 int32_t* count_out, double* stats_out, void* ws);
 int launch_voxel_coverage(hipStream_t stream, const float* pts, long N, float vs, const long long* h_bounds6, unsigned char* table, long slots,
                           unsigned long long* total);
+int launch_spin_conv3x3(hipStream_t stream, const float* y, int ldy, int Cin, const float* Wt, const float* bias, const float* zeros, float* out,
+                        int Cout, int M, bool relu);
+int launch_spin_fold_tapmajor(hipStream_t stream, const float* W, const float* b, const float* rm, const float* rv, int Cin, int Cout, int ntap, int ldt,
+                              float* Wt, float* bout);
+int launch_spin_conv3d(hipStream_t stream, const float* x0, const float* Wt448, const float* bias, const float* zeros, float* out, int M);

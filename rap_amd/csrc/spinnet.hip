@@ -53,26 +53,56 @@ __global__ __launch_bounds__(256) void spin_patch_kernel(const float* __restrict
   for (int i = tid; i < SP_PATCH; i += 256) { patch[i * 3 + 0] = kx; patch[i * 3 + 1] = ky; patch[i * 3 + 2] = kz; }
   if (tid == 0) total_s = 0;
   __syncthreads();
-  // ---- ordered ball query: first 512 in-radius points in index order (pytorch3d ball_query: dist2 < radius2)
-  for (long base = 0; base < N; base += 256) {
+  // ---- ordered ball query: first 512 in-radius points in index order (pytorch3d ball_query: dist2 < radius2).
+  // 1024 candidates per block iteration, 4 CONSECUTIVE indices per thread (r02: a quarter of the block-wide barriers of the
+  // one-point-per-thread scan); a thread's hits go to slots before + (hits of lower lanes) + (own earlier hits), where the lane prefix of
+  // the per-thread counts 0..4 comes from three ballots (one per bit of the count).
+  for (long base = 0; base < N; base += 1024) {
     const int total = total_s;
     if (total >= SP_PATCH) break;
-    const long i = base + tid;
-    float px = 0.f, py = 0.f, pz = 0.f;
-    bool in = false;
-    if (i < N) {
-      const long src = perm ? (long)perm[i] : i;
-      px = pts[src * 3 + 0]; py = pts[src * 3 + 1]; pz = pts[src * 3 + 2];
-      const float dx = px - kx, dy = py - ky, dz = pz - kz;
-      in = (dx * dx + dy * dy + dz * dz) < r2;
+    float px[4], py[4], pz[4];
+    bool in[4];
+    int cnt = 0;
+    if (!perm && base + tid * 4 + 3 < N) {
+      // the caller's order IS the scan order (the host mirror gathers pts[perm] once): 4 consecutive points = 48 contiguous bytes
+      const float4* q4 = reinterpret_cast<const float4*>(pts + (base + tid * 4) * 3);
+      const float4 u0 = q4[0], u1 = q4[1], u2 = q4[2];
+      px[0] = u0.x; py[0] = u0.y; pz[0] = u0.z; px[1] = u0.w; py[1] = u1.x; pz[1] = u1.y;
+      px[2] = u1.z; py[2] = u1.w; pz[2] = u2.x; px[3] = u2.y; py[3] = u2.z; pz[3] = u2.w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dx = px[j] - kx, dy = py[j] - ky, dz = pz[j] - kz;
+        in[j] = (dx * dx + dy * dy + dz * dz) < r2;
+        cnt += in[j] ? 1 : 0;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long i = base + tid * 4 + j;
+        in[j] = false; px[j] = py[j] = pz[j] = 0.f;
+        if (i < N) {
+          const long src = perm ? (long)perm[i] : i;
+          px[j] = pts[src * 3 + 0]; py[j] = pts[src * 3 + 1]; pz[j] = pts[src * 3 + 2];
+          const float dx = px[j] - kx, dy = py[j] - ky, dz = pz[j] - kz;
+          in[j] = (dx * dx + dy * dy + dz * dz) < r2;
+        }
+        cnt += in[j] ? 1 : 0;
+      }
     }
-    const unsigned long long m = __ballot(in);
-    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long m0 = __ballot(cnt & 1), m1 = __ballot(cnt & 2), m2 = __ballot(cnt & 4);
+    const int lane_prefix = __popcll(m0 & lt) + 2 * __popcll(m1 & lt) + 4 * __popcll(m2 & lt);
+    if (lane == 0) wave_cnt[wave] = __popcll(m0) + 2 * __popcll(m1) + 4 * __popcll(m2);
     __syncthreads();
-    int before = total;
-    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-    const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
-    if (in && slot < SP_PATCH) { patch[slot * 3 + 0] = px; patch[slot * 3 + 1] = py; patch[slot * 3 + 2] = pz; }
+    int slot = total + lane_prefix;
+    for (int w = 0; w < wave; ++w) slot += wave_cnt[w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (in[j]) {
+        if (slot < SP_PATCH) { patch[slot * 3 + 0] = px[j]; patch[slot * 3 + 1] = py[j]; patch[slot * 3 + 2] = pz[j]; }
+        ++slot;
+      }
+    }
     __syncthreads();
     if (tid == 0) total_s = total + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     __syncthreads();
@@ -184,6 +214,230 @@ __global__ __launch_bounds__(256) void spin_patch_kernel(const float* __restrict
     dst[2] = make_float4(best[8], best[9], best[10], best[11]);
     dst[3] = make_float4(best[12], best[13], best[14], best[15]);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage 2 (r02): the seven 3x3 cylindrical convolutions as IMPLICIT GEMMs on the fp32 matrix cores -- no im2col round trip (r01: the
+// materialised (K*140, 9 Cin) matrix cost 3.4 of the 8 ms per 2048-keypoint chunk) and no padding of the 32- / 64-channel layers to 128
+// output columns (r01: 4x / 2x the MFMA work on those layers).
+//   C[(k,h,w)][n] = bias[n] + sum_{tap=(dy,dx)} sum_ci  y[k][h+dy-1][(w+dx-1) mod 20][ci] * Wt[n][tap*Cin + ci]      (+ ReLU)
+// Structure = gemm_f32_dma_kernel (LDS-DMA tiles, XOR slot swizzle, v_mfma_f32_32x32x2_f32, two LDS stages, two blocks per CU): the
+// contraction index is ordered tap-major, so a 32-float k-tile lies inside ONE tap (Cin is a multiple of 32) and the A row piece of a
+// pixel is 128 contiguous bytes of the shifted input pixel -- the per-lane DMA source address does the im2col gather; rows outside the
+// elevation range (zero pad) read a zero page.  Activations are channels-last with exactly Cin / Cout floats per pixel.
+// Block tile (64 WM) x (32 TN WN): 128 x 128 for the 128-channel layers, 256 x 64 and 256 x 32 for the 64- / 32-channel ones.
+// ---------------------------------------------------------------------------------------------
+struct SpinConvParams {
+  const float* y; int ldy; int Cin;   // input (M, ldy) channels-last (Cin meaningful floats per pixel), M = K * 140 pixels
+  const float* Wt;                // (Cout, 9 * Cin) tap-major, BatchNorm folded
+  const float* bias;              // (Cout)
+  const float* zeros;             // >= 128 bytes of zeros
+  float* out; int Cout;           // output (M, Cout)
+  int M;
+};
+// C3D: the first layer, Conv3d 16 -> 64 over the (3 radial, 7 elevation, 20 azimuth) grid with no radial pad (3 -> 1): 27 taps x 16 input channels =
+// 432 contraction values, padded to 14 k-tiles; a 16-byte DMA chunk (4 channels) lies inside one tap, so every lane gathers its own chunk.
+template <int WM, int WN, int TN, int RELU, int C3D = 0>
+__global__ __launch_bounds__(256, 2) void spin_conv3x3_kernel(SpinConvParams p) {
+  constexpr int BM = 64 * WM, BN = 32 * TN * WN;
+  constexpr int CA = BM * 8 / 256, CB = (BN * 8 + 255) / 256;
+  constexpr int AF = BM * 32, BF = BN * 32;                     // floats per A / B stage
+  static_assert(WM * WN == 4, "four waves");
+  extern __shared__ __attribute__((aligned(1024))) float smem_c[];   // [A0 A1 B0 B1]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM;                                // BN == Cout: one n-tile
+
+  // A chunk i of this thread: LDS row (i*256 + tid) >> 3 = pixel m0 + row, slot (id & 7) holding logical slot (slot ^ swz(row))
+  int a_pix[CA], a_h[CA], a_w[CA], a_ls[CA];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int id = i * 256 + tid;
+    const int row = id >> 3;
+    int m = m0 + row; m = m < p.M ? m : p.M - 1;
+    a_ls[i] = 4 * ((id & 7) ^ ((row >> 1) & 7));
+    a_w[i] = m % SP_AZI; a_h[i] = (m / SP_AZI) % SP_ELE; a_pix[i] = m - a_h[i] * SP_AZI - a_w[i];      // first pixel of the keypoint
+    if (C3D) a_pix[i] *= 3;                                                                            // 420 input voxels per keypoint
+  }
+  const float* w_src[CB];
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int id = i * 256 + tid;
+    const int row = (id >> 3) < BN ? (id >> 3) : BN - 1;
+    w_src[i] = p.Wt + (size_t)row * (C3D ? 448 : 9 * p.Cin) + 4 * ((id & 7) ^ ((row >> 1) & 7));
+  }
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = C3D ? 14 : 9 * p.Cin / 32;
+  const int tiles_per_tap = C3D ? 1 : p.Cin / 32;
+  const int sw = (l31 >> 1) & 7;
+  const int a_row = (wm * 64 + l31) * 32;
+  const int b_row = 2 * AF + (wn * 32 * TN + l31) * 32;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem_c;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+#define SC_DMA1(GSRC, LDSB)                                                                                   \
+  {                                                                                                           \
+    unsigned keep_;                                                                                           \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(GSRC), "s"(LDSB) : "memory");                                           \
+  }
+  auto dma = [&](int kt, int buf) {
+    const int tap = kt / tiles_per_tap, c0 = (kt - tap * tiles_per_tap) * 32;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const float* src;
+      if (C3D) {
+        const int kidx = kt * 32 + a_ls[i];                       // this lane's 4 contraction values: one tap, 4 channels
+        const int t3 = kidx >> 4, ci0 = kidx & 15;
+        const int dz = t3 / 9, r9 = t3 - 9 * dz;
+        const int hh = a_h[i] + r9 / 3 - 1;
+        int ww = a_w[i] + r9 % 3 - 1; ww = ww < 0 ? ww + SP_AZI : (ww >= SP_AZI ? ww - SP_AZI : ww);
+        src = (t3 < 27 && hh >= 0 && hh < SP_ELE) ? p.y + (size_t)(a_pix[i] + dz * (SP_ELE * SP_AZI) + hh * SP_AZI + ww) * 16 + ci0 : p.zeros;
+      } else {
+        const int hh = a_h[i] + dy;
+        int ww = a_w[i] + dx; ww = ww < 0 ? ww + SP_AZI : (ww >= SP_AZI ? ww - SP_AZI : ww);
+        src = (hh >= 0 && hh < SP_ELE) ? p.y + (size_t)(a_pix[i] + hh * SP_AZI + ww) * p.ldy + c0 + a_ls[i] : p.zeros + a_ls[i];
+      }
+      SC_DMA1(src, lds_wave + (unsigned)((buf * AF + i * 1024) * 4))
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+      if (CB * 256 <= BN * 8 || i * 256 + tid < BN * 8)            // BN = 32: only the first 256 chunks exist
+        SC_DMA1(w_src[i] + (size_t)kt * 32, lds_wave + (unsigned)((2 * AF + buf * BF + i * 1024) * 4))
+  };
+#define SC_SYNC asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+#define SC_RD(OFF) (*reinterpret_cast<const float4*>(&smem_c[OFF]))
+  struct Frag { float4 a0, a1, b[TN]; } f0, f1;
+  auto read_frag = [&](Frag& f, int buf, int g) {
+    const int co = ((2 * g + hi) ^ sw) * 4;
+    f.a0 = SC_RD(buf * AF + a_row + co);
+    f.a1 = SC_RD(buf * AF + a_row + 32 * 32 + co);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) f.b[j] = SC_RD(buf * BF + b_row + j * 32 * 32 + co);
+  };
+#define SC_STEP(F, C)                                                                                        \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                           \
+    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a0.C, F.b[j].C, acc[0][j], 0, 0, 0);                   \
+    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a1.C, F.b[j].C, acc[1][j], 0, 0, 0);                   \
+  }
+#define SC_MFMA(F) SC_STEP(F, x) SC_STEP(F, y) SC_STEP(F, z) SC_STEP(F, w)
+#define SC_FENCE __builtin_amdgcn_sched_barrier(0);
+
+  dma(0, 0);
+  SC_SYNC
+  read_frag(f0, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) dma(kt + 1, cur ^ 1);
+    read_frag(f1, cur, 1);
+    SC_FENCE
+    SC_MFMA(f0)
+    SC_FENCE
+    read_frag(f0, cur, 2);
+    SC_FENCE
+    SC_MFMA(f1)
+    SC_FENCE
+    read_frag(f1, cur, 3);
+    SC_FENCE
+    SC_MFMA(f0)
+    SC_FENCE
+    SC_SYNC                                   // tile kt+1 landed and visible; every wave is done reading tile kt
+    if (more) read_frag(f0, cur ^ 1, 0);
+    SC_FENCE
+    SC_MFMA(f1)
+    SC_FENCE
+  }
+  // epilogue: lane = output channel, registers = pixels (32 consecutive channels per store instruction: 128-byte row pieces)
+  const int mw = m0 + wm * 64, nw = wn * 32 * TN;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nw + 32 * j + l31;
+      const float bn = p.bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + mi * 32 + mfma32_crow(r, hi);
+        if (m < p.M) {
+          const float v = acc[mi][j][r] + bn;
+          p.out[(size_t)m * p.Cout + n] = RELU ? fmaxf(v, 0.f) : v;
+        }
+      }
+    }
+}
+
+template <int WM, int WN, int TN>
+static int launch_spin_conv_cfg(hipStream_t stream, const SpinConvParams& p, bool relu) {
+  constexpr int BM = 64 * WM, BN = 32 * TN * WN;
+  constexpr int LDS = 2 * (BM + BN) * 32 * 4;
+  auto k1 = spin_conv3x3_kernel<WM, WN, TN, 1>;
+  auto k0 = spin_conv3x3_kernel<WM, WN, TN, 0>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)((p.M + BM - 1) / BM);
+  if (relu) hipLaunchKernelGGL(k1, dim3(grid), dim3(256), LDS, stream, p);
+  else hipLaunchKernelGGL(k0, dim3(grid), dim3(256), LDS, stream, p);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+int launch_spin_conv3x3(hipStream_t stream, const float* y, int ldy, int Cin, const float* Wt, const float* bias, const float* zeros, float* out,
+                        int Cout, int M, bool relu) {
+  if (M <= 0) return RAP_OK;
+  if (Cin % 32 != 0) return RAP_ERR_INVALID;
+  SpinConvParams p{y, ldy, Cin, Wt, bias, zeros, out, Cout, M};
+  if (Cout == 128) return launch_spin_conv_cfg<2, 2, 2>(stream, p, relu);
+  if (Cout == 64) return launch_spin_conv_cfg<4, 1, 2>(stream, p, relu);
+  if (Cout == 32) return launch_spin_conv_cfg<4, 1, 1>(stream, p, relu);
+  return RAP_ERR_INVALID;
+}
+
+int launch_spin_conv3d(hipStream_t stream, const float* x0, const float* Wt448, const float* bias, const float* zeros, float* out, int M) {
+  if (M <= 0) return RAP_OK;
+  constexpr int LDS = 2 * (256 + 64) * 32 * 4;
+  auto kern = spin_conv3x3_kernel<4, 1, 2, 1, 1>;
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_done = true; }
+  SpinConvParams p{x0, 16, 16, Wt448, bias, zeros, out, 64, M};
+  hipLaunchKernelGGL(kern, dim3((unsigned)((M + 255) / 256)), dim3(256), LDS, stream, p);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
+// Wt[n][tap * Cin + ci] = W[n][ci * 9 + tap] * s (BatchNorm folded), bias likewise -- the tap-major weights of spin_conv3x3_kernel
+// (ntap = 9 for the 2-d layers; 27 for the Conv3d, whose rows are padded with zeros to ldt = 448)
+__global__ __launch_bounds__(256) void spin_fold_tapmajor_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ rm,
+                                                                 const float* __restrict__ rv, int Cin, int ntap, int ldt, float* __restrict__ Wt,
+                                                                 float* __restrict__ bout) {
+  const int n = blockIdx.x;
+  float s = 1.f, sh = 0.f;
+  if (rv) { s = 1.f / sqrtf(rv[n] + 1e-5f); sh = -rm[n] * s; }
+  for (int c = threadIdx.x; c < ldt; c += 256) {
+    const int tap = c / Cin, ci = c - tap * Cin;
+    Wt[(size_t)n * ldt + c] = tap < ntap ? W[(size_t)n * ntap * Cin + ci * ntap + tap] * s : 0.f;
+  }
+  if (threadIdx.x == 0) bout[n] = b[n] * s + sh;
+}
+int launch_spin_fold_tapmajor(hipStream_t stream, const float* W, const float* b, const float* rm, const float* rv, int Cin, int Cout, int ntap, int ldt,
+                              float* Wt, float* bout) {
+  hipLaunchKernelGGL(spin_fold_tapmajor_kernel, dim3(Cout), dim3(256), 0, stream, W, b, rm, rv, Cin, ntap, ldt, Wt, bout);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

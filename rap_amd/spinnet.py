@@ -147,7 +147,9 @@ class MiniSpinNet:
         N, K = p.shape[0], kp.shape[0]
         if perm is None:
             perm = np.random.choice(N, N, replace=False)
-        perm_d = torch.as_tensor(np.asarray(perm), dtype=torch.int32).to(device)
+        # the shuffle is applied once here (a gather: data movement only), so the kernel scans a contiguous cloud in the shuffled order
+        p = p[torch.as_tensor(np.asarray(perm), dtype=torch.int64).to(device)].contiguous()
+        perm_d = None
         desc = torch.empty((K, 32), dtype=torch.float32, device=device)
         lib = _lib.load()
         chunk = max(1, min(self.keypoints_per_chunk, K))
