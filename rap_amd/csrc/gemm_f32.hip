@@ -17,6 +17,7 @@
 //    tile t+1 are issued before the 64 MFMAs of tile t.
 //  * 1-D grid, XCD-aware remap, n-tile fastest: all n-tiles of one 128-row A panel run back to
 //    back on one XCD (A panel stays in that XCD's L2; W streams from L2 / Infinity Cache).
+#include <type_traits>
 #include "kernels.h"
 
 #define GBM 128
@@ -597,55 +598,94 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
     const int nout = (nw >> 1) + l31;
     const float bh = p.bias ? p.bias[nw + l31] : 0.f;
     const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+    auto geglu = [&](auto G) {                       // G: guard rows against M (only the last row tile needs it)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mw + mi * 32 + mfma32_crow(r, hi);
-        if (m < p.M) {
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + mi * 32 + mfma32_crow(r, hi);
+          if (decltype(G)::value && m >= p.M) continue;
           const float h = acc[mi][0][r] + bh;
           const float g = acc[mi][1][r] + bg;
           const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
           p.C[(size_t)m * p.ldc + nout] = h * ge;
         }
       }
-    }
+    };
+    if (mw + 64 <= p.M) geglu(std::false_type{}); else geglu(std::true_type{});
     return;
   }
+  if (EPI == EPI_BIAS_RESID) {
+    // r02: the residual rows are loaded UNCONDITIONALLY (row index clamped) and all 64 loads of the wave tile are issued before the
+    // first use -- the per-register `if (m < M)` of the generic loop made hipcc emit load -> wait -> add -> store 64 times in a row
+    // (64 exposed memory latencies per tile: the K = 512 shapes ran at 0.67-0.70 of the matrix peak against 0.84 at K = 2048).
+    const bool full = mw + 64 <= p.M;
+    float rr[2][2][16];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int n = nw + ni * 32 + l31;
-      const float bn = p.bias ? p.bias[n] : 0.f;
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mw + mi * 32 + mfma32_crow(r, hi);
-        if (m >= p.M) continue;
-        float v = acc[mi][ni][r] + bn;
-        if (EPI == EPI_BIAS) {
-          p.C[(size_t)m * p.ldc + n] = v;
-        } else if (EPI == EPI_SPLITK_PART) {
-          p.splitk_ws[((size_t)blockIdx.y * p.M + m) * p.N + n] = acc[mi][ni][r];
-        } else if (EPI == EPI_BIAS_RESID) {
-          p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
-        } else if (EPI == EPI_BIAS_SILU) {
-          p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
-        } else if (EPI == EPI_BIAS_RELU) {
-          p.C[(size_t)m * p.ldc + n] = fmaxf(v, 0.f);
-        } else if (EPI == EPI_BIAS_ANCHOR) {
-          const int sel = p.anchor[m] ? 1 : 0;
-          p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
-        } else if (EPI == EPI_QKV_HEADMAJOR) {
-          const int dmodel = p.heads * 64;
-          const int c = n / dmodel;
-          const int rem = n - c * dmodel;
-          const int h = rem >> 6, j = rem & 63;
-          p.C[(((size_t)c * p.heads + h) * p.M + m) * 64 + j] = v;
+        for (int r = 0; r < 16; ++r) {
+          int m = mw + mi * 32 + mfma32_crow(r, hi);
+          m = m < p.M ? m : p.M - 1;
+          rr[mi][ni][r] = p.resid[(size_t)m * p.ldr + nw + ni * 32 + l31];
+        }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = nw + ni * 32 + l31;
+        const float bn = p.bias ? p.bias[n] : 0.f;
+        if (full) {                                  // wave-uniform: straight-line stores
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            p.C[(size_t)(mw + mi * 32 + mfma32_crow(r, hi)) * p.ldc + n] = rr[mi][ni][r] + (acc[mi][ni][r] + bn);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mw + mi * 32 + mfma32_crow(r, hi);
+            if (m < p.M) p.C[(size_t)m * p.ldc + n] = rr[mi][ni][r] + (acc[mi][ni][r] + bn);
+          }
+        }
+      }
+    return;
+  }
+  auto store_tile = [&](auto G) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = nw + ni * 32 + l31;
+        const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + mi * 32 + mfma32_crow(r, hi);
+          if (decltype(G)::value && m >= p.M) continue;
+          float v = acc[mi][ni][r] + bn;
+          if (EPI == EPI_BIAS) {
+            p.C[(size_t)m * p.ldc + n] = v;
+          } else if (EPI == EPI_SPLITK_PART) {
+            p.splitk_ws[((size_t)blockIdx.y * p.M + m) * p.N + n] = acc[mi][ni][r];
+          } else if (EPI == EPI_BIAS_SILU) {
+            p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
+          } else if (EPI == EPI_BIAS_RELU) {
+            p.C[(size_t)m * p.ldc + n] = fmaxf(v, 0.f);
+          } else if (EPI == EPI_BIAS_ANCHOR) {
+            const int sel = p.anchor[m] ? 1 : 0;
+            p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
+          } else if (EPI == EPI_QKV_HEADMAJOR) {
+            const int dmodel = p.heads * 64;
+            const int c = n / dmodel;
+            const int rem = n - c * dmodel;
+            const int h = rem >> 6, j = rem & 63;
+            p.C[(((size_t)c * p.heads + h) * p.M + m) * 64 + j] = v;
+          }
         }
       }
     }
-  }
+  };
+  if (mw + 64 <= p.M) store_tile(std::false_type{}); else store_tile(std::true_type{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -788,21 +828,56 @@ __global__ __launch_bounds__(512) void gemm_f32_dma256_kernel(GemmParams p) {
     const int nout = (nw >> 1) + l31;
     const float bh = p.bias ? p.bias[nw + l31] : 0.f;
     const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+    auto geglu = [&](auto G) {
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
+      for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mw + mi * 32 + mfma32_crow(r, hi);
-        if (m < p.M) {
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + mi * 32 + mfma32_crow(r, hi);
+          if (decltype(G)::value && m >= p.M) continue;
           const float h = acc[mi][0][r] + bh;
           const float g = acc[mi][1][r] + bg;
           const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
           p.C[(size_t)m * p.ldc + nout] = h * ge;
         }
       }
+    };
+    if (mw + 32 * TM <= p.M) geglu(std::false_type{}); else geglu(std::true_type{});
+    return;
+  }
+  if (EPI == EPI_BIAS_RESID) {                     // see gemm_f32_dma_kernel: unconditional, batched residual loads
+    const bool full = mw + 32 * TM <= p.M;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      float rr[TN][16];
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = mw + mi * 32 + mfma32_crow(r, hi);
+          m = m < p.M ? m : p.M - 1;
+          rr[ni][r] = p.resid[(size_t)m * p.ldr + nw + ni * 32 + l31];
+        }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int n = nw + ni * 32 + l31;
+        const float bn = p.bias ? p.bias[n] : 0.f;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            p.C[(size_t)(mw + mi * 32 + mfma32_crow(r, hi)) * p.ldc + n] = rr[ni][r] + (acc[mi][ni][r] + bn);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mw + mi * 32 + mfma32_crow(r, hi);
+            if (m < p.M) p.C[(size_t)m * p.ldc + n] = rr[ni][r] + (acc[mi][ni][r] + bn);
+          }
+        }
+      }
     }
     return;
   }
+  auto store_tile = [&](auto G) {
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
@@ -812,12 +887,10 @@ __global__ __launch_bounds__(512) void gemm_f32_dma256_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mw + mi * 32 + mfma32_crow(r, hi);
-        if (m >= p.M) continue;
+        if (decltype(G)::value && m >= p.M) continue;
         const float v = acc[mi][ni][r] + bn;
         if (EPI == EPI_BIAS) {
           p.C[(size_t)m * p.ldc + n] = v;
-        } else if (EPI == EPI_BIAS_RESID) {
-          p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
         } else if (EPI == EPI_BIAS_SILU) {
           p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
         } else if (EPI == EPI_BIAS_RELU) {
@@ -835,6 +908,8 @@ __global__ __launch_bounds__(512) void gemm_f32_dma256_kernel(GemmParams p) {
       }
     }
   }
+  };
+  if (mw + 32 * TM <= p.M) store_tile(std::false_type{}); else store_tile(std::true_type{});
 }
 
 // C[m][n] = resid[m][n] + bias[n] + sum_s part[s][m][n]   (the split-K path of EPI_BIAS_RESID; one thread per 4 columns)
