@@ -68,6 +68,8 @@ def parse_args():
     ap.add_argument("--dtype", default="float32", choices=list(DTYPE_TAG),
                     help="arithmetic of the transformer blocks for the HEADLINE number: float32 = BASELINE configs[1] (default); "
                          "bfloat16 = the per-GPU shard of configs[2]; float16 = the reference's shipped GPU precision")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
+                    help="rap_set_tuning(KEY, VALUE) before the run (A/B experiments; recorded in config.tuning)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra bf16 measurement of the same workload that a float32 run appends as 'reduced_precision'")
     return ap.parse_args()
@@ -176,6 +178,12 @@ def main():
     x_1 = data["x_1"]
     pts_per_rank = args.batch * args.views * args.points
     lib = _lib.load()
+    tuning = {}
+    for kv in args.tuning:
+        key, val = (int(x) for x in kv.split("="))
+        if lib.rap_set_tuning(key, val) != 0:
+            raise SystemExit(f"rap_set_tuning({key}, {val}) refused")
+        tuning[str(key)] = val
     profile = not args.no_profile
 
     def barrier():
@@ -305,6 +313,8 @@ def main():
                        "flow_steps": args.flow_steps, "num_layers": args.layers, "rigidity_forcing": bool(args.rigidity),
                        "sharding": f"independent pairs, {world} rank(s), one RCCL all-gather of clouds+poses per step"},
         }
+        if tuning:
+            result["config"]["tuning"] = tuning
         # host time spent INSIDE the sample call: ~3 300 launches at ~2.6 us each while the HIP queue has room (8.5 ms for a
         # single call), the GPU's own pace once the queue is full (the driver's 20-step run: the call blocks on queue slots)
         result["host_call_ms_per_step"] = host_enqueue_ms

@@ -50,21 +50,25 @@ __device__ __forceinline__ float hmax3(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-template <int DT, int ABL, int OPT>
+// PERSIST (r02, rap_set_tuning(3, 19)): the grid is a fixed number of blocks that walk the (work item, head) list with stride gridDim.x
+// (a multiple of the head count, so a block keeps its head = its XCD) instead of one block per entry.
+template <int DT, int ABL, int OPT, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
                                                                int vt_nblk, u16* __restrict__ out, int TP, int heads,
                                                                const AttnWorkItem* __restrict__ items,
-                                                               const float* __restrict__ bound) {
+                                                               const float* __restrict__ bound, int total_blocks) {
   typedef typename H16<DT>::T8 T8;
   __shared__ __attribute__((aligned(16))) u16 smem[4 * HKV * HLD];
   u16* Ks = smem;                    // [2][64 keys][72]
   u16* Vs = smem + 2 * HKV * HLD;    // [2][64 d][72]   (columns = vt_pos of the key)
 
-  const int head = blockIdx.x % heads;
-  const AttnWorkItem it = items[blockIdx.x / heads];
-  const int len = it.seg_len;
-  if (len <= 0) return;
   const int tid = threadIdx.x;
+  int vb = blockIdx.x;
+  do {
+  const int head = vb % heads;
+  const AttnWorkItem it = items[vb / heads];
+  const int len = it.seg_len;
+  if (len <= 0) continue;
   const int lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int seg0 = it.seg_start, seg1 = it.seg_start + len;
@@ -83,7 +87,10 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
     q = q < len ? q : len - 1;
     const u16* qp = Qg + (size_t)(seg0 + q) * 64 + 8 * hi;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(qp + 16 * s));
+    for (int s = 0; s < 4; ++s) {
+      if (ABL & 128) qf[s] = __builtin_bit_cast(T8, make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u + s, 0x3c003c00u));   // timing-only: no Q loads
+      else qf[s] = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(qp + 16 * s));
+    }
   }
 
   f32x16 o0, o1;
@@ -243,10 +250,11 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
     if (!(ABL & 2)) __syncthreads();
   }
 
-  if (!wave_active) return;
+  if (!wave_active) continue;
   // ---- normalise and store: lane owns query l31; register r of tile e is d = 32e + crow(r, hi): groups of 4 contiguous d
   const int q = qw0 + l31;
   const float inv = 1.0f / h_xhalf_sum(lsum);
+  if ((ABL & 64) && inv != 12345.678f) continue;    // timing-only: no output stores
   if (q < len) {
     u16* op = out + (size_t)(seg0 + q) * (heads * 64) + head * 64 + 4 * hi;
 #pragma unroll
@@ -257,6 +265,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
           h16_pack4<DT>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
     }
   }
+  } while (PERSIST && (vb += (int)gridDim.x) < total_blocks);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -623,6 +632,204 @@ __global__ __launch_bounds__(512, 2) void attention_h16_sp_kernel(const u16* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined kernel, second form (r02 calls 24-26; rap_set_tuning(3, 13)).  scripts/attn_mix.hip runs the instruction mix of
+// this loop with no global traffic in six arrangements (profiles/r02_c24..c26_attn_mix*.jsonl):
+//     phase-serial + barrier per tile (the r01 kernel's structure)            1 200-1 250 TF
+//     pipelined across tiles, groups pinned with sched_barrier (the kernel above)  1 200-1 300
+//     pipelined, order left to the compiler                                    1 490-1 560
+//     ... + one block barrier per TILE                                         1 120-1 220   <- the barrier splits the scheduling region
+//     ... + one block barrier per TWO tiles                                    1 410-1 450
+// so this kernel drops the pins, keeps two tiles in one basic block (the two score register sets swap roles inside it) and
+// synchronises the block once per two tiles: K / V^T are staged TWO tiles ahead into a two-stage ring of two-tile stages
+// (K stage j = K tiles 2j+1, 2j+2; V stage j = V tiles 2j, 2j+1; K(0) has its own buffer), 83 KB of LDS, one 8-wave block per CU.
+// Row sums are plain v_add_f32 on eight independent accumulators (packed fp32 beside MFMAs measured 3 % slower in the mix).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sp2_fadd(float a, float b) {   // one v_add_f32 the SLP vectoriser cannot turn into v_pk_add_f32.
+  float r = a + b;              // NOT an inline-asm add: hipcc's hazard recogniser cannot see into asm, and a VALU read of a
+  asm("" : "+v"(r));            // v_exp_f32 result needs a wait state (r02 call 27: row sums of stale registers); the empty asm only
+  return r;                     // makes the value opaque to the vectoriser and emits nothing.
+}
+#define SP2_TILE_U16 (HKV * HLD)
+#define SP2_LDS_BYTES (9 * SP2_TILE_U16 * 2)
+// ABL (timing only, RAP_ABLATION_BUILD): 1 = no K / V^T stream (every tile re-reads stage 0), 2 = additionally no barriers
+template <int DT, int PRE, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void attention_h16_sp2_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
+                                                                   int vt_nblk, u16* __restrict__ out, int TP, int heads,
+                                                                   const AttnWorkItem* __restrict__ items,
+                                                                   const float* __restrict__ bound) {
+  typedef typename H16<DT>::T8 T8;
+  extern __shared__ __attribute__((aligned(16))) u16 sp2_smem[];
+  u16* K0s = sp2_smem;                              // K tile 0
+  u16* Kst = sp2_smem + SP2_TILE_U16;               // [stage 2][slot 2][64 keys][72]
+  u16* Vst = sp2_smem + 5 * SP2_TILE_U16;           // [stage 2][slot 2][64 d][72]
+
+  const int head = blockIdx.x % heads;
+  const AttnWorkItem it = items[blockIdx.x / heads];
+  const int len = it.seg_len;
+  if (len <= 0) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int seg0 = it.seg_start, seg1 = it.seg_start + len;
+
+  const u16* Qg = qk + (size_t)head * TP * 64;
+  const u16* Kg = qk + (size_t)(heads + head) * TP * 64;
+  const u16* Vg = vt + (size_t)head * vt_nblk * (64 * 64);
+
+  const int qw0 = it.q0 + wave * 32;
+  const bool wave_active = qw0 < len;
+
+  T8 qf[4];
+  {
+    int q = qw0 + l31;
+    q = q < len ? q : len - 1;
+    const u16* qp = Qg + (size_t)(seg0 + q) * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(qp + 16 * s));
+  }
+  f32x16 o0, o1, sa0, sa1, sb0, sb1, zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; sa0[r] = 0.f; sa1[r] = 0.f; sb0[r] = 0.f; sb1[r] = 0.f; zero16[r] = 0.f; }
+  const float c = 0.125f * 1.44269504088896340736f;
+  const float nmc = PRE ? 0.f : -bound[head] * 8.0f * c;
+  float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  const int srow = tid >> 3, sch = (tid & 7) * 8;
+  const int b_first = seg0 >> 6;
+  const int ntile = ((seg1 - 1) >> 6) - b_first + 1;
+  const int soff = srow * HLD + sch;
+  // K tile T / V tile T of this segment (T < ntile); the K row index is clamped, the V^T image is padded to whole blocks
+#define SP2_LDK(T) ({ int tok_ = (b_first + (T)) * 64 + srow; tok_ = tok_ < TP ? tok_ : TP - 1;                \
+                      *reinterpret_cast<const uint4*>(Kg + (size_t)tok_ * 64 + sch); })
+#define SP2_LDV(T) (*reinterpret_cast<const uint4*>(Vg + ((size_t)(b_first + (T)) * 64 + srow) * 64 + sch))
+  {  // prologue: K(0); stage 0 = K(1), K(2), V(0), V(1)
+    const uint4 k0 = SP2_LDK(0);
+    const uint4 v0 = SP2_LDV(0);
+    uint4 k1 = k0, k2 = k0, v1 = v0;
+    if (1 < ntile) { k1 = SP2_LDK(1); v1 = SP2_LDV(1); }
+    if (2 < ntile) k2 = SP2_LDK(2);
+    *reinterpret_cast<uint4*>(K0s + soff) = k0;
+    *reinterpret_cast<uint4*>(Vst + soff) = v0;
+    *reinterpret_cast<uint4*>(Kst + soff) = k1;
+    *reinterpret_cast<uint4*>(Vst + SP2_TILE_U16 + soff) = v1;
+    *reinterpret_cast<uint4*>(Kst + SP2_TILE_U16 + soff) = k2;
+  }
+  __syncthreads();
+  const int lrow = l31 * HLD + 8 * hi;
+  if (wave_active) {                          // S(0) = K(0) Q^T (once per block)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const T8 k0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(K0s + lrow + 16 * s));
+      const T8 k1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(K0s + lrow + 32 * HLD + 16 * s));
+      sa0 = H16<DT>::mfma(k0, qf[s], s == 0 ? zero16 : sa0);
+      sa1 = H16<DT>::mfma(k1, qf[s], s == 0 ? zero16 : sa1);
+    }
+  }
+  // the exponentials of 8 scores -> the 16-bit B operand of one P*V step; row sums into ps[0..7]
+#define SP2_EXP8(SC, RB, PB)                                                                         \
+  {                                                                                                  \
+    float e_[8];                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                  \
+      const float a_ = PRE ? SC[(RB) + u] : __builtin_fmaf(SC[(RB) + u], c, nmc);                    \
+      e_[u] = __builtin_amdgcn_exp2f(a_);                                                            \
+      ps[u] = sp2_fadd(ps[u], e_[u]);                                                                \
+    }                                                                                                \
+    PB = h16_pack8<DT>(e_[0], e_[1], e_[2], e_[3], e_[4], e_[5], e_[6], e_[7]);                      \
+  }
+  // Tile T: SC = finished (and masked) scores of tile T, SN = accumulators of tile T+1; SLOT = T & 1, stage = (T >> 1) & 1.
+  // Straight-line on purpose (one basic block per pair of tiles): the loads of V(T+2) / K(T+3) are unconditional with the tile
+  // index clamped to the last tile (a duplicate lands in a slot nobody reads), and S(T+1) is computed even when T+1 does not
+  // exist except in the peeled last tile (LAST).
+#define SP2_STAGE_LOADS(T, RV, RK)                                                                   \
+  {                                                                                                  \
+    const int tv_ = (T) + 2 < last ? (T) + 2 : last, tk_ = (T) + 3 < last ? (T) + 3 : last;          \
+    RV = SP2_LDV(tv_);                                                                               \
+    RK = SP2_LDK(tk_);                                                                               \
+  }
+#define SP2_STAGE_PARK(T, SLOT, RV, RK)                                                              \
+  {                                                                                                  \
+    const int so_ = (((((T) >> 1) & 1) ^ 1) * 2 + (SLOT)) * SP2_TILE_U16 + soff;                     \
+    *reinterpret_cast<uint4*>(Vst + so_) = RV;                                                       \
+    *reinterpret_cast<uint4*>(Kst + so_) = RK;                                                       \
+  }
+#define SP2_TILE(T, SLOT, SC0, SC1, SN0, SN1, LAST)                                                  \
+  {                                                                                                  \
+    const int fo_ = ((ABL ? 0 : (((T) >> 1) & 1)) * 2 + (SLOT)) * SP2_TILE_U16 + lrow;               \
+    const u16* kp_ = Kst + fo_;                                                                      \
+    const u16* vp_ = Vst + fo_;                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                               \
+      if (!(LAST)) {                                                                                 \
+        const T8 fk0_ = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp_ + 16 * ks));      \
+        const T8 fk1_ = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp_ + 32 * HLD + 16 * ks)); \
+        SN0 = H16<DT>::mfma(fk0_, qf[ks], ks == 0 ? zero16 : SN0);                                   \
+        SN1 = H16<DT>::mfma(fk1_, qf[ks], ks == 0 ? zero16 : SN1);                                   \
+      }                                                                                              \
+      T8 pb_;                                                                                        \
+      if ((ks >> 1) == 0) SP2_EXP8(SC0, 8 * (ks & 1), pb_) else SP2_EXP8(SC1, 8 * (ks & 1), pb_)     \
+      const T8 fv0_ = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp_ + 16 * ks));        \
+      const T8 fv1_ = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp_ + 32 * HLD + 16 * ks)); \
+      o0 = H16<DT>::mfma(fv0_, pb_, o0);                                                             \
+      o1 = H16<DT>::mfma(fv1_, pb_, o1);                                                             \
+    }                                                                                                \
+  }
+  // keys of tile T outside the segment (only the first and the last tile can have any)
+#define SP2_MASK(T, SC0, SC1)                                                                        \
+  {                                                                                                  \
+    const int tile0_ = (b_first + (T)) * 64;                                                         \
+    if (tile0_ < seg0 || tile0_ + 64 > seg1) {                                                       \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
+        const int kg_ = tile0_ + mfma32_crow(r, hi);                                                 \
+        SC0[r] = (kg_ >= seg0 && kg_ < seg1) ? SC0[r] : -1e30f;                                      \
+        SC1[r] = (kg_ + 32 >= seg0 && kg_ + 32 < seg1) ? SC1[r] : -1e30f;                            \
+      }                                                                                              \
+    }                                                                                                \
+  }
+
+  uint4 rk0, rv0, rk1, rv1;
+  const int last = ntile - 1;
+  int t = 0;
+  if (!wave_active) {                         // a wave without queries only stages its share of K / V^T (same barriers as the others)
+    for (; t + 2 <= last; t += 2) {
+      SP2_STAGE_LOADS(t, rv0, rk0) SP2_STAGE_LOADS(t + 1, rv1, rk1)
+      SP2_STAGE_PARK(t, 0, rv0, rk0) SP2_STAGE_PARK(t + 1, 1, rv1, rk1)
+      __syncthreads();
+    }
+    return;
+  }
+  SP2_MASK(0, sa0, sa1)
+  for (; t + 2 <= last; t += 2) {             // tiles t, t + 1 (neither is the last one): one basic block, one barrier
+    if (!ABL) { SP2_STAGE_LOADS(t, rv0, rk0) SP2_STAGE_LOADS(t + 1, rv1, rk1) }   // the next stage: issued first, parked last (hipcc would sink them to the stores)
+    __builtin_amdgcn_sched_barrier(0);
+    SP2_TILE(t, 0, sa0, sa1, sb0, sb1, false)
+    SP2_TILE(t + 1, 1, sb0, sb1, sa0, sa1, false)
+    __builtin_amdgcn_sched_barrier(0);
+    if (!ABL) { SP2_STAGE_PARK(t, 0, rv0, rk0) SP2_STAGE_PARK(t + 1, 1, rv1, rk1) }
+    if (ABL < 2) __syncthreads();
+  }
+  if (t < last) {                             // last is odd: tile last - 1 (slot 0), then the masked last tile (slot 1) from the same stage
+    SP2_TILE(t, 0, sa0, sa1, sb0, sb1, false)
+    if (last > 0) SP2_MASK(last, sb0, sb1)
+    SP2_TILE(t + 1, 1, sb0, sb1, sa0, sa1, true)
+  } else {                                    // last is even: the masked last tile (slot 0)
+    if (last > 0) SP2_MASK(last, sa0, sa1)
+    SP2_TILE(t, 0, sa0, sa1, sb0, sb1, true)
+  }
+
+  const int q = qw0 + l31;
+  const float inv = 1.0f / h_xhalf_sum(((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
+  if (q < len) {
+    u16* op = out + (size_t)(seg0 + q) * (heads * 64) + head * 64 + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<uint2*>(op + 8 * g) =
+          h16_pack4<DT>(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+      *reinterpret_cast<uint2*>(op + 32 + 8 * g) =
+          h16_pack4<DT>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+  }
+}
+
 // tuning knob (rap_set_tuning key 3): 0 = v1 (bounded softmax when per-head logit bounds are supplied -- bf16 only -- else
 // v_max3 row maximum + deferred rescale); 5 = v1 online softmax even with bounds; 11 = ping-pong schedule (slower, see above); 8 = first v1 (fmaxf chain, rescale
 // every tile); 4 = max3 only; 1..3, 6, 7 = timing-only ablations (bf16 only), see ABL above.
@@ -632,7 +839,7 @@ int g_rap_attn_h16_variant = 0;
 // the model path asks before it runs qk-norm: pre-scaled q only feeds the default bounded bf16 kernel
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {
   const int v = g_rap_attn_h16_variant;
-  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10 || v == 12);
+  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10 || v == 12 || v == 13 || v == 19);
 }
 
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
@@ -650,7 +857,7 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
     return RAP_OK;
   }
 #define HATT_LAUNCH(DTV, ABLV, OPTV) \
-  hipLaunchKernelGGL((attention_h16_kernel<DTV, ABLV, OPTV>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound)
+  hipLaunchKernelGGL((attention_h16_kernel<DTV, ABLV, OPTV>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, max_items * heads)
   if (dtype == RAP_DT_BF16) {
     switch (g_rap_attn_h16_variant) {
 #ifdef RAP_ABLATION_BUILD      // timing-only kernels whose output is NOT attention: never part of the shipped library
@@ -659,6 +866,9 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
       case 3: HATT_LAUNCH(RAP_DT_BF16, 3, 0); break;
       case 6: HATT_LAUNCH(RAP_DT_BF16, 8, 3); break;     // ... without transcendentals
       case 7: HATT_LAUNCH(RAP_DT_BF16, 32, 3); break;    // ... without the max chain
+      case 16: if (bound) HATT_LAUNCH(RAP_DT_BF16, 64, 8); break;    // bounded kernel without the output stores
+      case 17: if (bound) HATT_LAUNCH(RAP_DT_BF16, 128, 8); break;   // ... without the Q loads
+      case 18: if (bound) HATT_LAUNCH(RAP_DT_BF16, 192, 8); break;   // ... without either
 #endif
       case 4: HATT_LAUNCH(RAP_DT_BF16, 0, 7); break;     // + s_setprio(1) around the MFMA clusters
       case 5: HATT_LAUNCH(RAP_DT_BF16, 0, 3); break;     // max3 + deferred rescale
@@ -670,6 +880,44 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
           hipLaunchKernelGGL((attention_h16_sp_kernel<RAP_DT_BF16, 0>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound);
         else HATT_LAUNCH(RAP_DT_BF16, 0, 3);
         break;
+#ifdef RAP_ABLATION_BUILD
+      case 14: case 15: {
+        const void* f = g_rap_attn_h16_variant == 14 ? reinterpret_cast<const void*>(&attention_h16_sp2_kernel<RAP_DT_BF16, 0, 1>)
+                                                     : reinterpret_cast<const void*>(&attention_h16_sp2_kernel<RAP_DT_BF16, 0, 2>);
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SP2_LDS_BYTES) != hipSuccess || !bound) return RAP_ERR_HIP;
+        if (g_rap_attn_h16_variant == 14)
+          hipLaunchKernelGGL((attention_h16_sp2_kernel<RAP_DT_BF16, 0, 1>), dim3(max_items * heads), dim3(512), SP2_LDS_BYTES, stream, qk, vt, vt_nblk, out, TP, heads, items, bound);
+        else
+          hipLaunchKernelGGL((attention_h16_sp2_kernel<RAP_DT_BF16, 0, 2>), dim3(max_items * heads), dim3(512), SP2_LDS_BYTES, stream, qk, vt, vt_nblk, out, TP, heads, items, bound);
+        break;
+      }
+#endif
+      case 13: {                                          // software-pipelined, compiler-scheduled, one barrier per two tiles
+        static bool sp2_attr = false;
+        if (!sp2_attr) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_h16_sp2_kernel<RAP_DT_BF16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, SP2_LDS_BYTES) != hipSuccess ||
+              hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_h16_sp2_kernel<RAP_DT_BF16, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, SP2_LDS_BYTES) != hipSuccess)
+            return RAP_ERR_HIP;
+          sp2_attr = true;
+        }
+        if (bound && q_prescaled)
+          hipLaunchKernelGGL((attention_h16_sp2_kernel<RAP_DT_BF16, 1>), dim3(max_items * heads), dim3(512), SP2_LDS_BYTES, stream, qk, vt, vt_nblk, out, TP, heads, items, bound);
+        else if (bound)
+          hipLaunchKernelGGL((attention_h16_sp2_kernel<RAP_DT_BF16, 0>), dim3(max_items * heads), dim3(512), SP2_LDS_BYTES, stream, qk, vt, vt_nblk, out, TP, heads, items, bound);
+        else HATT_LAUNCH(RAP_DT_BF16, 0, 3);
+        break;
+      }
+      case 19: {                                          // persistent blocks (two per CU) walking the work list
+        const int total = max_items * heads;
+        int grid = (512 / heads) * heads;
+        if (grid <= 0 || grid > total) grid = total;
+#define HATT_LAUNCH_P(OPTV) \
+  hipLaunchKernelGGL((attention_h16_kernel<RAP_DT_BF16, 0, OPTV, true>), dim3(grid), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, total)
+        if (bound && q_prescaled) HATT_LAUNCH_P(24);
+        else if (bound) HATT_LAUNCH_P(8);
+        else HATT_LAUNCH_P(3);
+        break;
+      }
       default:
         if (bound && q_prescaled) HATT_LAUNCH(RAP_DT_BF16, 0, 24);
         else if (bound) HATT_LAUNCH(RAP_DT_BF16, 0, 8);

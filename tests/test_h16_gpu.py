@@ -552,27 +552,55 @@ def test_baseline_geometries_h16_agrees_with_fp32_path(label, batch, views, poin
 
 
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("variant", [5, 11], ids=["online-softmax", "ping-pong"])
+@pytest.mark.parametrize("variant", [5, 11, 12, 13, 19], ids=["online-softmax", "ping-pong", "pipelined-pinned", "pipelined-2-tiles-per-barrier", "persistent-blocks"])
 def test_attention_h16_schedule_variants_agree(lib, dev, dt, variant):
     """rap_set_tuning(3, .) selects alternative schedules of the 16-bit attention (online softmax even when logit bounds are
     given; the ping-pong wave schedule): same function, results within rounding of the default."""
     g = torch.Generator().manual_seed(31)
     H = 4
-    cu = torch.tensor([0, 100, 164, 700, 1213, 1214, 2000])
-    TP = int(cu[-1])
-    q = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8
-    k = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8
-    v = torch.randn(H, TP, 64, generator=g)
-    bound = logit_bound(q, k)
-    base = run_attention_h(lib, dev, dt, q, k, v, cu, bound=bound)
-    assert lib.rap_set_tuning(3, variant) == 0
+    # segment lengths around every tile-count parity of the two-tiles-per-barrier ring (1..7 key tiles, unaligned starts, one query)
+    for cu in (torch.tensor([0, 100, 164, 700, 1213, 1214, 2000]),
+               torch.tensor([0] + [1, 63, 64, 65, 128, 129, 192, 300, 0, 257, 384, 31, 449]).cumsum(0)):
+        TP = int(cu[-1])
+        q = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8
+        k = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8
+        v = torch.randn(H, TP, 64, generator=g)
+        bound = logit_bound(q, k)
+        base = run_attention_h(lib, dev, dt, q, k, v, cu, bound=bound)
+        assert lib.rap_set_tuning(3, variant) == 0
+        try:
+            alt = run_attention_h(lib, dev, dt, q, k, v, cu, bound=bound)
+        finally:
+            assert lib.rap_set_tuning(3, 0) == 0
+        ref = attention_ref64(q, k, v, cu, dt)
+        assert (alt.double() - ref).abs().max().item() < 8 * ULP[dt]
+        assert (alt.float() - base.float()).abs().max().item() < 4 * ULP[dt]
+
+
+@pytest.mark.parametrize("variant", [12, 13, 19])
+def test_attention_h16_pipelined_variants_in_the_model_path(dev, variant):
+    """the software-pipelined kernels with the pre-scaled q the fused qk-norm epilogue writes (PRE = 1): whole bf16 velocity network
+    against the fp32 reference golden, and against the default kernel"""
+    lib = _lib.load()
+    g, inp = load_golden("l12_small_rigid")
+    outs = {}
     try:
-        alt = run_attention_h(lib, dev, dt, q, k, v, cu, bound=bound)
+        for var in (variant, 0):
+            assert lib.rap_set_tuning(3, var) == 0
+            cfg, sd, model = get_model(12, int(g["weight_seed"]), dev, "bfloat16")
+            cu_b, cu_p = O.prepare_cu_seqlens(inp)
+            d = {k: v.to(dev) for k, v in inp.items()}
+            outs[var] = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
+                              local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                              cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev)).cpu()
     finally:
         assert lib.rap_set_tuning(3, 0) == 0
-    ref = attention_ref64(q, k, v, cu, dt)
-    assert (alt.double() - ref).abs().max().item() < 8 * ULP[dt]
-    assert (alt.float() - base.float()).abs().max().item() < 4 * ULP[dt]
+    v_ref = torch.from_numpy(g["fwd_velocity"])
+    vmax = v_ref.abs().max().item()
+    e_alt, e_def = (outs[variant] - v_ref).abs().max().item() / vmax, (outs[0] - v_ref).abs().max().item() / vmax
+    print(f"bf16 forward vs fp32 golden: variant {variant} {e_alt:.2e}, default {e_def:.2e}")
+    assert e_alt < FWD_REL_BOUND["bfloat16"] and e_def < FWD_REL_BOUND["bfloat16"]
+    assert (outs[variant] - outs[0]).abs().max().item() / vmax < FWD_REL_BOUND["bfloat16"]
 
 
 
