@@ -131,9 +131,9 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
   if (key == 2 && value >= 0 && value <= 15) { g_rap_gemm_h16_variant = value; return RAP_OK; }
 #ifdef RAP_ABLATION_BUILD
-  if (key == 3 && value >= 14 && value <= 18) { g_rap_attn_h16_variant = value; return RAP_OK; }
+  if (key == 3 && ((value >= 14 && value <= 18) || value == 21)) { g_rap_attn_h16_variant = value; return RAP_OK; }
 #endif
-  if (key == 3 && ((value >= 0 && value <= 13) || value == 19)) {
+  if (key == 3 && ((value >= 0 && value <= 13) || value == 19 || value == 20)) {
 #ifndef RAP_ABLATION_BUILD
     // 1-3, 6, 7 are timing-only ablations ("NOT attention"): compiled out of the shipped library, refused here
     if (value == 1 || value == 2 || value == 3 || value == 6 || value == 7) return RAP_ERR_INVALID;

@@ -52,7 +52,18 @@ __device__ __forceinline__ float hmax3(float a, float b, float c) {
 }
 // PERSIST (r02, rap_set_tuning(3, 19)): the grid is a fixed number of blocks that walk the (work item, head) list with stride gridDim.x
 // (a multiple of the head count, so a block keeps its head = its XCD) instead of one block per entry.
-template <int DT, int ABL, int OPT, bool PERSIST = false>
+// ROT (r02, rap_set_tuning(3, 20)): block j of a segment starts its walk over the key tiles at ITS OWN diagonal (tile 4j) and wraps, so
+// that the blocks of one (segment, head) -- which run at the same time on one XCD -- do not all ask for the same cold K / V^T tile
+// at the same moment (softmax is order-independent; the masks follow the rotated tile index).
+#ifdef RAP_ABLATION_BUILD
+__device__ unsigned long long* g_attn_ts = nullptr;      // [block][8] s_memtime stamps of wave 0 (ABL bit 8), set by rap_debug_attn_ts
+extern "C" int rap_debug_attn_ts(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_ts), &p, sizeof(p)) == hipSuccess ? 0 : -3; }
+#define ATT_TS(I) if ((ABL & 256) && g_attn_ts && threadIdx.x == 0) { g_attn_ts[(size_t)blockIdx.x * 8 + (I)] = __builtin_readcyclecounter(); \
+    if ((I) == 0) g_attn_ts[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); if ((I) == 5) g_attn_ts[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define ATT_TS(I)
+#endif
+template <int DT, int ABL, int OPT, bool PERSIST = false, bool ROT = false>
 __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
                                                                int vt_nblk, u16* __restrict__ out, int TP, int heads,
                                                                const AttnWorkItem* __restrict__ items,
@@ -64,6 +75,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
 
   const int tid = threadIdx.x;
   int vb = blockIdx.x;
+  ATT_TS(0)
   do {
   const int head = vb % heads;
   const AttnWorkItem it = items[vb / heads];
@@ -124,14 +136,21 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   *reinterpret_cast<uint4*>(Ks + (BUF) * (HKV * HLD) + soff) = rk;                                   \
   *reinterpret_cast<uint4*>(Vs + (BUF) * (HKV * HLD) + soff) = rv;
 
-  HATT_LOAD(0)
+  int rt = ROT ? (int)(((unsigned)it.q0 >> 6) % (unsigned)ntile) : 0;     // rotated tile index of iteration t
+  ATT_TS(1)
+  HATT_LOAD(rt)
   HATT_STORE(0)
   __syncthreads();
+  ATT_TS(2)
+  if (ABL & 256) { const uint4 q0_ = __builtin_bit_cast(uint4, qf[0]); const uint4 q3_ = __builtin_bit_cast(uint4, qf[3]); if ((q0_.x ^ q3_.w) == 0x9e3779b9u && tid == 9999) return; }   // the Q loads complete before stamp 3
+  ATT_TS(3)
 
   for (int t = 0; t < ntile; ++t) {
     const int cur = (ABL & 2) ? 0 : (t & 1);
     const bool more = (ABL & 2) ? false : (t + 1) < ntile;
-    if (more) { HATT_LOAD(t + 1) }
+    const int rt_cur = rt;
+    if (ROT) { rt = rt + 1; rt = rt == ntile ? 0 : rt; }
+    if (more) { HATT_LOAD(ROT ? rt : t + 1) }
 
     if (wave_active) {
       // ---- S^T = K Q^T : two 32-key sub-tiles x 32 queries
@@ -149,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
       }
       if (OPT & 4) __builtin_amdgcn_s_setprio(0);
       // ---- mask keys outside the segment (first / last tile only)
-      const int tile0 = (b_first + t) * 64;
+      const int tile0 = (b_first + (ROT ? rt_cur : t)) * 64;
       if (tile0 < seg0 || tile0 + 64 > seg1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -250,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
     if (!(ABL & 2)) __syncthreads();
   }
 
+  ATT_TS(4)
   if (!wave_active) continue;
   // ---- normalise and store: lane owns query l31; register r of tile e is d = 32e + crow(r, hi): groups of 4 contiguous d
   const int q = qw0 + l31;
@@ -265,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
           h16_pack4<DT>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
     }
   }
+  ATT_TS(5)
   } while (PERSIST && (vb += (int)gridDim.x) < total_blocks);
 }
 
@@ -839,7 +860,7 @@ int g_rap_attn_h16_variant = 0;
 // the model path asks before it runs qk-norm: pre-scaled q only feeds the default bounded bf16 kernel
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {
   const int v = g_rap_attn_h16_variant;
-  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10 || v == 12 || v == 13 || v == 19);
+  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10 || v == 12 || v == 13 || v == 19 || v == 20);
 }
 
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
@@ -866,6 +887,7 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
       case 3: HATT_LAUNCH(RAP_DT_BF16, 3, 0); break;
       case 6: HATT_LAUNCH(RAP_DT_BF16, 8, 3); break;     // ... without transcendentals
       case 7: HATT_LAUNCH(RAP_DT_BF16, 32, 3); break;    // ... without the max chain
+      case 21: if (bound) HATT_LAUNCH(RAP_DT_BF16, 256, 8); break;   // bounded kernel with s_memtime stamps (rap_debug_attn_ts)
       case 16: if (bound) HATT_LAUNCH(RAP_DT_BF16, 64, 8); break;    // bounded kernel without the output stores
       case 17: if (bound) HATT_LAUNCH(RAP_DT_BF16, 128, 8); break;   // ... without the Q loads
       case 18: if (bound) HATT_LAUNCH(RAP_DT_BF16, 192, 8); break;   // ... without either
@@ -907,6 +929,13 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
         else HATT_LAUNCH(RAP_DT_BF16, 0, 3);
         break;
       }
+      case 20:                                            // rotated key-tile walk
+#define HATT_LAUNCH_R(OPTV) \
+  hipLaunchKernelGGL((attention_h16_kernel<RAP_DT_BF16, 0, OPTV, false, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, max_items * heads)
+        if (bound && q_prescaled) HATT_LAUNCH_R(24);
+        else if (bound) HATT_LAUNCH_R(8);
+        else HATT_LAUNCH_R(3);
+        break;
       case 19: {                                          // persistent blocks (two per CU) walking the work list
         const int total = max_items * heads;
         int grid = (512 / heads) * heads;
