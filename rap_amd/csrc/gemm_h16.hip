@@ -36,6 +36,46 @@ __device__ __forceinline__ float gelu_erf_fast(float g) {
   return g < 0.f ? 0.5f * g * q : g * (1.0f - 0.5f * q);
 }
 
+// Two GEGLU outputs per call on the packed fp32 pipe (r02): the epilogue is VALU-bound -- r01's ablation prices it at 0.42 ms of the
+// 1.6 ms ff1 GEMM, and the disassembly showed ~24 scalar VALU instructions per output (nothing packed).  Here every multiply / FMA of
+// the polynomial handles two outputs (v_pk_mul_f32 / v_pk_fma_f32: twice the fp32 rate when no MFMA is in flight), the branch of
+// gelu_erf_fast becomes Phi(g) = 1/2 + copysign(1/2 - q/2, g), and the two results leave as ONE v_cvt_pk: ~13 instructions per output.
+// Stage-major over NP independent pairs: a packed result feeds the next packed op only NP instructions later (issued back to back,
+// hipcc pads every dependent v_pk pair with an s_nop: 249 of them in the first version).
+template <int NP>
+__device__ __forceinline__ void geglu_pairs(const f32x2 (&h)[NP], const f32x2 (&g)[NP], f32x2 (&o)[NP]) {
+  f32x2 ax[NP], t[NP], poly[NP], q[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) ax[i] = f32x2{fabsf(g[i].x), fabsf(g[i].y)} * f32x2{0.70710678118654752440f, 0.70710678118654752440f};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const f32x2 d = __builtin_elementwise_fma(ax[i], f32x2{0.3275911f, 0.3275911f}, f32x2{1.0f, 1.0f});
+    t[i] = f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const f32x2 e = ax[i] * (ax[i] * f32x2{-1.44269504088896340736f, -1.44269504088896340736f});
+    q[i] = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) poly[i] = __builtin_elementwise_fma(t[i], f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+#pragma unroll
+  for (int i = 0; i < NP; ++i) poly[i] = __builtin_elementwise_fma(t[i], poly[i], f32x2{1.421413741f, 1.421413741f});
+#pragma unroll
+  for (int i = 0; i < NP; ++i) poly[i] = __builtin_elementwise_fma(t[i], poly[i], f32x2{-0.284496736f, -0.284496736f});
+#pragma unroll
+  for (int i = 0; i < NP; ++i) poly[i] = __builtin_elementwise_fma(t[i], poly[i], f32x2{0.254829592f, 0.254829592f});
+#pragma unroll
+  for (int i = 0; i < NP; ++i) q[i] *= poly[i] * t[i];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const f32x2 u = __builtin_elementwise_fma(q[i], f32x2{-0.5f, -0.5f}, f32x2{0.5f, 0.5f});     // 1/2 - q/2 >= 0
+    q[i] = f32x2{0.5f, 0.5f} + f32x2{__builtin_copysignf(u.x, g[i].x), __builtin_copysignf(u.y, g[i].y)};
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) o[i] = h[i] * (g[i] * q[i]);
+}
+
 // ---------------- epilogue (shared by the kernels below) ----------------
 // acc[i][j][r] = C[mw + 32 i + crow(r, hi)][nw + 32 j + l31]: a lane owns ONE column, so direct stores would be
 // 2- or 4-byte scatters (measured: the out-projection ran at 147 TF, 4x its HBM floor).  Every wave therefore
@@ -53,11 +93,18 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
     const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      f32x2 h2[8], g2[8], o2[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float h = acc[i][0][r] + bh;
-        const float g = acc[i][1][r] + bg;
-        sh[mfma32_crow(r, hi) * 32 + l31] = h16_from_f32<DT>(h * gelu_erf_fast(g));
+      for (int j = 0; j < 8; ++j) {
+        h2[j] = f32x2{acc[i][0][2 * j], acc[i][0][2 * j + 1]} + f32x2{bh, bh};
+        g2[j] = f32x2{acc[i][1][2 * j], acc[i][1][2 * j + 1]} + f32x2{bg, bg};
+      }
+      geglu_pairs<8>(h2, g2, o2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(o2[j], typename H16<DT>::T2));   // one v_cvt_pk for both
+        sh[mfma32_crow(2 * j, hi) * 32 + l31] = (u16)(pk & 0xffffu);
+        sh[mfma32_crow(2 * j + 1, hi) * 32 + l31] = (u16)(pk >> 16);
       }
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
@@ -155,6 +202,9 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
     return;
   }
   if constexpr (EPI == EPI_H_BIAS_RESID_F32) {
+    // (r02 call 39: requesting the residual rows of slab i + 1 while slab i is transposed and stored -- rolling through one register
+    // set, or two sets -- pushes this 225-VGPR kernel over 256 and spills in the epilogue: out-projection 0.32 -> 0.33 ms, ff2 unchanged.
+    // Both GEMMs are bound by this fp32 read-modify-write of the residual stream, 1.34 / 2.4 GB per call at 4.2 / 3.8 TB/s.)
     float* C = reinterpret_cast<float*>(p.C);
     float* sf = reinterpret_cast<float*>(stg);   // [32 rows][64 columns]
     const float b0 = p.bias ? p.bias[nw + l31] : 0.f;
