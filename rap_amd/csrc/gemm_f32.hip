@@ -973,7 +973,10 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
   if (p.N % GBN != 0 || p.K % GBK != 0 || p.K <= 0) return RAP_ERR_INVALID;
   if ((p.lda & 3) || (p.ldw & 3)) return RAP_ERR_INVALID;
   int v = g_rap_gemm_variant;
-  if (v == 48) v = (p.N >= 1536 && p.N % 256 == 0 && p.K <= 512 && (long)((p.M + 255) / 256) * (p.N / 256) >= 512) ? 32 : 16;
+  // per shape (r02 call 40, after the epilogue rewrite): the 256x256 kernel wherever there are at least two rounds of its tiles and
+  // K >= 256 -- qkv 128 vs 119 TF, ff1 132 vs 129, ff2 139 vs 131, head 125 vs 119, out-projection equal; the K = 64 embedding GEMM and
+  // few-token calls stay on the 128x128 kernel (two blocks per CU cover each other's prologue).
+  if (v == 48) v = (p.N % 256 == 0 && p.K >= 256 && (long)((p.M + 255) / 256) * (p.N / 256) >= 512) ? 32 : 16;
   if (epilogue == EPI_BIAS_RESID && (v == 16 || v == 32) && p.splitk_ws && g_rap_gemm_splitk && p.K >= 1024 && (p.ldr & 3) == 0 && (p.ldc & 3) == 0 &&
       (long)((p.M + GBM - 1) / GBM) * (p.N / GBN) <= 128) {
     const int splits = 4;
