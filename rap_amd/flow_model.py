@@ -20,8 +20,10 @@ _WORKSPACES: dict = {}
 
 
 def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Grow-only per-device scratch buffer handed to the C ABI as the caller-owned workspace."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer handed to the C ABI as the caller-owned workspace: one per (device, current stream) -- calls that
+    are in flight on different streams (RectifiedPointFlow's concurrent batch shards) must not share scratch."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, idx, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None

@@ -23,7 +23,7 @@ class RectifiedPointFlow:
     def __init__(self, flow_model: PointCloudDiT = None, inference_sampling_steps: int = 20,
                  inference_sampler: str = "euler", n_generations: int = 1, rigidity_forcing: bool = False,
                  return_end_point_trajectory: bool = True, encoder_on: bool = False, validate_inputs: bool | None = None,
-                 **_ignored):
+                 num_streams: int | None = None, **_ignored):
         if flow_model is None:
             raise ValueError("flow_model is required")            # modeling.py:80-81
         if encoder_on:
@@ -40,6 +40,16 @@ class RectifiedPointFlow:
         # the reference asserts the batch layout in split_parts (utils/point_clouds.py:33-52) -- with a host sync per call; here
         # the check is a device kernel + one 4-byte read, off by default (RAP_VALIDATE_INPUTS=1 or validate_inputs=True turns it on)
         self.validate_inputs = (os.environ.get("RAP_VALIDATE_INPUTS") == "1") if validate_inputs is None else bool(validate_inputs)
+        # Concurrent batch shards (opt-in, num_streams > 1): samples are independent, so a batch can be run as contiguous shards on
+        # several HIP streams.  MEASURED (r02 call 44, 32 pairs x 2 x 4096, product path, results bit-identical): bf16 2 421 ms on one
+        # stream, 2 408 / 2 394 / 2 396 ms on 2 / 3 / 4; fp16 and fp32 +-0.3 % -- every kernel already fills the chip, nothing is left
+        # for a second stream to overlap with.  (A first experiment that showed +16 % had both shards in ONE scratch buffer; the
+        # per-(device, stream) workspace cache in flow_model.workspace() exists because of it.)  The same shards one after the other
+        # on one stream -- a smaller per-layer working set against the 256 MB Infinity Cache -- are slower: 2 457 / 2 465 / 2 544 /
+        # 2 574 / 2 886 ms for 1 / 2 / 4 / 8 / 16 chunks (call 45).  Default: one stream; RAP_NUM_STREAMS overrides.
+        env = os.environ.get("RAP_NUM_STREAMS")
+        self.num_streams = int(env) if env else num_streams
+        self._aux_streams: dict = {}
 
     # modeling.py:203-231 without the boolean-mask compaction (which syncs): empty parts stay in the table as
     # zero-length segments, which every kernel treats as a no-op and which yields the same zero R,t rows.
@@ -54,11 +64,83 @@ class RectifiedPointFlow:
             ppp=data_dict["points_per_part"].to(device=device, dtype=torch.int64).contiguous(),
             cu_batch=data_dict["cu_seqlens"].to(device=device, dtype=torch.int32).contiguous())
 
+    def _resolved_streams(self) -> int:
+        n = self.num_streams
+        if n is None:
+            n = 1
+        return max(1, int(n))
+
     @torch.inference_mode()
     def sample_and_register(self, data_dict: dict, x_1: torch.Tensor | None = None,
                             return_transformer_features: bool = False) -> dict:
-        """One generation: {'end_point_trajectory','trajectory' (S,TP,3), 'R' (B,P,3,3), 't' (B,P,3)[, features]}."""
+        """One generation: {'end_point_trajectory','trajectory' (S,TP,3), 'R' (B,P,3,3), 't' (B,P,3)[, features]}.
+
+        With ``num_streams`` > 1 the batch is cut at sample boundaries into that many shards of about equal token count, which run
+        concurrently on the current stream and on auxiliary streams (forked from / joined back into the current stream with
+        events: the call stays stream-ordered for the caller).  The cut needs the token offsets of the samples on the HOST: free
+        when ``cu_seqlens`` is a CPU tensor (as the reference's collate delivers it), one (B+1)-int read otherwise."""
         d = self._prepare_data(data_dict)
+        B = d["ppp"].shape[0]
+        n = min(self._resolved_streams(), B)
+        if n <= 1:
+            return self._sample_shard(d, x_1, return_transformer_features)
+        cond = d["cond"]
+        device = cond.device
+        TP = cond.shape[0]
+        x_1 = torch.randn_like(cond) if x_1 is None else _f32c(x_1.to(device))
+        cu_src = data_dict["cu_seqlens"]
+        cu_host = (cu_src if not cu_src.is_cuda else cu_src.cpu()).to(torch.int64).tolist()
+        cuts = [0]                                                   # sample index where shard k starts
+        for k in range(1, n):
+            target = TP * k / n
+            b = min(range(cuts[-1] + 1, B - (n - 1 - k)), key=lambda i: abs(cu_host[i] - target), default=None)
+            if b is None:
+                break
+            cuts.append(b)
+        cuts.append(B)
+        if len(cuts) <= 2:
+            return self._sample_shard(d, x_1, return_transformer_features)
+        cur = torch.cuda.current_stream(device)
+        parts = []
+        for k in range(len(cuts) - 1):
+            b0, b1 = cuts[k], cuts[k + 1]
+            t0, t1 = cu_host[b0], cu_host[b1]
+            shard = dict(cond=cond[t0:t1], feats=d["feats"][t0:t1], scales=d["scales"][b0:b1], anchor=d["anchor"][t0:t1],
+                         ppp=d["ppp"][b0:b1], cu_batch=None)
+            if k == 0:
+                shard["cu_batch"] = d["cu_batch"][: b1 + 1]
+                parts.append(self._sample_shard(shard, x_1[t0:t1], return_transformer_features))
+                continue
+            if getattr(self, "_sequential_shards", False):            # experiment knob: the same shards one after the other on one stream
+                shard["cu_batch"] = (d["cu_batch"][b0: b1 + 1] - int(t0)).contiguous()
+                parts.append(self._sample_shard(shard, x_1[t0:t1], return_transformer_features))
+                continue
+            key = (device.index, k)
+            st = self._aux_streams.get(key)
+            if st is None:
+                st = self._aux_streams[key] = torch.cuda.Stream(device)
+            st.wait_stream(cur)                                      # fork: the inputs are ready on the caller's stream
+            with torch.cuda.stream(st):
+                shard["cu_batch"] = (d["cu_batch"][b0: b1 + 1] - int(t0)).contiguous()
+                out = self._sample_shard(shard, x_1[t0:t1], return_transformer_features)
+            for v in (cond, d["feats"], d["scales"], d["anchor"], d["ppp"], d["cu_batch"], x_1):
+                v.record_stream(st)                                  # caching-allocator safety: these are read on `st`
+            parts.append(out)
+        for k in range(1, len(parts)):
+            if (device.index, k) in self._aux_streams:
+                cur.wait_stream(self._aux_streams[(device.index, k)])    # join
+        res = {"end_point_trajectory": torch.cat([o["end_point_trajectory"] for o in parts], dim=1),
+               "trajectory": torch.cat([o["trajectory"] for o in parts], dim=1),
+               "R": torch.cat([o["R"] for o in parts], dim=0), "t": torch.cat([o["t"] for o in parts], dim=0)}
+        if return_transformer_features:
+            res["transformer_features"] = torch.cat([o["transformer_features"] for o in parts], dim=0)
+        for o in parts[1:]:
+            for v in o.values():
+                v.record_stream(cur)                                 # allocated on an auxiliary stream, last read (the cat) on `cur`
+        return res
+
+    def _sample_shard(self, d: dict, x_1: torch.Tensor | None, return_transformer_features: bool) -> dict:
+        """rap_sample on the current stream for one (shard of a) prepared batch."""
         cond = d["cond"]
         device = cond.device
         TP = cond.shape[0]

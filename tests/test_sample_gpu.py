@@ -488,3 +488,29 @@ def test_fp32_fused_qknorm_agrees_with_the_unfused_path(dev):
     v_ref = torch.from_numpy(g["fwd_velocity"])
     assert (outs[1] - outs[0]).abs().max().item() < 2e-6
     assert (outs[1] - v_ref).abs().max().item() < 2e-5 and (outs[0] - v_ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("n_streams", [2, 3])
+def test_concurrent_batch_shards_equal_the_single_stream_call(dev, n_streams):
+    """RectifiedPointFlow(num_streams=n): the batch cut at sample boundaries into n shards that run concurrently on n HIP streams
+    (samples are independent: attention per segment, adaLN per sample, Procrustes per part) returns what the one-stream call returns.
+    Ragged batch (parts of different sizes, an empty part slot, token cuts that are not multiples of the 64-token attention
+    blocks), cu_seqlens once on the host (no read-back) and once on the device."""
+    cfg, sd, model = get_model(2, 5, dev)
+    inp = S.make_inputs([[300, 200], [257], [129, 64, 190], [511, 100], [96, 96]], seed=21, max_parts=3)
+    d = to_dev(inp, dev)
+    one = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=5, rigidity_forcing=True, num_streams=1)
+    many = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=5, rigidity_forcing=True, num_streams=n_streams)
+    ref = one.sample_and_register(d, x_1=d["x_1"], return_transformer_features=True)
+    for cu_on_host in (True, False):
+        dd = dict(d)
+        dd["cu_seqlens"] = inp["cu_seqlens"] if cu_on_host else d["cu_seqlens"]
+        out = many.sample_and_register(dd, x_1=d["x_1"], return_transformer_features=True)
+        torch.cuda.synchronize()
+        for k in ("end_point_trajectory", "trajectory", "R", "t", "transformer_features"):
+            assert out[k].shape == ref[k].shape, k
+            err = (out[k] - ref[k]).abs().max().item()
+            assert err < 2e-5, (k, err)
+    # and the next call on the caller's stream sees the joined result (stream order is preserved for the caller)
+    again = many.sample_and_register(d, x_1=d["x_1"])
+    assert (again["R"] - ref["R"]).abs().max().item() < 2e-5
