@@ -213,6 +213,15 @@ int rap_voxel_coverage(const float* points, int64_t N, float voxel_size, const i
                        size_t ws_bytes, void* stream);
 int rap_voxel_downsample(const float* points, int64_t N, float voxel_size, const int64_t* h_bounds6, float dist_max,
                          int64_t* indices_out, int32_t* count_out, void* ws, size_t ws_bytes, void* stream);
+/* The same two results with O(N) memory (a radix sort of one 64-bit key per point instead of a table over the grid volume): for grids
+ * whose dense table would be large against N or exceed its slot limit.  Identical outputs (kept indices in ascending voxel-key order;
+ * the exact occupied-voxel count).  Limits: N < 2^32; down-sampling needs the largest grid extent v < 2^18 cells.
+ * ws >= rap_voxel_sorted_workspace_bytes(N) for both.  Reference: dataset_utils.py:279-322, point_sampling_utils.py:11-31. */
+size_t rap_voxel_sorted_workspace_bytes(int64_t N);
+int rap_voxel_downsample_sorted(const float* points, int64_t N, float voxel_size, const int64_t* h_bounds6, float dist_max,
+                                int64_t* indices_out, int32_t* count_out, void* ws, size_t ws_bytes, void* stream);
+int rap_voxel_coverage_sorted(const float* points, int64_t N, float voxel_size, const int64_t* h_bounds6, int64_t* count_out, void* ws,
+                              size_t ws_bytes, void* stream);
 
 /* ---- kernel-level entry points (used by the parity tests; same kernels the calls above launch) ---- */
 /* C(M,N) = A(M,K) W(N,K)^T (+bias) (+resid) ; epilogue: 0 bias, 1 bias+resid, 2 bias+SiLU,

@@ -61,6 +61,9 @@ SIGNATURES = {
     "rap_voxel_coverage_workspace_bytes": (c_size_t, [_P]),
     "rap_voxel_coverage": (c_int32, [_P, c_int64, c_float, _P, _P, _P, c_size_t, _P]),
     "rap_voxel_downsample": (c_int32, [_P, c_int64, c_float, _P, c_float, _P, _P, _P, c_size_t, _P]),
+    "rap_voxel_sorted_workspace_bytes": (c_size_t, [c_int64]),
+    "rap_voxel_downsample_sorted": (c_int32, [_P, c_int64, c_float, _P, c_float, _P, _P, _P, c_size_t, _P]),
+    "rap_voxel_coverage_sorted": (c_int32, [_P, c_int64, c_float, _P, _P, _P, c_size_t, _P]),
     "rap_farthest_point_sampling": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P]),
     "rap_spinnet_weight_count": (c_int64, []),
     "rap_spinnet_create": (c_int32, [_P, c_int64, _P, ctypes.POINTER(_P)]),

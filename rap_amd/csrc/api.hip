@@ -1195,6 +1195,24 @@ extern "C" int rap_voxel_coverage(const float* points, int64_t N, float voxel_si
                                (unsigned long long*)count_out);
 }
 
+// O(N)-memory variants of the two calls above (voxel_sort.hip): identical results from a radix sort of per-point keys.  For grids whose
+// dense table is large against N or beyond its 2^33 / 2^36-slot limits (a 100 m scene at 5 cm voxels = 64 GB of table).
+extern "C" size_t rap_voxel_sorted_workspace_bytes(int64_t N) { return N > 0 && N <= 0xffffffffLL ? voxel_sorted_workspace_bytes((long)N) : 0; }
+extern "C" int rap_voxel_downsample_sorted(const float* points, int64_t N, float voxel_size, const int64_t* h_bounds6, float dist_max,
+                                           int64_t* indices_out, int32_t* count_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!points || !h_bounds6 || !indices_out || !count_out || N <= 0 || N > 0xffffffffLL || !(voxel_size > 0.f)) return RAP_ERR_INVALID;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  return launch_voxel_downsample_sorted((hipStream_t)stream, points, (long)N, voxel_size, (const long long*)h_bounds6,
+                                        dist_max > 0.f ? dist_max : 1.f, ws, ws_bytes, (long long*)indices_out, count_out);
+}
+extern "C" int rap_voxel_coverage_sorted(const float* points, int64_t N, float voxel_size, const int64_t* h_bounds6, int64_t* count_out,
+                                         void* ws, size_t ws_bytes, void* stream) {
+  if (!points || !h_bounds6 || !count_out || N <= 0 || N > 0xffffffffLL || !(voxel_size > 0.f)) return RAP_ERR_INVALID;
+  if (!ws) return RAP_ERR_WORKSPACE;
+  return launch_voxel_coverage_sorted((hipStream_t)stream, points, (long)N, voxel_size, (const long long*)h_bounds6, ws, ws_bytes,
+                                      (long long*)count_out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // input side of the boundary: raw parts -> the packed batch
 // ---------------------------------------------------------------------------------------------

@@ -209,6 +209,12 @@ int launch_statistical_outliers(hipStream_t stream, const float* pts, long N, in
                                 int32_t* count_out, double* stats_out, void* ws);
 int launch_voxel_coverage(hipStream_t stream, const float* pts, long N, float vs, const long long* h_bounds6, unsigned char* table, long slots,
                           unsigned long long* total);
+// voxel_sort.hip: the same two results from a radix sort, O(N) memory (for grids whose dense table would be large against N)
+size_t voxel_sorted_workspace_bytes(long N);
+int launch_voxel_downsample_sorted(hipStream_t stream, const float* pts, long N, float vs, const long long* h_bounds6, float dmax, void* ws,
+                                   size_t ws_bytes, long long* idx_out, int* count_out);
+int launch_voxel_coverage_sorted(hipStream_t stream, const float* pts, long N, float vs, const long long* h_bounds6, void* ws, size_t ws_bytes,
+                                 long long* count_out);
 int launch_spin_conv3x3(hipStream_t stream, const float* y, int ldy, int Cin, const float* Wt, const float* bias, const float* zeros, float* out,
                         int Cout, int M, bool relu);
 int launch_spin_fold_tapmajor(hipStream_t stream, const float* W, const float* b, const float* rm, const float* rv, int Cin, int Cout, int ntap, int ldt,

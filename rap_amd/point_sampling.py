@@ -5,6 +5,8 @@ Also ``voxel_down_sample_torch`` of ``dataset_process/utils/dataset_utils.py:279
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -53,10 +55,24 @@ def apply_batched_fps(batch_augmented_tensor, batch_lengths_tensor, batch_k_tens
     return parts, idx
 
 
-def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float) -> torch.Tensor:
+def _use_sorted_voxel_path(slots: int, N: int, path: str | None) -> bool:
+    """Dense key table (volume of the grid) or radix sort (O(N))?  The table is a memset + two passes over `slots` 8-byte entries:
+    worth it while it is small (<= 2^27 slots = 1 GiB) or within 32x the point count; beyond that -- and beyond its hard limit -- sort.
+    ``path`` / RAP_VOXEL_PATH = "dense" | "sorted" forces one (tests)."""
+    path = path or os.environ.get("RAP_VOXEL_PATH")
+    if path == "sorted":
+        return True
+    if path == "dense":
+        return False
+    return slots < 0 or (slots > (1 << 27) and slots > 32 * N)
+
+
+def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float, path: str | None = None) -> torch.Tensor:
     """dataset_utils.py:279-322: points (N,3) on the GPU -> indices (M,) int64 of the point closest to each occupied voxel's
     centre, in ascending voxel-key order (``points[indices]`` is the down-sampled cloud).  Same result as the reference's CPU path
-    bit for bit (its CUDA path divides by multiplying with 1/voxel_size and reduces with a non-deterministic scatter)."""
+    bit for bit (its CUDA path divides by multiplying with 1/voxel_size and reduces with a non-deterministic scatter).
+    Two device paths with identical results: a dense key table over the grid volume, or -- for grids that are large against the
+    number of points -- a radix sort of per-point keys (memory O(N); see ``_use_sorted_voxel_path``)."""
     _require_cuda(points, "points")
     device = points.device
     pts = _f32c(points)
@@ -70,14 +86,23 @@ def voxel_down_sample_torch(points: torch.Tensor, voxel_size: float) -> torch.Te
         h_bounds = bounds.cpu()                            # sizes the key table (the reference synchronises here too: .item())
         h_dmax = float(dmax.cpu())
         slots = lib.rap_voxel_table_slots(h_bounds.data_ptr())
-        if slots < 0:
-            raise ValueError(f"voxel grid {tuple((h_bounds[3:] - h_bounds[:3]).tolist())} needs more than 2^33 table slots")
-        ws = torch.empty(lib.rap_voxel_workspace_bytes(h_bounds.data_ptr()), dtype=torch.uint8, device=device)
-        idx = torch.empty(min(N, slots), dtype=torch.int64, device=device)
         count = torch.empty(1, dtype=torch.int32, device=device)
-        rc = lib.rap_voxel_downsample(_lib.ptr(pts), N, float(voxel_size), h_bounds.data_ptr(), h_dmax, _lib.ptr(idx), _lib.ptr(count),
-                                      _lib.ptr(ws), ws.numel(), stream)
-    _lib.check(rc, "rap_voxel_downsample")
+        if _use_sorted_voxel_path(slots, N, path):
+            if int((h_bounds[3:] - h_bounds[:3]).max()) >= (1 << 18):
+                raise ValueError(f"voxel grid {tuple((h_bounds[3:] - h_bounds[:3]).tolist())}: more than 2^18 cells along an axis")
+            ws = torch.empty(lib.rap_voxel_sorted_workspace_bytes(N), dtype=torch.uint8, device=device)
+            idx = torch.empty(N, dtype=torch.int64, device=device)
+            rc = lib.rap_voxel_downsample_sorted(_lib.ptr(pts), N, float(voxel_size), h_bounds.data_ptr(), h_dmax, _lib.ptr(idx),
+                                                 _lib.ptr(count), _lib.ptr(ws), ws.numel(), stream)
+            _lib.check(rc, "rap_voxel_downsample_sorted")
+        else:
+            if slots < 0:
+                raise ValueError(f"voxel grid {tuple((h_bounds[3:] - h_bounds[:3]).tolist())} needs more than 2^33 table slots")
+            ws = torch.empty(lib.rap_voxel_workspace_bytes(h_bounds.data_ptr()), dtype=torch.uint8, device=device)
+            idx = torch.empty(min(N, slots), dtype=torch.int64, device=device)
+            rc = lib.rap_voxel_downsample(_lib.ptr(pts), N, float(voxel_size), h_bounds.data_ptr(), h_dmax, _lib.ptr(idx), _lib.ptr(count),
+                                          _lib.ptr(ws), ws.numel(), stream)
+            _lib.check(rc, "rap_voxel_downsample")
     return idx[: int(count.cpu())]
 
 
@@ -104,9 +129,10 @@ def remove_statistical_outlier(points: torch.Tensor, nb_neighbors: int = 20, std
     return pts[idx], idx
 
 
-def calculate_voxel_coverage(points: torch.Tensor, voxel_size: float) -> int:
+def calculate_voxel_coverage(points: torch.Tensor, voxel_size: float, path: str | None = None) -> int:
     """point_sampling_utils.py:11-31: number of distinct voxels floor(p / voxel_size) the cloud occupies (exact key: the
-    down-sampling table reproduces the reference's colliding cubic key and cannot be used to count)."""
+    down-sampling table reproduces the reference's colliding cubic key and cannot be used to count).  A byte table over the grid's
+    bounding box, or a radix sort of the per-point voxel ids when that box is large against the number of points."""
     if points.shape[0] == 0:
         return 0
     _require_cuda(points, "points")
@@ -121,12 +147,19 @@ def calculate_voxel_coverage(points: torch.Tensor, voxel_size: float) -> int:
         _lib.check(lib.rap_voxel_bounds(_lib.ptr(pts), N, float(voxel_size), _lib.ptr(bounds), _lib.ptr(dmax), stream), "rap_voxel_bounds")
         h_bounds = bounds.cpu()
         nbytes = lib.rap_voxel_coverage_workspace_bytes(h_bounds.data_ptr())
-        if nbytes == 0:
-            raise ValueError(f"voxel grid {tuple((h_bounds[3:] - h_bounds[:3] + 1).tolist())} is too large for the coverage table")
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         count = torch.empty(1, dtype=torch.int64, device=device)
-        rc = lib.rap_voxel_coverage(_lib.ptr(pts), N, float(voxel_size), h_bounds.data_ptr(), _lib.ptr(count), _lib.ptr(ws), ws.numel(), stream)
-    _lib.check(rc, "rap_voxel_coverage")
+        path = path or os.environ.get("RAP_VOXEL_PATH")
+        if path == "sorted" or (path != "dense" and (nbytes == 0 or (nbytes > (1 << 30) and nbytes > 256 * N))):
+            ws = torch.empty(lib.rap_voxel_sorted_workspace_bytes(N), dtype=torch.uint8, device=device)
+            rc = lib.rap_voxel_coverage_sorted(_lib.ptr(pts), N, float(voxel_size), h_bounds.data_ptr(), _lib.ptr(count), _lib.ptr(ws),
+                                               ws.numel(), stream)
+            _lib.check(rc, "rap_voxel_coverage_sorted")
+        else:
+            if nbytes == 0:
+                raise ValueError(f"voxel grid {tuple((h_bounds[3:] - h_bounds[:3] + 1).tolist())} is too large for the coverage table")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            rc = lib.rap_voxel_coverage(_lib.ptr(pts), N, float(voxel_size), h_bounds.data_ptr(), _lib.ptr(count), _lib.ptr(ws), ws.numel(), stream)
+            _lib.check(rc, "rap_voxel_coverage")
     return int(count.cpu())
 
 

@@ -168,6 +168,40 @@ def test_voxel_downsample_matches_reference_golden_and_oracle(dev):
         voxel_down_sample_torch(torch.tensor([[0.0, 0.0, 0.0], [1e4, 1e4, 1e4]], device=dev), 1e-3)      # 1e7^3 slots
 
 
+def test_voxel_downsample_sorted_path_equals_the_dense_table(dev):
+    """The O(N)-memory path (radix sort of per-point keys, voxel_sort.hip) returns exactly what the dense key table returns: the
+    reference's golden index lists, the oracle on ragged cases, 2M points -- and it is what runs when the grid is far too large for
+    a table: two clusters 5 km apart at 5 cm voxels (10^15 table slots), checked against the oracle."""
+    import numpy as np
+    from oracle import rap_oracle as O
+    from rap_amd.point_sampling import calculate_voxel_coverage, voxel_down_sample_torch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voxel_downsample.npz"))
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    p = (torch.rand(int(z["n"]), 3, generator=g) - 0.4) * torch.from_numpy(z["scale"])
+    for vs in (0.25, 1.0):
+        assert np.array_equal(voxel_down_sample_torch(p.to(dev), vs, path="sorted").cpu().numpy(), z[f"idx_{vs}"])
+    for seed, (n, vs, scale) in enumerate([(1, 0.3, 1.0), (7, 0.3, 1.0), (1000, 0.1, 1.0), (30000, 0.004, 1.0), (5000, 0.5, 40.0)]):
+        g = torch.Generator().manual_seed(seed)
+        q = (torch.rand(n, 3, generator=g) - 0.4) * scale + 0.01
+        if n == 1000:
+            q[500:] = q[:500]                  # duplicates: the lower index wins
+        a = voxel_down_sample_torch(q.to(dev), vs, path="sorted").cpu().numpy()
+        assert np.array_equal(a, voxel_down_sample_torch(q.to(dev), vs, path="dense").cpu().numpy()), (n, vs)
+        assert np.array_equal(a, O.voxel_down_sample(q.numpy(), vs)), (n, vs)
+        assert calculate_voxel_coverage(q.to(dev), vs, path="sorted") == calculate_voxel_coverage(q.to(dev), vs, path="dense") \
+            == int(torch.unique(torch.floor(q / vs).long(), dim=0).shape[0])
+    g = torch.Generator().manual_seed(5)
+    big = ((torch.rand(2_000_000, 3, generator=g) - 0.5) * torch.tensor([60.0, 60.0, 8.0])).to(dev)
+    assert torch.equal(voxel_down_sample_torch(big, 0.2, path="sorted"), voxel_down_sample_torch(big, 0.2, path="dense"))
+    # far too large for a table: picked automatically
+    g = torch.Generator().manual_seed(6)
+    far = torch.rand(40_000, 3, generator=g) * 3.0
+    far[20_000:] += torch.tensor([5000.0, -3000.0, 40.0])
+    idx = voxel_down_sample_torch(far.to(dev), 0.05).cpu().numpy()
+    assert np.array_equal(idx, O.voxel_down_sample(far.numpy(), 0.05))
+    assert calculate_voxel_coverage(far.to(dev), 0.05) == int(torch.unique(torch.floor(far / 0.05).long(), dim=0).shape[0])
+
+
 # ---------------------------------------------------------------------------------------------
 # preprocessing in front of the descriptor: statistical outlier removal and the voxel-adaptive per-part sample count
 # ---------------------------------------------------------------------------------------------
