@@ -17,6 +17,24 @@ from . import _lib
 from .flow_model import PointCloudDiT, _f32c, _require_cuda, workspace
 
 
+def shard_cuts(cu_seqlens_host, n_shards: int) -> list[int]:
+    """Sample indices [0, b_1, ..., B] that cut a packed batch (``cu_seqlens_host``: B+1 token offsets) into at most ``n_shards``
+    contiguous, non-empty shards of about equal TOKEN count: cut k is the sample boundary closest to k/n of the tokens, leaving at
+    least one sample for every later shard."""
+    B = len(cu_seqlens_host) - 1
+    n = max(1, min(int(n_shards), B))
+    TP = cu_seqlens_host[-1] - cu_seqlens_host[0]
+    cuts = [0]
+    for k in range(1, n):
+        target = cu_seqlens_host[0] + TP * k / n
+        cand = range(cuts[-1] + 1, B - (n - 1 - k))
+        if len(cand) == 0:
+            break
+        cuts.append(min(cand, key=lambda i: abs(cu_seqlens_host[i] - target)))
+    cuts.append(B)
+    return cuts
+
+
 class RectifiedPointFlow:
     """Inference-side drop-in for the reference LightningModule's sampling API."""
 
@@ -90,14 +108,7 @@ class RectifiedPointFlow:
         x_1 = torch.randn_like(cond) if x_1 is None else _f32c(x_1.to(device))
         cu_src = data_dict["cu_seqlens"]
         cu_host = (cu_src if not cu_src.is_cuda else cu_src.cpu()).to(torch.int64).tolist()
-        cuts = [0]                                                   # sample index where shard k starts
-        for k in range(1, n):
-            target = TP * k / n
-            b = min(range(cuts[-1] + 1, B - (n - 1 - k)), key=lambda i: abs(cu_host[i] - target), default=None)
-            if b is None:
-                break
-            cuts.append(b)
-        cuts.append(B)
+        cuts = shard_cuts(cu_host, n)
         if len(cuts) <= 2:
             return self._sample_shard(d, x_1, return_transformer_features)
         cur = torch.cuda.current_stream(device)

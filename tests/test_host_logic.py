@@ -109,3 +109,24 @@ def test_checkpoint_loader_edits_keys_like_the_reference(tmp_path):
     torch.save({"Desc.pnt_layer.0.weight": torch.ones(1), "Other.k": torch.ones(1)}, tmp_path / "d.pth")
     load_spinnet_checkpoint(s, str(tmp_path / "d.pth"))
     assert list(s.sd) == ["pnt_layer.0.weight"] and s.strict is False
+
+
+def test_shard_cuts_balance_tokens_at_sample_boundaries():
+    """rap_amd.modeling.shard_cuts: the sample boundaries at which RectifiedPointFlow(num_streams=n) cuts a packed batch -- every shard
+    non-empty, cuts strictly increasing, token counts balanced as well as whole samples allow, never more shards than samples."""
+    from rap_amd.modeling import shard_cuts
+    cu = [0, 8192, 16384, 24576, 32768]                       # uniform
+    assert shard_cuts(cu, 1) == [0, 4]
+    assert shard_cuts(cu, 2) == [0, 2, 4]
+    assert shard_cuts(cu, 4) == [0, 1, 2, 3, 4]
+    assert shard_cuts(cu, 9) == [0, 1, 2, 3, 4]               # at most one shard per sample
+    ragged = [0, 100, 5000, 5100, 5200, 9000, 9050]           # token-balanced, not sample-balanced
+    assert shard_cuts(ragged, 2) == [0, 2, 6]                 # 5000 | 4050 is the closest split to 4525
+    c3 = shard_cuts(ragged, 3)
+    assert c3[0] == 0 and c3[-1] == 6 and len(c3) == 4 and all(b > a for a, b in zip(c3, c3[1:]))
+    for n in range(1, 8):
+        c = shard_cuts(ragged, n)
+        assert c[0] == 0 and c[-1] == 6 and all(b > a for a, b in zip(c, c[1:])) and len(c) - 1 <= min(n, 6)
+    assert shard_cuts([0, 10], 4) == [0, 1]                   # a single sample cannot be cut
+    off = [1000, 1100, 6000, 6100]                            # offsets that do not start at 0 (a shard of a larger batch)
+    assert shard_cuts(off, 2) == [0, 2, 3] or shard_cuts(off, 2) == [0, 1, 3]
