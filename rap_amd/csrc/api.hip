@@ -129,7 +129,7 @@ int g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QK
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 48)) { g_rap_gemm_variant = value; return RAP_OK; }
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
-  if (key == 2 && value >= 0 && value <= 15) { g_rap_gemm_h16_variant = value; return RAP_OK; }
+  if (key == 2 && value >= 0 && value <= 16) { g_rap_gemm_h16_variant = value; return RAP_OK; }
 #ifdef RAP_ABLATION_BUILD
   if (key == 3 && ((value >= 14 && value <= 18) || value == 21)) { g_rap_attn_h16_variant = value; return RAP_OK; }
 #endif

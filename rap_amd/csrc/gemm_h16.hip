@@ -497,6 +497,176 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent form of the two-stage 256x256 kernel (r02; rap_set_tuning(2, 16), NOT the default until measured): one block per CU
+// walks the output tiles with stride gridDim.x (a multiple of 8, so a block keeps its XCD and xcd_remap keeps its meaning), and the
+// FIRST k-tile of the next output tile is requested at the start of the LAST k-tile of the current one -- into the stage buffer the
+// k-loop has just released -- so that it lands under the last MFMAs and the epilogue instead of in front of an idle matrix pipe
+// (K = 512 is only 8 k-tiles per output tile).  The epilogue's per-wave transposition slabs therefore move out of stage 0: three
+// waves each in A1 and B1 (free once the last k-tile has been read) and two in the 32 KB of LDS beyond the stage buffers.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int DT>
+__global__ __launch_bounds__(512, 2) void gemm_h16_pers_kernel(GemmParamsH p) {
+  typedef typename H16<DT>::T8 T8;
+  constexpr int WN = 4, TM = 4, TN = 2, NT = 512, BM = 256, BN = 256;
+  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;   // 16-byte chunks per thread per k-tile
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [A0 A1 B0 B1 | 32 KB of slab space]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  const int nt = p.N / BN;
+  const int mt = (p.M + BM - 1) / BM;
+  const int total = mt * nt;
+  const int nk = p.K / 64;
+  const int sw = (l31 >> 1) & 7;
+  const int a_row = (wm * TM * 32 + l31) * 128;
+  const int b_row = (wn * TN * 32 + l31) * 128;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+  // slab of this wave: waves 0-2 in A1, 3-5 in B1, 6-7 behind the stage buffers
+  const int slab_off = wave < 3 ? ABYTES + wave * H16_STG_BYTES
+                     : wave < 6 ? 2 * ABYTES + BBYTES + (wave - 3) * H16_STG_BYTES
+                                : 2 * ABYTES + 2 * BBYTES + (wave - 6) * H16_STG_BYTES;
+  static_assert(3 * H16_STG_BYTES <= ABYTES && 3 * H16_STG_BYTES <= BBYTES && 2 * H16_STG_BYTES <= 32768, "slab placement");
+
+  const u16* a_src[CA];
+  const u16* w_src[CB];
+  auto set_sources = [&](int tile) {
+    const int logical = xcd_remap(tile, total);
+    const int m0_ = (logical / nt) * BM, n0_ = (logical % nt) * BN;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int id = i * NT + tid;
+      const int row = id >> 3;
+      const int lslot = (id & 7) ^ ((row >> 1) & 7);
+      int r = m0_ + row;
+      r = r < p.M ? r : p.M - 1;
+      a_src[i] = p.A + (size_t)r * p.lda + 8 * lslot;
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int id = i * NT + tid;
+      const int row = id >> 3;
+      const int lslot = (id & 7) ^ ((row >> 1) & 7);
+      w_src[i] = p.W + (size_t)(n0_ + row) * p.ldw + 8 * lslot;
+    }
+  };
+
+  struct Frag { uint4 a[TM]; uint4 b[TN]; };
+  Frag f0, f1;
+  f32x16 acc[TM][TN];
+  auto read_frag = [&](Frag& f, int buf, int g) {
+    const int co = ((2 * g + hi) ^ sw) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      f.a[i] = *reinterpret_cast<const uint4*>(smem + buf * ABYTES + a_row + i * 32 * 128 + co);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      f.b[j] = *reinterpret_cast<const uint4*>(smem + 2 * ABYTES + buf * BBYTES + b_row + j * 32 * 128 + co);
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, f.a[i]), __builtin_bit_cast(T8, f.b[j]), acc[i][j]);
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= total) return;
+  set_sources(tile);
+  HG_DMA(0, 0)
+  for (; tile < total; tile += gridDim.x) {
+    const int logical = xcd_remap(tile, total);
+    const int m0 = (logical / nt) * BM, n0 = (logical % nt) * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    HG_SYNC                                   // k-tile 0 of this tile has landed; the previous tile's slabs are no longer in use
+    read_frag(f0, 0, 0);
+    int kt = 0;
+    for (; kt + 1 < nk; ++kt) {
+      const int cur = kt & 1;
+      HG_DMA(kt + 1, cur ^ 1)
+      read_frag(f1, cur, 1);
+      HG_FENCE
+      mma(f0);
+      HG_FENCE
+      read_frag(f0, cur, 2);
+      HG_FENCE
+      mma(f1);
+      HG_FENCE
+      read_frag(f1, cur, 3);
+      HG_FENCE
+      mma(f0);
+      HG_FENCE
+      HG_SYNC
+      read_frag(f0, cur ^ 1, 0);
+      HG_FENCE
+      mma(f1);
+      HG_FENCE
+    }
+    {
+      const int cur = kt & 1;                 // = 1: nk is even (checked by the launcher), stage 0 is free from here on
+      const int next = tile + (int)gridDim.x;
+      if (next < total) {                     // block-uniform
+        set_sources(next);
+        HG_DMA(0, 0)                          // the next output tile's first k-tile, under the last MFMAs and the epilogue
+      }
+      read_frag(f1, cur, 1);
+      HG_FENCE
+      mma(f0);
+      HG_FENCE
+      read_frag(f0, cur, 2);
+      HG_FENCE
+      mma(f1);
+      HG_FENCE
+      read_frag(f1, cur, 3);
+      HG_FENCE
+      mma(f0);
+      HG_FENCE
+      mma(f1);
+    }
+    __syncthreads();                          // every wave has read the last k-tile: A1 / B1 may become slabs
+    gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + slab_off, m0 + wm * TM * 32, n0 + wn * 64, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI, int DT>
+static int launch_pers(hipStream_t stream, const GemmParamsH& p) {
+  constexpr int LDS = 2 * (256 + 256) * 128 + 32768;
+  static bool attr_done = false;
+  static int n_cu = 0;
+  auto kern = gemm_h16_pers_kernel<EPI, DT>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      rap_set_last_hip_error((int)hipGetLastError());
+      return RAP_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RAP_ERR_HIP;
+    n_cu = prop.multiProcessorCount > 8 ? (prop.multiProcessorCount / 8) * 8 : 8;
+  }
+  const int total = ((p.M + 255) / 256) * (p.N / 256);
+  const int grid = total < n_cu ? total : n_cu;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Ring variants (rap_set_tuning(2, 3 | 4); NOT the default): BK = 32 slices in an LDS ring with NSTAGE - 1 slices in flight
 // (counted s_waitcnt vmcnt, never 0 in the steady state) -- 256x256 / 8 waves / four 32 KB stages, or 256x128 / 4 waves /
 // three 24 KB stages at TWO blocks per CU.
@@ -1169,6 +1339,10 @@ static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
   if (v == 4) return launch_ring<EPI, DT, 2, 2, 4, 3>(stream, p);
   // 6 / 7 / 8 (r02): pipelined ring, 256x256, five 32 KB stages (6), + s_setprio around the MFMA groups (7), four stages (8)
   // 13 / 14 / 15 (r02): phase-split kernel: staggered wave rows + setprio (13), staggered without setprio (14), lockstep + setprio (15)
+  if constexpr (EPI == EPI_H_BIAS || EPI == EPI_H_BIAS_RESID_F32 || EPI == EPI_H_GEGLU) {
+    if (v == 16 && p.N % 256 == 0 && p.K >= 128 && (p.K / 64) % 2 == 0) return launch_pers<EPI, DT>(stream, p);
+  }
+  if (v == 16 && p.N % 256 == 0 && p.K >= 128) return launch_ph<EPI, DT, 0, 1>(stream, p);      // epilogues without a persistent form: the default
   if (v == 13 && p.N % 256 == 0 && p.K >= 128) return launch_ph<EPI, DT, 1, 1>(stream, p);
   if (v == 14 && p.N % 256 == 0 && p.K >= 128) return launch_ph<EPI, DT, 0, 1>(stream, p);
   if (v == 15 && p.N % 256 == 0 && p.K >= 128) return launch_ph<EPI, DT, 1, 0>(stream, p);

@@ -70,9 +70,9 @@ def gemm_h(lib, dev, dt, epi, A, W, C, M, N, K, bias=None, resid=None, heads=0, 
 DEFAULT_GEMM_H16_VARIANT = 14      # phase-split 256x256 (r02)
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 9, 11, 14],
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 9, 11, 14, 16],
                 ids=["tile128x128", "tile256x256", "tile256x128", "ring256x256", "ring256x128", "tile128x512", "pipe5stage", "interleaved",
-                     "interleaved_staggered", "phase_split"])
+                     "interleaved_staggered", "phase_split", "persistent_prefetch"])
 def tile_variant(request, lib):
     assert lib.rap_set_tuning(2, request.param) == 0
     yield request.param
