@@ -118,6 +118,7 @@ static bool desc_ok(const rap_model_desc* d) {
 extern int g_rap_gemm_variant;   // gemm_f32.hip
 extern int g_rap_gemm_stagger;   // gemm_f32.hip
 extern int g_rap_gemm_splitk;    // gemm_f32.hip
+extern int g_rap_geglu_fast;     // gemm_f32.hip
 extern int g_rap_attn_variant;   // attn_f32.hip
 extern int g_rap_attn_split;     // attn_f32.hip
 extern int g_rap_gemm_h16_variant;   // gemm_h16.hip
@@ -145,6 +146,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 6 && (value == 0 || value == 1)) { g_rap_gemm_splitk = value; return RAP_OK; }
   if (key == 7 && (value == 0 || value == 1)) { g_rap_fuse_qknorm = value; return RAP_OK; }
   if (key == 8 && (value == 0 || value == 1)) { g_rap_fuse_ln = value; return RAP_OK; }
+  if (key == 9 && (value == 0 || value == 1)) { g_rap_geglu_fast = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 

@@ -18,6 +18,7 @@
 //  * 1-D grid, XCD-aware remap, n-tile fastest: all n-tiles of one 128-row A panel run back to
 //    back on one XCD (A panel stays in that XCD's L2; W streams from L2 / Infinity Cache).
 #include <type_traits>
+#include "half.h"
 #include "kernels.h"
 
 #define GBM 128
@@ -598,6 +599,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
     const int nout = (nw >> 1) + l31;
     const float bh = p.bias ? p.bias[nw + l31] : 0.f;
     const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+    if (p.geglu_fast) {                              // tuning key 9: packed-pair GEGLU (see half.h), stage-major over 8 pairs
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        f32x2 h2[8], g2[8], o2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          h2[j] = f32x2{acc[mi][0][2 * j], acc[mi][0][2 * j + 1]} + f32x2{bh, bh};
+          g2[j] = f32x2{acc[mi][1][2 * j], acc[mi][1][2 * j + 1]} + f32x2{bg, bg};
+        }
+        geglu_pairs<8>(h2, g2, o2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int m = mw + mi * 32 + mfma32_crow(2 * j, hi);
+          if (m < p.M) p.C[(size_t)m * p.ldc + nout] = o2[j].x;
+          if (m + 1 < p.M) p.C[(size_t)(m + 1) * p.ldc + nout] = o2[j].y;
+        }
+      }
+      return;
+    }
     auto geglu = [&](auto G) {                       // G: guard rows against M (only the last row tile needs it)
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -828,6 +848,25 @@ __global__ __launch_bounds__(512) void gemm_f32_dma256_kernel(GemmParams p) {
     const int nout = (nw >> 1) + l31;
     const float bh = p.bias ? p.bias[nw + l31] : 0.f;
     const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+    if (p.geglu_fast) {                              // tuning key 9: packed-pair GEGLU (see half.h), stage-major over 8 pairs
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        f32x2 h2[8], g2[8], o2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          h2[j] = f32x2{acc[mi][0][2 * j], acc[mi][0][2 * j + 1]} + f32x2{bh, bh};
+          g2[j] = f32x2{acc[mi][1][2 * j], acc[mi][1][2 * j + 1]} + f32x2{bg, bg};
+        }
+        geglu_pairs<8>(h2, g2, o2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int m = mw + mi * 32 + mfma32_crow(2 * j, hi);
+          if (m < p.M) p.C[(size_t)m * p.ldc + nout] = o2[j].x;
+          if (m + 1 < p.M) p.C[(size_t)(m + 1) * p.ldc + nout] = o2[j].y;
+        }
+      }
+      return;
+    }
     auto geglu = [&](auto G) {
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
@@ -966,8 +1005,15 @@ static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int var
 
 int g_rap_gemm_splitk = 1;      // tuning key 6: 0 = never split K for few-row calls
 int g_rap_gemm_stagger = 1;     // measured (r01 run 39): +1.3 % on the K = 512 shapes, +1.2 % at K = 2048; 2 (by CU id) is no better
+// tuning key 9 (fp32 path): GEGLU's Phi(g).  1 (default since r02 call 50) = Abramowitz-Stegun 7.1.26 erfc, |error| <= 1.5e-7 absolute
+// (about one fp32 ulp of Phi near 1/2), on the packed fp32 pipe, stage-major over eight output pairs (half.h: geglu_pairs) -- the
+// epilogue of the largest GEMM of a layer was ~50 scalar VALU instructions per output with erff: ff1 8.35 -> 8.09 ms (131.7 -> 135.9 TF),
+// headline 15 940 -> 16 049 points/s, all-step deviation from the unmodified reference unchanged (final cloud 5.4e-7 vs 6.6e-7,
+// per-step maximum 9.5e-7 vs 8.3e-7: the fp32 noise floor).  0 = libm-grade erff.
+int g_rap_geglu_fast = 1;
 int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
   GemmParams p = p_in;
+  p.geglu_fast = g_rap_geglu_fast;
   p.stagger = ((long)((p.M + GBM - 1) / GBM) * (p.N / GBN) >= 1024) ? g_rap_gemm_stagger : 0;     // only when the chip is filled twice over
   if (p.M <= 0) return RAP_OK;
   if (p.N % GBN != 0 || p.K % GBK != 0 || p.K <= 0) return RAP_ERR_INVALID;

@@ -40,42 +40,6 @@ __device__ __forceinline__ float gelu_erf_fast(float g) {
 // 1.6 ms ff1 GEMM, and the disassembly showed ~24 scalar VALU instructions per output (nothing packed).  Here every multiply / FMA of
 // the polynomial handles two outputs (v_pk_mul_f32 / v_pk_fma_f32: twice the fp32 rate when no MFMA is in flight), the branch of
 // gelu_erf_fast becomes Phi(g) = 1/2 + copysign(1/2 - q/2, g), and the two results leave as ONE v_cvt_pk: ~13 instructions per output.
-// Stage-major over NP independent pairs: a packed result feeds the next packed op only NP instructions later (issued back to back,
-// hipcc pads every dependent v_pk pair with an s_nop: 249 of them in the first version).
-template <int NP>
-__device__ __forceinline__ void geglu_pairs(const f32x2 (&h)[NP], const f32x2 (&g)[NP], f32x2 (&o)[NP]) {
-  f32x2 ax[NP], t[NP], poly[NP], q[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) ax[i] = f32x2{fabsf(g[i].x), fabsf(g[i].y)} * f32x2{0.70710678118654752440f, 0.70710678118654752440f};
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const f32x2 d = __builtin_elementwise_fma(ax[i], f32x2{0.3275911f, 0.3275911f}, f32x2{1.0f, 1.0f});
-    t[i] = f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-  }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const f32x2 e = ax[i] * (ax[i] * f32x2{-1.44269504088896340736f, -1.44269504088896340736f});
-    q[i] = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-  }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) poly[i] = __builtin_elementwise_fma(t[i], f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
-#pragma unroll
-  for (int i = 0; i < NP; ++i) poly[i] = __builtin_elementwise_fma(t[i], poly[i], f32x2{1.421413741f, 1.421413741f});
-#pragma unroll
-  for (int i = 0; i < NP; ++i) poly[i] = __builtin_elementwise_fma(t[i], poly[i], f32x2{-0.284496736f, -0.284496736f});
-#pragma unroll
-  for (int i = 0; i < NP; ++i) poly[i] = __builtin_elementwise_fma(t[i], poly[i], f32x2{0.254829592f, 0.254829592f});
-#pragma unroll
-  for (int i = 0; i < NP; ++i) q[i] *= poly[i] * t[i];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const f32x2 u = __builtin_elementwise_fma(q[i], f32x2{-0.5f, -0.5f}, f32x2{0.5f, 0.5f});     // 1/2 - q/2 >= 0
-    q[i] = f32x2{0.5f, 0.5f} + f32x2{__builtin_copysignf(u.x, g[i].x), __builtin_copysignf(u.y, g[i].y)};
-  }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) o[i] = h[i] * (g[i] * q[i]);
-}
-
 // ---------------- epilogue (shared by the kernels below) ----------------
 // acc[i][j][r] = C[mw + 32 i + crow(r, hi)][nw + 32 j + l31]: a lane owns ONE column, so direct stores would be
 // 2- or 4-byte scatters (measured: the out-projection ran at 147 TF, 4x its HBM floor).  Every wave therefore

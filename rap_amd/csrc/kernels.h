@@ -35,6 +35,7 @@ struct GemmParams {
   // (x / max(|x|, 1e-12) * gamma * 8 per head row), v unchanged; NULL = plain projection
   const float* gamma_q; const float* gamma_k;
   int stagger;     // set by launch_gemm_f32 (tuning key 4): 0 off, 1 first-wave blocks [256,512) start half a tile late, 2 by CU slot
+  int geglu_fast;  // set by launch_gemm_f32 (tuning key 9): 1 = GEGLU on the packed fp32 pipe with the 1.5e-7 erfc (half.h geglu_pairs), 0 = erff
 };
 int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p);
 

@@ -115,12 +115,16 @@ def main():
     ap.add_argument("--attn-variant", type=int, default=-1)
     ap.add_argument("--dtype", default="float32", help="float32 | bfloat16 | float16 (16-bit: GEMM / attention / LN / qknorm twins)")
     ap.add_argument("--h16-gemm-variant", type=int, default=-1)
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE", help="rap_set_tuning(KEY, VALUE) before the run")
     ap.add_argument("--pad-lda", type=int, default=0, help="16-bit GEMM: extra elements per row of A and W (row stride K + pad)")
     ap.add_argument("--h16-attn-variant", type=int, default=-1, help="timing-only ablations of the 16-bit attention kernel")
     ap.add_argument("--bounded", type=int, default=1, help="pass per-head logit bounds to the 16-bit attention (bounded-softmax v2, bf16)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
+    for kv in args.tuning:
+        k_, v_ = (int(x) for x in kv.split('='))
+        assert lib.rap_set_tuning(k_, v_) == 0, kv
     if args.gemm_variant >= 0:
         assert lib.rap_set_tuning(0, args.gemm_variant) == 0
     if args.gemm_stagger >= 0:
