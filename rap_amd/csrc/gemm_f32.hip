@@ -43,8 +43,14 @@ __device__ __forceinline__ void qkv_store_normalised(const GemmParams& p, f32x16
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float s = acc[mi][0][r] * acc[mi][0][r] + acc[mi][1][r] * acc[mi][1][r];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      // sum over the 32 lanes of the half-wave (= the 64 columns of the head): four DPP steps inside the VALU (quad xor 1, quad xor 2,
+      // mirror within 8, mirror within 16 -- mirrored partners hold the same partial sums, so every lane ends with the total) and one
+      // ds_swizzle across the two 16-lane rows, instead of five ds_bpermute round trips through the LDS queue (r02: 320 per wave tile)
+      s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));
+      s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));
+      s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));
+      s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, true));
+      s += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, s), 0x401F));
       const float nrm = fmaxf(sqrtf(s), 1e-12f);
       const int m = mw + mi * 32 + mfma32_crow(r, hi);
       if (m < p.M) {
@@ -678,6 +684,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
       for (int ni = 0; ni < 2; ++ni) {
         const int n = nw + ni * 32 + l31;
         const float bn = p.bias ? p.bias[n] : 0.f;
+        size_t qkv_col = 0;                            // head-major plane and column of this lane's output column (one division per column, not per element)
+        if (EPI == EPI_QKV_HEADMAJOR) {
+          const int dmodel = p.heads * 64;
+          const int c = n / dmodel;
+          const int rem = n - c * dmodel;
+          qkv_col = ((size_t)c * p.heads + (rem >> 6)) * (size_t)p.M * 64 + (rem & 63);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mw + mi * 32 + mfma32_crow(r, hi);
@@ -695,11 +708,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
             const int sel = p.anchor[m] ? 1 : 0;
             p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
           } else if (EPI == EPI_QKV_HEADMAJOR) {
-            const int dmodel = p.heads * 64;
-            const int c = n / dmodel;
-            const int rem = n - c * dmodel;
-            const int h = rem >> 6, j = rem & 63;
-            p.C[(((size_t)c * p.heads + h) * p.M + m) * 64 + j] = v;
+            p.C[qkv_col + (size_t)m * 64] = v;
           }
         }
       }
@@ -923,6 +932,13 @@ __global__ __launch_bounds__(512) void gemm_f32_dma256_kernel(GemmParams p) {
     for (int ni = 0; ni < TN; ++ni) {
       const int n = nw + ni * 32 + l31;
       const float bn = p.bias ? p.bias[n] : 0.f;
+      size_t qkv_col = 0;                              // head-major plane and column of this lane's output column
+      if (EPI == EPI_QKV_HEADMAJOR) {
+        const int dmodel = p.heads * 64;
+        const int c = n / dmodel;
+        const int rem = n - c * dmodel;
+        qkv_col = ((size_t)c * p.heads + (rem >> 6)) * (size_t)p.M * 64 + (rem & 63);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mw + mi * 32 + mfma32_crow(r, hi);
@@ -938,11 +954,7 @@ __global__ __launch_bounds__(512) void gemm_f32_dma256_kernel(GemmParams p) {
           const int sel = p.anchor[m] ? 1 : 0;
           p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
         } else if (EPI == EPI_QKV_HEADMAJOR) {
-          const int dmodel = p.heads * 64;
-          const int c = n / dmodel;
-          const int rem = n - c * dmodel;
-          const int h = rem >> 6, j = rem & 63;
-          p.C[(((size_t)c * p.heads + h) * p.M + m) * 64 + j] = v;
+          p.C[qkv_col + (size_t)m * 64] = v;
         }
       }
     }
