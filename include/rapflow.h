@@ -340,15 +340,18 @@ int rap_check_batch(const int64_t* points_per_part, const int32_t* cu_batch, int
  * (0 attention per part, 1 attention per sample, 2 layer GEMMs), the summed milliseconds and the launch count
  * into HOST arrays of 3 entries.  Not thread-safe; off by default. */
 int rap_profile_enable(int on);
-/* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py): key 0 = fp32 GEMM {0: 128x128 v1, 2: pipelined
- * 128x128, 4: pipelined 128x256, 8: 256x128 8-wave, 16: LDS-DMA staged 128x128, 32: LDS-DMA staged 256x256 8-wave, 48: per shape (default)}, key 1 = fp32 attention
- * {1: 4-wave v1 (default), 3: pipelined, 5: 8-wave v1}, key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave (default),
- * 2: 256x128 8-wave, 3/4: ring-buffered, 5: 128x512, 6-8: pipelined rings, 9-12: interleaved issue, 13-15: phase-split}, key 3 = 16-bit attention schedule (0 default, see attn_h16.hip), key 4 = fp32 GEMM
- * phase stagger {0 off, 1 by block index (default), 2 by CU id}, key 5 = split-KV attention for few-token calls {0 off, 1 on
- * (default)}, key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}, key 7 = qk-norm fused
- * into the QKV GEMM epilogue {1 (default)} or as its own kernel {0} (both precisions), key 8 = 16-bit path: the next LayerNorm fused into the epilogue of
- * the residual GEMMs (out-projection, FFN down-projection) {1} or as its own kernel {0 (default: measured faster)}.
- * All variants compute the same function. */
+/* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py, bench.py --tuning); process-global, not thread-safe, not for a
+ * serving path.  key 0 = fp32 GEMM {0: 128x128 v1, 2: pipelined 128x128, 4: pipelined 128x256, 8: 256x128 8-wave, 16: LDS-DMA staged
+ * 128x128, 32: LDS-DMA staged 256x256 8-wave, 48: per shape (default)}; key 1 = fp32 attention {1: 4-wave v1 (default), 3: pipelined,
+ * 5: 8-wave v1}; key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave two-stage, 2: 256x128 8-wave, 3/4: ring-buffered, 5: 128x512,
+ * 6-8: pipelined rings, 9-12: interleaved issue, 13-15: phase-split (14 = default), 16: persistent two-stage with next-tile prefetch};
+ * key 3 = 16-bit attention schedule {0 default, 4/5/8: softmax variants, 9: un-scaled q, 11: ping-pong, 12: software-pipelined (pinned),
+ * 13: software-pipelined, two tiles per barrier, 19: persistent blocks, 20: rotated key walk; see attn_h16.hip}; key 4 = fp32 GEMM phase
+ * stagger {0 off, 1 by block index (default), 2 by CU id}; key 5 = split-KV attention for few-token calls {0 off, 1 on (default)};
+ * key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}; key 7 = qk-norm fused into the QKV GEMM
+ * epilogue {1 (default)} or as its own kernel {0} (both precisions); key 8 = 16-bit path: the next LayerNorm fused into the epilogue of the
+ * residual GEMMs {1} or as its own kernel {0 (default: measured faster)}; key 9 = fp32 GEGLU epilogue {1 (default): erfc to 1.5e-7 on the
+ * packed fp32 pipe, 0: erff}.  All variants compute the same function (key 9: to within 1.5e-7 of Phi). */
 int rap_set_tuning(int32_t key, int32_t value);
 int rap_profile_reset(void);
 int rap_profile_collect(float* h_ms_out, int64_t* h_count_out);
