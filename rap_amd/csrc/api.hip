@@ -134,7 +134,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
 #ifdef RAP_ABLATION_BUILD
   if (key == 3 && ((value >= 14 && value <= 18) || value == 21)) { g_rap_attn_h16_variant = value; return RAP_OK; }
 #endif
-  if (key == 3 && ((value >= 0 && value <= 13) || value == 19 || value == 20)) {
+  if (key == 3 && ((value >= 0 && value <= 13) || value == 19 || value == 20 || value == 22 || value == 23)) {
 #ifndef RAP_ABLATION_BUILD
     // 1-3, 6, 7 are timing-only ablations ("NOT attention"): compiled out of the shipped library, refused here
     if (value == 1 || value == 2 || value == 3 || value == 6 || value == 7) return RAP_ERR_INVALID;

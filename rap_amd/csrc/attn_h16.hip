@@ -63,7 +63,9 @@ extern "C" int rap_debug_attn_ts(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(
 #else
 #define ATT_TS(I)
 #endif
-template <int DT, int ABL, int OPT, bool PERSIST = false, bool ROT = false>
+// LST (r02, rap_set_tuning(3, 22)): the output tile leaves through the wave's own 4.6 KB slab of the (by then idle) K / V^T buffers and
+// is stored as whole 128-byte rows, 16 bytes per lane, instead of eight 8-byte pieces per lane at a 1 KB row stride.
+template <int DT, int ABL, int OPT, bool PERSIST = false, bool ROT = false, bool LST = false>
 __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
                                                                int vt_nblk, u16* __restrict__ out, int TP, int heads,
                                                                const AttnWorkItem* __restrict__ items,
@@ -275,7 +277,28 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   const int q = qw0 + l31;
   const float inv = 1.0f / h_xhalf_sum(lsum);
   if ((ABL & 64) && inv != 12345.678f) continue;    // timing-only: no output stores
-  if (q < len) {
+  if (LST) {
+    // every wave of the block is past the last tile's barrier: the K / V^T buffers are free.  Slab of this wave: [32 queries][72]
+    u16* slab = smem + wave * (32 * HLD);
+    u16* wp = slab + l31 * HLD + 4 * hi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<uint2*>(wp + 8 * g) =
+          h16_pack4<DT>(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+      *reinterpret_cast<uint2*>(wp + 32 + 8 * g) =
+          h16_pack4<DT>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slab is private to the wave and LDS operations of a wave execute in order:
+    __builtin_amdgcn_wave_barrier();                          // no block barrier (waves without queries have left already)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (lane >> 3) + 8 * i, piece = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(slab + row * HLD + piece * 8);
+      if (qw0 + row < len)
+        *reinterpret_cast<uint4*>(out + (size_t)(seg0 + qw0 + row) * (heads * 64) + head * 64 + piece * 8) = v;
+    }
+    if (PERSIST) __syncthreads();
+  } else if (q < len) {
     u16* op = out + (size_t)(seg0 + q) * (heads * 64) + head * 64 + 4 * hi;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -860,7 +883,7 @@ int g_rap_attn_h16_variant = 0;
 // the model path asks before it runs qk-norm: pre-scaled q only feeds the default bounded bf16 kernel
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {
   const int v = g_rap_attn_h16_variant;
-  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10 || v == 12 || v == 13 || v == 19 || v == 20);
+  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10 || v == 12 || v == 13 || v == 19 || v == 20 || v == 22 || v == 23);
 }
 
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
@@ -879,6 +902,10 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
   }
 #define HATT_LAUNCH(DTV, ABLV, OPTV) \
   hipLaunchKernelGGL((attention_h16_kernel<DTV, ABLV, OPTV>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, max_items * heads)
+  // the shipped default since r02 call 54: the same kernel with the output stored as whole rows through an LDS slab (LST): +0.2 ... 1.8 % per
+  // launch, bench 106.8 k -> 107.4 k points/s; rap_set_tuning(3, 23) = the direct 8-byte stores
+#define HATT_LAUNCH_D(DTV, OPTV) \
+  hipLaunchKernelGGL((attention_h16_kernel<DTV, 0, OPTV, false, false, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, max_items * heads)
   if (dtype == RAP_DT_BF16) {
     switch (g_rap_attn_h16_variant) {
 #ifdef RAP_ABLATION_BUILD      // timing-only kernels whose output is NOT attention: never part of the shipped library
@@ -929,6 +956,13 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
         else HATT_LAUNCH(RAP_DT_BF16, 0, 3);
         break;
       }
+      case 22:                                            // output stored as whole rows through an LDS slab
+#define HATT_LAUNCH_L(OPTV) \
+  hipLaunchKernelGGL((attention_h16_kernel<RAP_DT_BF16, 0, OPTV, false, false, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, max_items * heads)
+        if (bound && q_prescaled) HATT_LAUNCH_L(24);
+        else if (bound) HATT_LAUNCH_L(8);
+        else HATT_LAUNCH_L(3);
+        break;
       case 20:                                            // rotated key-tile walk
 #define HATT_LAUNCH_R(OPTV) \
   hipLaunchKernelGGL((attention_h16_kernel<RAP_DT_BF16, 0, OPTV, false, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, max_items * heads)
@@ -947,14 +981,21 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
         else HATT_LAUNCH_P(3);
         break;
       }
-      default:
+      case 23:                                            // the r01 epilogue: direct 8-byte stores
         if (bound && q_prescaled) HATT_LAUNCH(RAP_DT_BF16, 0, 24);
         else if (bound) HATT_LAUNCH(RAP_DT_BF16, 0, 8);
         else HATT_LAUNCH(RAP_DT_BF16, 0, 3);
         break;
+      default:
+        if (bound && q_prescaled) HATT_LAUNCH_D(RAP_DT_BF16, 24);
+        else if (bound) HATT_LAUNCH_D(RAP_DT_BF16, 8);
+        else HATT_LAUNCH_D(RAP_DT_BF16, 3);
+        break;
     }
   } else if (dtype == RAP_DT_F16) {
-    if (g_rap_attn_h16_variant == 8) HATT_LAUNCH(RAP_DT_F16, 0, 0); else HATT_LAUNCH(RAP_DT_F16, 0, 3);
+    if (g_rap_attn_h16_variant == 8) HATT_LAUNCH(RAP_DT_F16, 0, 0);
+    else if (g_rap_attn_h16_variant == 23) HATT_LAUNCH(RAP_DT_F16, 0, 3);
+    else HATT_LAUNCH_D(RAP_DT_F16, 3);
   } else {
     return RAP_ERR_INVALID;
   }
