@@ -100,7 +100,7 @@ __global__ __launch_bounds__(COL_THREADS) void collate_frame_kernel(const void* 
     scales[b] = (float)scale;
     global_translation[3 * b + 0] = (float)gx; global_translation[3 * b + 1] = (float)gy; global_translation[3 * b + 2] = (float)gz;
   }
-  if (threadIdx.x < P) {
+  if ((int)threadIdx.x < P) {                           // P <= 256 = COL_THREADS (checked by rap_collate_transform)
     const int i = threadIdx.x, part = p0 + i;
     const int n = off[part + 1] - off[part];
     double cx = 0, cy = 0, cz = 0;
