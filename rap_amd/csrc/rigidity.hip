@@ -87,9 +87,11 @@ __global__ __launch_bounds__(64) void argmin_generation_kernel(const float* __re
   if (b >= B) return;
   int bi = 0;
   float bv = rmse[b];
-  for (int g = 1; g < G; ++g) {
+  bool bn = bv != bv;                      // torch.argmin / argmax treat NaN as the extremum: the FIRST NaN wins
+  for (int g = 1; g < G && !bn; ++g) {
     const float v = rmse[(size_t)g * B + b];
-    if (largest ? (v > bv) : (v < bv)) { bv = v; bi = g; }
+    const bool vn = v != v;
+    if (vn || (largest ? (v > bv) : (v < bv))) { bv = v; bi = g; bn = vn; }
   }
   best[b] = bi;
 }

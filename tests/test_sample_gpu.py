@@ -212,6 +212,28 @@ def test_rigidity_rmse_and_selection_match_reference_golden(dev):
     assert (pp.cpu() - torch.from_numpy(g["per_part_rmse"])).abs().max().item() < 2e-6
 
 
+def test_generation_selection_follows_torch_argmin_on_ties_inf_and_nan(dev):
+    """per-object argmin over generations like torch.argmin (modeling.py:518): first index on ties, inf never beats a finite value,
+    and a NaN rigidity -- torch.argmin returns the first NaN -- is selected, not skipped; argmax (overlap ratio, :601) likewise."""
+    nan, inf = float("nan"), float("inf")
+    rig = torch.tensor([[0.3, inf, 0.5, nan, 0.2, 1.0],
+                        [0.1, 0.7, 0.5, 0.1, nan, 1.0],
+                        [0.1, 0.2, 0.5, 0.0, nan, 1.0]])                       # (G=3, B=6)
+    B, P, n = 6, 1, 4
+    cu = torch.arange(0, (B + 1) * n, n)
+    clouds = torch.arange(3 * B * n * 3, dtype=torch.float32).reshape(3, B * n, 3).to(dev)
+    R = torch.arange(3 * B * 9, dtype=torch.float32).reshape(3, B, P, 3, 3).to(dev)
+    t = torch.arange(3 * B * 3, dtype=torch.float32).reshape(3, B, P, 3).to(dev)
+    best, cloud, Rs, ts = rap_amd.select_generations_by_rigidity(rig.to(dev), clouds, R, t, cu)
+    want = torch.argmin(rig, dim=0)
+    assert torch.equal(best.cpu(), want), (best.cpu(), want)
+    for b in range(B):
+        assert torch.equal(cloud[b * n:(b + 1) * n].cpu(), clouds[want[b], b * n:(b + 1) * n].cpu())
+        assert torch.equal(Rs[b].cpu(), R[want[b], b].cpu()) and torch.equal(ts[b].cpu(), t[want[b], b].cpu())
+    best_max, _, _, _ = rap_amd.select_generations_by_rigidity(rig.to(dev), clouds, R, t, cu, _pick_largest=True)
+    assert torch.equal(best_max.cpu(), torch.argmax(rig, dim=0))
+
+
 def test_rigidity_rmse_edge_cases_match_oracle(dev):
     """object without points -> inf; exact rigid image -> 0; per-step output of the trajectory average vs the oracle."""
     inp = S.make_inputs([[64, 31, 0], [200, 100, 50]], seed=8)
