@@ -115,18 +115,18 @@ static bool desc_ok(const rap_model_desc* d) {
   return true;
 }
 
-extern int g_rap_gemm_variant;   // gemm_f32.hip
-extern int g_rap_gemm_stagger;   // gemm_f32.hip
-extern int g_rap_gemm_splitk;    // gemm_f32.hip
-extern int g_rap_geglu_fast;     // gemm_f32.hip
-extern int g_rap_attn_variant;   // attn_f32.hip
-extern int g_rap_attn_split;     // attn_f32.hip
-extern int g_rap_gemm_h16_variant;   // gemm_h16.hip
-extern int g_rap_attn_h16_variant;   // attn_h16.hip
-int g_rap_fuse_ln = 0;                // tuning key 8: 16-bit path, the next LayerNorm fused into the residual GEMMs' epilogue (1) or as its own kernel (0, default:
+extern rap_tuning_t g_rap_gemm_variant;   // gemm_f32.hip
+extern rap_tuning_t g_rap_gemm_stagger;   // gemm_f32.hip
+extern rap_tuning_t g_rap_gemm_splitk;    // gemm_f32.hip
+extern rap_tuning_t g_rap_geglu_fast;     // gemm_f32.hip
+extern rap_tuning_t g_rap_attn_variant;   // attn_f32.hip
+extern rap_tuning_t g_rap_attn_split;     // attn_f32.hip
+extern rap_tuning_t g_rap_gemm_h16_variant;   // gemm_h16.hip
+extern rap_tuning_t g_rap_attn_h16_variant;   // attn_h16.hip
+rap_tuning_t g_rap_fuse_ln = 0;                // tuning key 8: 16-bit path, the next LayerNorm fused into the residual GEMMs' epilogue (1) or as its own kernel (0, default:
                                       // r02 call 16 -- fused, the 128x512 kernel's epilogue with its three block-wide reductions per row tile costs more (GEMM class
                                       // 918 -> 1057 ms per sample call) than the three HBM-bound LayerNorm launches it removes (100 ms): 106.3k -> 101.6k points/s)
-int g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
+rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 48)) { g_rap_gemm_variant = value; return RAP_OK; }
   if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }

@@ -572,8 +572,8 @@ __global__ void build_attn_worklist_kernel(const int32_t* __restrict__ cu, int n
 // tuning knob (rap_set_tuning key 1): 1 = v1 with 4 waves (256 queries per block, the default: 136 TF at the C1 shapes,
 // profiles/r01_run3_kernel_variant_sweep.jsonl), 5 = v1 with 8 waves + static priority split (512 queries per block,
 // 134 TF), 3 = v3 (one query tile per wave, cross-sub-tile pipelining, 124 TF).
-int g_rap_attn_variant = 1;
-int g_rap_attn_split = 1;     // tuning key 5: 0 = never split few-token calls over key ranges
+rap_tuning_t g_rap_attn_variant = 1;
+rap_tuning_t g_rap_attn_split = 1;     // tuning key 5: 0 = never split few-token calls over key ranges
 static int attn_block_queries() { return g_rap_attn_variant == 5 ? 512 : RAP_ATTN_BQ; }
 
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,

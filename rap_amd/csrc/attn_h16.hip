@@ -878,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_sp2_kernel(const u16* __
 // v_max3 row maximum + deferred rescale); 5 = v1 online softmax even with bounds; 11 = ping-pong schedule (slower, see above); 8 = first v1 (fmaxf chain, rescale
 // every tile); 4 = max3 only; 1..3, 6, 7 = timing-only ablations (bf16 only), see ABL above.
 // 9 = as 0 but the model path keeps q un-scaled (the per-score FMA form, for A/B timing of the pre-scaled default).
-int g_rap_attn_h16_variant = 0;
+rap_tuning_t g_rap_attn_h16_variant = 0;
 
 // the model path asks before it runs qk-norm: pre-scaled q only feeds the default bounded bf16 kernel
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {

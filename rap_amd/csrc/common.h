@@ -6,6 +6,11 @@
 #include <stddef.h>
 
 #define RAP_OK 0
+// rap_set_tuning knobs: process-global A/B switches read on every launch; atomic so that a concurrent rap_set_tuning is a race on
+// the VALUE a launch sees, not undefined behaviour.  Host code only.
+#include <atomic>
+typedef std::atomic<int> rap_tuning_t;
+
 #define RAP_ERR_INVALID (-1)   // bad argument (shape / null / unsupported size)
 #define RAP_ERR_WORKSPACE (-2) // workspace too small
 #define RAP_ERR_HIP (-3)       // HIP runtime error (hipGetLastError recorded)

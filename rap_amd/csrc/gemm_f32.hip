@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(GemmParams p, 
 // 16 = LDS-DMA staged 128x128, 32 = LDS-DMA staged 256x256 (8 waves, one block per CU),
 // 48 = per shape (default, r02): the 256x256 kernel where r01 run 54 measured it faster -- wide outputs at K <= 512 (qkv 111 -> 115 TF,
 // ff1 123 -> 126) -- and the 128x128 kernel elsewhere (out-projection 105 vs 91, ff2 132 vs 127, embedding, head).
-int g_rap_gemm_variant = 48;
+rap_tuning_t g_rap_gemm_variant = 48;
 
 template <int EPI>
 static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int variant) {
@@ -1015,18 +1015,18 @@ static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int var
   }
 }
 
-int g_rap_gemm_splitk = 1;      // tuning key 6: 0 = never split K for few-row calls
-int g_rap_gemm_stagger = 1;     // measured (r01 run 39): +1.3 % on the K = 512 shapes, +1.2 % at K = 2048; 2 (by CU id) is no better
+rap_tuning_t g_rap_gemm_splitk = 1;      // tuning key 6: 0 = never split K for few-row calls
+rap_tuning_t g_rap_gemm_stagger = 1;     // measured (r01 run 39): +1.3 % on the K = 512 shapes, +1.2 % at K = 2048; 2 (by CU id) is no better
 // tuning key 9 (fp32 path): GEGLU's Phi(g).  1 (default since r02 call 50) = Abramowitz-Stegun 7.1.26 erfc, |error| <= 1.5e-7 absolute
 // (about one fp32 ulp of Phi near 1/2), on the packed fp32 pipe, stage-major over eight output pairs (half.h: geglu_pairs) -- the
 // epilogue of the largest GEMM of a layer was ~50 scalar VALU instructions per output with erff: ff1 8.35 -> 8.09 ms (131.7 -> 135.9 TF),
 // headline 15 940 -> 16 049 points/s, all-step deviation from the unmodified reference unchanged (final cloud 5.4e-7 vs 6.6e-7,
 // per-step maximum 9.5e-7 vs 8.3e-7: the fp32 noise floor).  0 = libm-grade erff.
-int g_rap_geglu_fast = 1;
+rap_tuning_t g_rap_geglu_fast = 1;
 int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
   GemmParams p = p_in;
   p.geglu_fast = g_rap_geglu_fast;
-  p.stagger = ((long)((p.M + GBM - 1) / GBM) * (p.N / GBN) >= 1024) ? g_rap_gemm_stagger : 0;     // only when the chip is filled twice over
+  p.stagger = ((long)((p.M + GBM - 1) / GBM) * (p.N / GBN) >= 1024) ? g_rap_gemm_stagger.load() : 0;     // only when the chip is filled twice over
   if (p.M <= 0) return RAP_OK;
   if (p.N % GBN != 0 || p.K % GBK != 0 || p.K <= 0) return RAP_ERR_INVALID;
   if ((p.lda & 3) || (p.ldw & 3)) return RAP_ERR_INVALID;

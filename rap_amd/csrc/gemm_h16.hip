@@ -1258,7 +1258,7 @@ static int launch_ph(hipStream_t stream, const GemmParamsH& p) {
 // (wave tile 128x64), two 64 KB stages (the default); 2 = 256x128 tile, 8 waves (wave tile 64x64); 3 = 256x256 ring of four 32 KB stages,
 // one block per CU; 4 = 256x128 ring (4 waves of 128x64, three 24 KB stages, TWO blocks per CU: one block's epilogue and
 // barrier stalls are covered by the other's k-loop).
-int g_rap_gemm_h16_variant = 14;    // r02 default: phase-split kernel (measured +4 % on ff1 / ff2 over the two-stage 256x256 kernel = 1, equal elsewhere)
+rap_tuning_t g_rap_gemm_h16_variant = 14;    // r02 default: phase-split kernel (measured +4 % on ff1 / ff2 over the two-stage 256x256 kernel = 1, equal elsewhere)
 
 template <int EPI, int DT, int WM, int WN, int TM, int NSTAGE>
 static int launch_ring(hipStream_t stream, const GemmParamsH& p) {
