@@ -340,7 +340,7 @@ int rap_check_batch(const int64_t* points_per_part, const int32_t* cu_batch, int
  * (0 attention per part, 1 attention per sample, 2 layer GEMMs), the summed milliseconds and the launch count
  * into HOST arrays of 3 entries.  Not thread-safe; off by default. */
 int rap_profile_enable(int on);
-/* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py, bench.py --tuning); process-global, not thread-safe, not for a
+/* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py, bench.py --tuning); process-global (atomic values), not for a
  * serving path.  key 0 = fp32 GEMM {0: 128x128 v1, 2: pipelined 128x128, 4: pipelined 128x256, 8: 256x128 8-wave, 16: LDS-DMA staged
  * 128x128, 32: LDS-DMA staged 256x256 8-wave, 48: per shape (default)}; key 1 = fp32 attention {1: 4-wave v1 (default), 3: pipelined,
  * 5: 8-wave v1}; key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave two-stage, 2: 256x128 8-wave, 3/4: ring-buffered, 5: 128x512,
