@@ -346,7 +346,7 @@ int rap_profile_enable(int on);
  * 5: 8-wave v1}; key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave two-stage, 2: 256x128 8-wave, 3/4: ring-buffered, 5: 128x512,
  * 6-8: pipelined rings, 9-12: interleaved issue, 13-15: phase-split (14 = default), 16: persistent two-stage with next-tile prefetch};
  * key 3 = 16-bit attention schedule {0 default, 4/5/8: softmax variants, 9: un-scaled q, 11: ping-pong, 12: software-pipelined (pinned),
- * 13: software-pipelined, two tiles per barrier, 19: persistent blocks, 20: rotated key walk, 23: direct 8-byte output stores (the default stores whole rows through an LDS slab); see attn_h16.hip}; key 4 = fp32 GEMM phase
+ * 13: software-pipelined, two tiles per barrier, 19: persistent blocks, 20: rotated key walk, 23: direct 8-byte output stores (the default stores whole rows through an LDS slab), 24: 512-query blocks of 16 waves; see attn_h16.hip}; key 4 = fp32 GEMM phase
  * stagger {0 off, 1 by block index (default), 2 by CU id}; key 5 = split-KV attention for few-token calls {0 off, 1 on (default)};
  * key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}; key 7 = qk-norm fused into the QKV GEMM
  * epilogue {1 (default)} or as its own kernel {0} (both precisions); key 8 = 16-bit path: the next LayerNorm fused into the epilogue of the

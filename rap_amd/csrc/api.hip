@@ -134,7 +134,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
 #ifdef RAP_ABLATION_BUILD
   if (key == 3 && ((value >= 14 && value <= 18) || value == 21)) { g_rap_attn_h16_variant = value; return RAP_OK; }
 #endif
-  if (key == 3 && ((value >= 0 && value <= 13) || value == 19 || value == 20 || value == 22 || value == 23)) {
+  if (key == 3 && ((value >= 0 && value <= 13) || value == 19 || value == 20 || value == 22 || value == 23 || value == 24)) {
 #ifndef RAP_ABLATION_BUILD
     // 1-3, 6, 7 are timing-only ablations ("NOT attention"): compiled out of the shipped library, refused here
     if (value == 1 || value == 2 || value == 3 || value == 6 || value == 7) return RAP_ERR_INVALID;
@@ -396,7 +396,7 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
                           int B, int nseg_part, int TP) {
   int rc;
   if ((rc = launch_token_sample(stream, cu_batch, B, w.token_sample))) return rc;
-  const int bq = m->dtype == RAP_DT_F32 ? 0 : RAP_ATTN_BQ;
+  const int bq = m->dtype == RAP_DT_F32 ? 0 : attention_h16_block_queries(m->dtype);
   if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch, bq))) return rc;
   if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part, bq))) return rc;
   // base = [PE63(cond) | PE21(scale) | feat | 0] Wstatic^T + emb bias + anchor embedding   (embedding.py:155-179,
@@ -784,7 +784,7 @@ extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16
   const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
-  if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, RAP_ATTN_BQ))) return rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, attention_h16_block_queries(dtype)))) return rc;
   // tuning variant 10 (timing only): treat q as already pre-scaled, i.e. run the kernel the model path runs
   return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound,
                               (g_rap_attn_h16_variant == 10 && logit_bound && dtype == RAP_DT_BF16) ? 1 : 0);

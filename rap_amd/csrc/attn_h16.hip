@@ -65,8 +65,11 @@ extern "C" int rap_debug_attn_ts(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(
 #endif
 // LST (r02, rap_set_tuning(3, 22)): the output tile leaves through the wave's own 4.6 KB slab of the (by then idle) K / V^T buffers and
 // is stored as whole 128-byte rows, 16 bytes per lane, instead of eight 8-byte pieces per lane at a 1 KB row stride.
-template <int DT, int ABL, int OPT, bool PERSIST = false, bool ROT = false, bool LST = false>
-__global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
+// W16 (r02, built at the end of the round, UNMEASURED; rap_set_tuning(3, 24)): 16 waves x 32 queries = 512 queries per block on a work
+// list of 512-query items: the K / V^T stream, its staging instructions and the barrier are shared by twice the matrix work (threads
+// 0-511 stage K, 512-1023 stage V^T: one 16-byte chunk per thread and tile).  Same 4 waves per SIMD, one block per CU.
+template <int DT, int ABL, int OPT, bool PERSIST = false, bool ROT = false, bool LST = false, bool W16 = false>
+__global__ __launch_bounds__(W16 ? 1024 : 512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
                                                                int vt_nblk, u16* __restrict__ out, int TP, int heads,
                                                                const AttnWorkItem* __restrict__ items,
                                                                const float* __restrict__ bound, int total_blocks) {
@@ -120,23 +123,25 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   float mrun = (OPT & 16) ? 0.f : (OPT & 8) ? bound[head] * 8.0f : -1e30f, lsum = 0.f;
   const float c = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e)
 
-  // ---- staging: 512 threads, one 16-byte chunk of K and one of V^T per thread per tile
-  const int srow = tid >> 3, sch = (tid & 7) * 8;
+  // ---- staging: 512 threads, one 16-byte chunk of K and one of V^T per thread per tile (W16: 1024 threads, K or V^T)
+  const int stid = W16 ? (tid & 511) : tid;
+  const bool st_k = !W16 || tid < 512, st_v = !W16 || tid >= 512;
+  const int srow = stid >> 3, sch = (stid & 7) * 8;
   const int b_first = seg0 >> 6;
   const int ntile = ((seg1 - 1) >> 6) - b_first + 1;
   const int soff = srow * HLD + sch;
-  uint4 rk, rv;
+  uint4 rk = make_uint4(0, 0, 0, 0), rv = rk;
 #define HATT_LOAD(T)                                                                                 \
   {                                                                                                  \
     const int blk_ = b_first + (T);                                                                  \
     int tok_ = blk_ * 64 + srow;                                                                     \
     tok_ = tok_ < TP ? tok_ : TP - 1;                                                                \
-    rk = *reinterpret_cast<const uint4*>(Kg + (size_t)tok_ * 64 + sch);                              \
-    rv = *reinterpret_cast<const uint4*>(Vg + ((size_t)blk_ * 64 + srow) * 64 + sch);                \
+    if (st_k) rk = *reinterpret_cast<const uint4*>(Kg + (size_t)tok_ * 64 + sch);                    \
+    if (st_v) rv = *reinterpret_cast<const uint4*>(Vg + ((size_t)blk_ * 64 + srow) * 64 + sch);      \
   }
 #define HATT_STORE(BUF)                                                                              \
-  *reinterpret_cast<uint4*>(Ks + (BUF) * (HKV * HLD) + soff) = rk;                                   \
-  *reinterpret_cast<uint4*>(Vs + (BUF) * (HKV * HLD) + soff) = rv;
+  if (st_k) *reinterpret_cast<uint4*>(Ks + (BUF) * (HKV * HLD) + soff) = rk;                         \
+  if (st_v) *reinterpret_cast<uint4*>(Vs + (BUF) * (HKV * HLD) + soff) = rv;
 
   int rt = ROT ? (int)(((unsigned)it.q0 >> 6) % (unsigned)ntile) : 0;     // rotated tile index of iteration t
   ATT_TS(1)
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   const int q = qw0 + l31;
   const float inv = 1.0f / h_xhalf_sum(lsum);
   if ((ABL & 64) && inv != 12345.678f) continue;    // timing-only: no output stores
+  static_assert(!(LST && W16), "the row-store slabs are sized for 8 waves");
   if (LST) {
     // every wave of the block is past the last tile's barrier: the K / V^T buffers are free.  Slab of this wave: [32 queries][72]
     u16* slab = smem + wave * (32 * HLD);
@@ -880,10 +886,13 @@ __global__ __launch_bounds__(512, 2) void attention_h16_sp2_kernel(const u16* __
 // 9 = as 0 but the model path keeps q un-scaled (the per-score FMA form, for A/B timing of the pre-scaled default).
 rap_tuning_t g_rap_attn_h16_variant = 0;
 
+// work-list granularity of the selected schedule (variant 24: 512-query blocks, bf16 only)
+int attention_h16_block_queries(int dtype) { return (g_rap_attn_h16_variant == 24 && dtype == RAP_DT_BF16) ? 512 : 256; }
+
 // the model path asks before it runs qk-norm: pre-scaled q only feeds the default bounded bf16 kernel
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {
   const int v = g_rap_attn_h16_variant;
-  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10 || v == 12 || v == 13 || v == 19 || v == 20 || v == 22 || v == 23);
+  return dtype == RAP_DT_BF16 && bounded && (v == 0 || v == 9 || v == 10 || v == 12 || v == 13 || v == 19 || v == 20 || v == 22 || v == 23 || v == 24);
 }
 
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
@@ -954,6 +963,14 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
         else if (bound)
           hipLaunchKernelGGL((attention_h16_sp2_kernel<RAP_DT_BF16, 0>), dim3(max_items * heads), dim3(512), SP2_LDS_BYTES, stream, qk, vt, vt_nblk, out, TP, heads, items, bound);
         else HATT_LAUNCH(RAP_DT_BF16, 0, 3);
+        break;
+      }
+      case 24: {                                          // 512-query blocks, 16 waves (the caller built the work list with 512-query items)
+#define HATT_LAUNCH_W(OPTV) \
+  hipLaunchKernelGGL((attention_h16_kernel<RAP_DT_BF16, 0, OPTV, false, false, false, true>), dim3(max_items * heads), dim3(1024), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, max_items * heads)
+        if (bound && q_prescaled) HATT_LAUNCH_W(24);
+        else if (bound) HATT_LAUNCH_W(8);
+        else HATT_LAUNCH_W(3);
         break;
       }
       case 22:                                            // output stored as whole rows through an LDS slab

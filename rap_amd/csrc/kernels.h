@@ -135,6 +135,7 @@ int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t
 int launch_attention_h16(hipStream_t stream, int dtype, const uint16_t* qk, const uint16_t* vt, int vt_nblk, uint16_t* out,
                          int TP, int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled);
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded);
+int attention_h16_block_queries(int dtype);      // work-list granularity of the selected 16-bit attention schedule (256; 512 for variant 24)
 // per-head logit bounds of one attention branch after qk-norm: out[h] = 8 * max_j|gamma_q[h][j]| * max_j|gamma_k[h][j]|
 int launch_qk_logit_bound(hipStream_t stream, const float* gamma_q, const float* gamma_k, int heads, float* out);
 // LayerNorm with 16-bit output (fp32 statistics), same modulation forms as launch_layernorm_*

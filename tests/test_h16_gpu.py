@@ -552,7 +552,7 @@ def test_baseline_geometries_h16_agrees_with_fp32_path(label, batch, views, poin
 
 
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("variant", [5, 11, 12, 13, 19, 20, 23], ids=["online-softmax", "ping-pong", "pipelined-pinned", "pipelined-2-tiles-per-barrier", "persistent-blocks", "rotated-key-walk", "direct-8-byte-stores"])
+@pytest.mark.parametrize("variant", [5, 11, 12, 13, 19, 20, 23, 24], ids=["online-softmax", "ping-pong", "pipelined-pinned", "pipelined-2-tiles-per-barrier", "persistent-blocks", "rotated-key-walk", "direct-8-byte-stores", "blocks-of-512-queries"])
 def test_attention_h16_schedule_variants_agree(lib, dev, dt, variant):
     """rap_set_tuning(3, .) selects alternative schedules of the 16-bit attention (online softmax even when logit bounds are
     given; the ping-pong wave schedule): same function, results within rounding of the default."""
@@ -577,7 +577,7 @@ def test_attention_h16_schedule_variants_agree(lib, dev, dt, variant):
         assert (alt.float() - base.float()).abs().max().item() < 4 * ULP[dt]
 
 
-@pytest.mark.parametrize("variant", [12, 13, 19, 20, 23])
+@pytest.mark.parametrize("variant", [12, 13, 19, 20, 23, 24])
 def test_attention_h16_pipelined_variants_in_the_model_path(dev, variant):
     """the software-pipelined kernels with the pre-scaled q the fused qk-norm epilogue writes (PRE = 1): whole bf16 velocity network
     against the fp32 reference golden, and against the default kernel"""
