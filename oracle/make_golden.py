@@ -27,6 +27,9 @@ CASES = [
     ("l2_emptypart_rigid", 2, [[70, 45, 0], [33, 90, 61]], 11, 1, 3, True),
     ("l12_small_rigid", 12, [[64, 96], [128, 40, 33]], 21, 0, 3, True),
     ("l12_pair512_free", 12, [[512, 512]], 31, 0, 2, False),
+    # the reference's other two model sizes (config/model/flow_model/point_cloud_dit_{10,16}.yaml): rap_10 and rap_16
+    ("l16_small_rigid", 16, [[96, 64], [40, 128, 33]], 41, 2, 3, True),
+    ("l10_small_free", 10, [[80, 80], [150, 30]], 43, 3, 3, False),
 ]
 
 
@@ -37,7 +40,10 @@ def weights_checksum(sd) -> float:
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--case=")]
     for name, L, parts, iseed, wseed, steps, rigid in CASES:
+        if only and name not in only:
+            continue
         cfg = dict(S.RAP_12); cfg["num_layers"] = L
         sd = S.make_weights(cfg, wseed)
         inp = S.make_inputs(parts, seed=iseed)
@@ -335,6 +341,9 @@ if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.endswith("-only")]     # e.g. --overlap-only regenerates one fixture
     if "--headline-only" in only:                               # ~1.5 h of CPU: never part of the default regeneration
         make_headline_goldens(tuple(a[2:] for a in sys.argv[1:] if a[2:] in ("c1_rigid", "c1_free", "c3", "c4")) or ("c1_rigid", "c1_free", "c3", "c4"))
+        sys.exit(0)
+    if any(a.startswith("--case=") for a in sys.argv[1:]):      # only the named sampler fixtures (main() filters)
+        main()
         sys.exit(0)
     if not only:
         main()

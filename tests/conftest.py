@@ -27,3 +27,6 @@ def load_golden(name):
 
 
 GOLDEN_CASES = ["l2_ragged_rigid", "l2_ragged_free", "l2_emptypart_rigid", "l12_small_rigid", "l12_pair512_free"]
+# the reference's other two model sizes (rap_10, rap_16; config/model/flow_model/point_cloud_dit_{10,16}.yaml), fixtures from the unmodified
+# reference like the ones above (oracle/make_golden.py --case=...)
+MODEL_SIZE_CASES = ["l16_small_rigid", "l10_small_free"]

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, load_golden
+from conftest import GOLDEN_CASES, MODEL_SIZE_CASES, load_golden
 from oracle import rap_oracle as O
 from oracle import ref_loader
 from rap_amd import synthetic as S
@@ -19,7 +19,7 @@ def _cfg(g):
     return cfg
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + MODEL_SIZE_CASES)
 def test_oracle_matches_reference_golden(name):
     g, inp = load_golden(name)
     cfg = _cfg(g)

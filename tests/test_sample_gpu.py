@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import rap_amd
-from conftest import GOLDEN_CASES, load_golden
+from conftest import GOLDEN_CASES, MODEL_SIZE_CASES, load_golden
 from oracle import rap_oracle as O
 from rap_amd import synthetic as S
 
@@ -83,6 +83,33 @@ def test_sample_matches_reference_golden(name, dev):
     valid = torch.from_numpy(g["in_points_per_part"]) > 0
     deg = O.rotation_error_deg(R.cpu()[valid], torch.from_numpy(g["R"])[valid]).max().item()
     print(f"{name}: x0 {e0:.2e} xt {e1:.2e} |dR|_F {eR:.2e} dt {et:.2e} rot {deg:.4f} deg")
+
+
+@pytest.mark.parametrize("name", MODEL_SIZE_CASES)
+def test_other_model_sizes_match_reference_golden(name, dev):
+    """rap_16 and rap_10 (the reference's other two shipped model sizes): one forward and the whole sampling call against fixtures
+    written by the unmodified reference, at the STATED tolerances (velocity 1e-4 max|v|, clouds 5e-4, poses 1e-3)."""
+    g, inp = load_golden(name)
+    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev)
+    cu_b, cu_p = O.prepare_cu_seqlens(inp)
+    d = to_dev(inp, dev)
+    out = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
+                local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev), return_transformer_features=True)
+    v_ref = torch.from_numpy(g["fwd_velocity"])
+    ev = (out["velocity"].cpu() - v_ref).abs().max().item()
+    assert ev <= 1e-4 * v_ref.abs().max().item(), ev
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=int(g["num_steps"]), rigidity_forcing=bool(g["rigidity"]))
+    res = flow.sample_rectified_flow(d, None, x_1=d["x_1"])
+    e0 = (res["end_point_trajectory"].cpu() - torch.from_numpy(g["end_point_trajectory"])).abs().max().item()
+    e1 = (res["trajectory"].cpu() - torch.from_numpy(g["trajectory"])).abs().max().item()
+    assert e0 <= 5e-4 and e1 <= 5e-4, (e0, e1)
+    if bool(g["rigidity"]):
+        R, t = flow.last_poses
+        eR = torch.linalg.matrix_norm(R.cpu() - torch.from_numpy(g["R"])).max().item()
+        et = (t.cpu() - torch.from_numpy(g["t"])).abs().max().item()
+        assert eR <= 1e-3 and et <= 1e-3, (eR, et)
+    print(f"{name} (L = {int(g['num_layers'])}): velocity {ev:.2e}  x0 {e0:.2e}  xt {e1:.2e}")
 
 
 def test_sample_matches_oracle_on_fresh_ragged_batch(dev):
