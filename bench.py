@@ -11,12 +11,20 @@ per-view SE(3) recovery) on BASELINE.json configs[1]: 32 scan pairs x 2 views x 
 inputs already resident in HBM.  Multi-GPU: independent pairs shard across ranks (32 pairs per rank, weak
 scaling), one RCCL all-gather of the registered clouds and poses at the end of every step.
 
+`python bench.py --gpus N` WITHOUT torchrun launches the N ranks itself (re-runs this file under `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`), refuses (exit code != 0) when fewer than N GPUs are visible, and every rank
+asserts WORLD_SIZE == --gpus before anything is timed: the line can never report an n_gpus that was not requested.
+
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
   roofline      -- the dominant kernel (attention_f32_kernel): algorithmic FLOPs / HIP-event time, vs the
                    157.3 TFLOP/s fp32 matrix peak of gfx950;
   cpu_baseline  -- the CPU oracle (restatement of the reference, pinned to it) timed on this box's host cores
                    on a bounded sample (1 pair, 1 of 20 flow steps), extrapolated linearly; the one-off measurement of the
                    LIVE reference over all 20 steps of that pair (build container) is cited from profiles/.
+  roofline_online_softmax -- the same dominant kernel in its ONLINE-softmax instantiation, measured on the same batch with the seeded
+                   q/k-norm gains multiplied by --gamma-scale (default 3: every logit bound 8 max|gamma_q| max|gamma_k| > 40, so every
+                   attention launch takes the online kernel): what a trained checkpoint with large gains runs; the kernel is chosen per
+                   (layer, branch) launch, so one hot head costs 1 / (2 * layers) of the difference.
   parity_vs_reference_golden -- pair 0 of the timed batch against tests/golden/headline_c1_*.npz: the unmodified reference's
                    result for that pair over ALL flow steps (final cloud, last x_t, poses, every 32nd point of every step).
 """
@@ -40,16 +48,31 @@ DTYPE_TAG = {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}
 CPU_BASELINE_THREADS = 16
 
 
-def pmc_traffic(dtype="float32"):
+# The template instantiation rap_sample launches per (precision, softmax kind) -- attn_f32.hip: launch_attention_f32,
+# attn_h16.hip: launch_attention_h16 -- as rocprofv3 prints it; the committed PMC traffic numbers are used only for the symbol they
+# were measured on.
+SHIPPED_ATTENTION_SYMBOL = {
+    ("float32", True): "attention_f32_kernel<4, true, false>", ("float32", False): "attention_f32_kernel<4, false, false>",
+    ("bfloat16", True): "attention_h16_kernel<1, 0, 24, false, false, true, false>",
+    ("bfloat16", False): "attention_h16_kernel<1, 0, 3, false, false, true, false>",
+    ("float16", True): "attention_h16_kernel<2, 0, 3, false, false, true, false>",
+    ("float16", False): "attention_h16_kernel<2, 0, 3, false, false, true, false>",
+}
+
+
+def pmc_traffic(dtype, symbol):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside this
-    process; the passes are separate runs of scripts/kernel_bench.py, summarised in profiles/)."""
+    process; the passes are separate runs of scripts/kernel_bench.py, summarised in profiles/).  Returned only when the passes
+    measured the instantiation this run timed (`kernel_symbol` in the JSON); otherwise (None, reason)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if dtype == "float32" else "pmc_traffic_h16.json")
     try:
         with open(path) as f:
             j = json.load(f)
+        if j.get("kernel_symbol") != symbol:
+            return None, f"no PMC pass for {symbol} (profiles/ holds {j.get('kernel_symbol')})"
         return j["hbm_bytes_per_launch"], j["source"]
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None, "no PMC summary under profiles/"
 
 
 def parse_args():
@@ -70,6 +93,9 @@ def parse_args():
                          "bfloat16 = the per-GPU shard of configs[2]; float16 = the reference's shipped GPU precision")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="rap_set_tuning(KEY, VALUE) before the run (A/B experiments; recorded in config.tuning)")
+    ap.add_argument("--gamma-scale", type=float, default=3.0,
+                    help="multiplier on the seeded q/k-norm gains for the extra 'roofline_online_softmax' leg (1 warm-up + 2 timed sample "
+                         "calls per precision; 0 = skip the leg)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra bf16 measurement of the same workload that a float32 run appends as 'reduced_precision'")
     return ap.parse_args()
@@ -135,7 +161,7 @@ def golden_parity(args, last, data):
 def reference_cpu_record():
     """The committed one-off timing of the LIVE reference on all 20 steps of one pair (build container, profiles/)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_cpu_reference_headline.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_cpu_reference_headline.json")) as f:      # the c1 fixtures were made in round 2
             j = json.load(f)["headline_c1_rigid"]
         return {"points_per_s": j["points_per_s"], "seconds": j["seconds"], "threads": j["threads"],
                 "what": "unmodified reference modules, all 20 flow steps of one 2x4096 pair, CPU of the build container "
@@ -144,8 +170,62 @@ def reference_cpu_record():
         return None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: launch the N ranks ourselves -- the whole command a driver needs.
+    Fails hard when the box has fewer than N GPUs instead of quietly timing one."""
+    import socket
+    import subprocess
+    selftest = os.environ.get("RAP_BENCH_LAUNCHER_SELFTEST") == "1"
+    if not selftest:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} requested but {n_dev} GPU(s) visible; refusing to run fewer ranks than requested")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launcher_selftest(args, world, rank, json_out):
+    """RAP_BENCH_LAUNCHER_SELFTEST=1 (tests/test_parallel_cpu.py only): the launch / rendezvous / shard / gather / timing / JSON
+    plumbing of this file on CPU ranks with the gloo backend and a STUB in place of the sampler (rap_amd has no CPU path).  The
+    line it prints is labelled as such and carries no throughput claim."""
+    import torch.distributed as dist
+    from rap_amd.parallel import gather_registrations, shard_range
+    dist.init_process_group(backend="gloo")
+    assert dist.get_world_size() == args.gpus == world
+    mine = shard_range(args.batch * world, world, rank)
+    assert (mine.start, mine.stop) == (rank * args.batch, (rank + 1) * args.batch)
+    n = args.batch * args.views * args.points
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        final = torch.full((n, 3), float(rank)); R = torch.eye(3).repeat(args.batch, args.views, 1, 1) * (rank + 1)
+        t = torch.full((args.batch, args.views, 3), float(rank))
+        g = gather_registrations(final, R, t, equal_shapes=True)
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    allt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(allt, elapsed)
+    ok = all(bool((g[0][r * n:(r + 1) * n] == float(r)).all()) for r in range(world)) and g[0].shape[0] == n * world
+    if rank == 0:
+        print(json.dumps({"metric": "launcher-selftest (stub sampler, gloo, CPU): NOT a measurement", "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "stub": True, "rccl_ranks": world, "pairs_total": args.batch * world,
+                          "gather_ok": ok, "per_rank": {"elapsed_s": [float(x) for x in allt]}}), file=json_out, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     # stdout carries exactly ONE line, the JSON result: RCCL prints a version banner to fd 1 when the first communicator is
     # created, so everything else this process (or a library in it) writes to fd 1 is sent to stderr instead.
     sys.stdout.flush()
@@ -156,15 +236,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # RAP_BENCH_FORCE_DIST=1: take the torch.distributed / RCCL path with a single rank too (exercises it on a 1-GPU box)
     distributed = world > 1 or os.environ.get("RAP_BENCH_FORCE_DIST") == "1"
-    if args.gpus != world and distributed:
+    if args.gpus != world:                                  # in EVERY mode: never time a rank count that was not requested
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("RAP_BENCH_LAUNCHER_SELFTEST") == "1":
+        return launcher_selftest(args, world, rank, json_out)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (rap_amd has no CPU path)")
+    if torch.cuda.device_count() < (world if distributed and world > 1 else 1) or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} / WORLD_SIZE {world} but {torch.cuda.device_count()} GPU(s) visible "
+                         "(one rank per GPU; RCCL refuses two ranks on one device)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     import rap_amd
     from rap_amd import _lib, synthetic as S
@@ -191,13 +278,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_mode(dtype, steps, warmup):
+    def scaled_gains(scale):
+        """seeded weights with every MultiHeadRMSNorm gain (flow_model/norm.py:15-33) multiplied by `scale`"""
+        if scale == 1.0:
+            return sd
+        return {k: (v * scale if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma") else v) for k, v in sd.items()}
+
+    def run_mode(dtype, steps, warmup, gamma_scale=1.0):
         """W untimed + K timed sample calls with the transformer blocks in `dtype`; returns (elapsed, prof, last, flow)."""
         model = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
                                       num_heads=cfg["num_heads"], local_feat_dim=cfg["local_feat_dim"],
                                       attn_dtype=dtype, compute_dtype=dtype)
-        model.load_state_dict(sd)
+        model.load_state_dict(scaled_gains(gamma_scale))
         model.to(dev)
+        run_mode.bounded_launches = lib.rap_model_bounded_attention_launches(model._handle)
         flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=args.flow_steps,
                                           rigidity_forcing=bool(args.rigidity))
 
@@ -220,7 +314,7 @@ def main():
         for _ in range(warmup):
             one_step()
         barrier()
-        # With concurrent batch shards (16-bit default: two streams) a kernel's event-to-event time includes the other shard's
+        # With concurrent batch shards (opt-in: RAP_NUM_STREAMS > 1; the default is one stream) a kernel's event-to-event time includes the other shard's
         # kernels sharing the GPU, so the roofline of the dominant kernel is taken from ONE extra single-stream step after the timed
         # region (the kernel alone, as for fp32); the timed K steps run unprofiled.
         profile_inline = profile and n_streams == 1
@@ -247,13 +341,14 @@ def main():
         prof_ms = (ctypes.c_float * 3)(); prof_n = (ctypes.c_int64 * 3)()
         run_mode.prof_region_s = elapsed                              # wall time of the region the profile covers
         if profile and not profile_inline:
+            prev_streams = flow.num_streams
             flow.num_streams = 1
             one_step(); torch.cuda.synchronize()                      # new workspace / allocator warm-up of the one-stream shape
             lib.rap_profile_reset(); lib.rap_profile_enable(1)
             tp0 = time.perf_counter()
             one_step(); torch.cuda.synchronize()
             run_mode.prof_region_s = time.perf_counter() - tp0
-            flow.num_streams = None
+            flow.num_streams = prev_streams
         if profile:
             lib.rap_profile_enable(0)
             _lib.check(lib.rap_profile_collect(prof_ms, prof_n), "rap_profile_collect")
@@ -263,7 +358,7 @@ def main():
             elapsed = float(tmax.item())
         return elapsed, (list(prof_ms), list(prof_n)), last
 
-    def roofline_of(dtype, prof, elapsed):
+    def roofline_of(dtype, prof, elapsed, bounded=True):
         prof_ms, prof_n = prof
         if not (profile and prof_n[0] > 0 and prof_n[1] > 0):
             return None
@@ -274,9 +369,12 @@ def main():
         secs = (prof_ms[0] + prof_ms[1]) * 1e-3
         achieved = flops / secs / 1e12
         elem = 4 if dtype == "float32" else 2
-        traffic, source = pmc_traffic(dtype)
+        symbol = SHIPPED_ATTENTION_SYMBOL[(dtype, bool(bounded))]
+        traffic, source = pmc_traffic(dtype, symbol)
         return {
-            "kernel": "attention_f32_kernel" if dtype == "float32" else "attention_h16_kernel", "bound": "mfma",
+            "kernel": "attention_f32_kernel" if dtype == "float32" else "attention_h16_kernel", "kernel_symbol": symbol,
+            "softmax": "bounded, offset-free (every logit bound <= 40)" if bounded and dtype != "float16" else "online (running maximum)",
+            "bound": "mfma",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": source,
             "algorithmic_bytes_per_launch": 4 * elem * args.batch * args.views * args.points * 512,
@@ -297,6 +395,10 @@ def main():
     elapsed, prof, last = run_mode(args.dtype, args.steps, args.warmup)
     host_enqueue_ms = run_mode.host_enqueue_ms
     prof_region_s, main_streams = run_mode.prof_region_s, run_mode.streams
+    main_bounded = run_mode.bounded_launches
+    main_rank_elapsed, main_gather_ms = list(run_mode.rank_elapsed), run_mode.gather_ms
+    if main_bounded != 2 * args.layers:
+        raise SystemExit(f"seeded weights: {main_bounded} of {2 * args.layers} attention launches bounded -- the headline expects all")
     secondary = None
     if args.dtype == "float32" and not args.no_secondary:
         # the same workload with bf16 MFMA blocks (BASELINE configs[2]'s per-GPU shard), reported beside the fp32 headline
@@ -307,6 +409,7 @@ def main():
             "host_call_ms_per_step": run_mode.host_enqueue_ms,
             "workload": "same batch, bf16 MFMA transformer blocks (fp32 accumulate / residual / LN / softmax / head)",
             "roofline": roofline_of("bfloat16", p2, run_mode.prof_region_s), "streams": run_mode.streams,
+            "bounded_attention_launches": f"{run_mode.bounded_launches} of {2 * args.layers}",
             "deviation_from_fp32_path": {"final_cloud_max_abs": float((a - b).abs().max()),
                                          "R_frob_max": float(torch.linalg.matrix_norm(l2["R"] - last["R"]).max()),
                                          "t_max_abs": float((l2["t"] - last["t"]).abs().max())}}
@@ -314,6 +417,40 @@ def main():
         if gp2:
             secondary["deviation_from_reference_golden"] = {k: gp2[k] for k in ("final_cloud_max_abs", "R_frob_max", "t_max_abs")}
         del l2
+
+    # ---- the online-softmax instantiation of the dominant kernel: same batch, q/k-norm gains x gamma_scale (every bound > 40)
+    online = None
+    if args.gamma_scale and args.gamma_scale != 1.0 and profile and world == 1:
+        online = {"gamma_scale": args.gamma_scale,
+                  "what": "same batch, MultiHeadRMSNorm gains of the seeded weights multiplied by gamma_scale: every logit bound "
+                          "8 max|gamma_q| max|gamma_k| exceeds 40, so every attention launch takes the online-softmax kernel "
+                          "(what a trained checkpoint with large gains runs); 1 warm-up + 2 timed sample calls"}
+        for dt_name in ([args.dtype] if (args.dtype != "float32" or args.no_secondary) else ["float32", "bfloat16"]):
+            eo, po, lo = run_mode(dt_name, 2, 1, gamma_scale=args.gamma_scale)
+            ro = roofline_of(dt_name, po, run_mode.prof_region_s, bounded=False)
+            if run_mode.bounded_launches != 0:
+                raise SystemExit(f"gamma scale {args.gamma_scale}: {run_mode.bounded_launches} launches still bounded")
+            if ro:
+                ro["points_per_s"] = pts_per_rank * 2 / eo
+                ro["ms_per_step"] = 1e3 * eo / 2
+            online[DTYPE_TAG[dt_name]] = ro
+            if dt_name == args.dtype and rank == 0 and not args.no_cpu_baseline:
+                # parity of the online path: pair 0, first flow step, vs the CPU oracle run with the same scaled gains
+                from oracle import rap_oracle as O
+                torch.set_num_threads(min(CPU_BASELINE_THREADS, os.cpu_count() or 1))
+                small = S.make_uniform_inputs(1, args.views, min(args.points, 1024), seed=1234)
+                ref = O.sample(scaled_gains(args.gamma_scale), cfg, small, args.flow_steps, bool(args.rigidity), max_steps=1)
+                m2 = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
+                                           num_heads=cfg["num_heads"], local_feat_dim=cfg["local_feat_dim"], attn_dtype=dt_name,
+                                           compute_dtype=dt_name)
+                m2.load_state_dict(scaled_gains(args.gamma_scale)); m2.to(dev)
+                f2 = rap_amd.RectifiedPointFlow(flow_model=m2, inference_sampling_steps=args.flow_steps, rigidity_forcing=bool(args.rigidity))
+                o2 = f2.sample_and_register({k: v.to(dev) for k, v in small.items()}, x_1=small["x_1"].to(dev))
+                online["parity_vs_cpu_oracle"] = {
+                    "workload": f"1 pair x {args.views} x {min(args.points, 1024)} points, first of {args.flow_steps} flow steps, {dt_name}",
+                    "x0_max_abs": float((o2["end_point_trajectory"][0].cpu() - ref["end_point_trajectory"][0]).abs().max())}
+                del m2, f2, o2
+            del lo
 
     result = None
     if rank == 0:
@@ -337,9 +474,13 @@ def main():
         # host time spent INSIDE the sample call: ~3 300 launches at ~2.6 us each while the HIP queue has room (8.5 ms for a
         # single call), the GPU's own pace once the queue is full (the driver's 20-step run: the call blocks on queue slots)
         result["host_call_ms_per_step"] = host_enqueue_ms
+        result["rccl_ranks"] = world if distributed else 0        # ranks in the RCCL process group (0: single process, no group)
+        result["pairs_total"] = args.batch * world
+        result["bounded_attention_launches"] = f"{main_bounded} of {2 * args.layers}"
         if distributed:
-            result["per_rank"] = {"elapsed_s": run_mode.rank_elapsed, "all_gather_ms_per_step": run_mode.gather_ms,
+            result["per_rank"] = {"elapsed_s": main_rank_elapsed, "all_gather_ms_per_step": main_gather_ms,
                                   "note": "elapsed_s = each rank's own K steps before the closing barrier; value uses the max"}
+            result["all_gather_ms_per_step"] = main_gather_ms
         roof = roofline_of(args.dtype, prof, prof_region_s)
         result["streams"] = main_streams
         if roof:
@@ -347,6 +488,8 @@ def main():
         if secondary:
             secondary["speedup_vs_fp32_path"] = secondary["value"] / value
             result["reduced_precision"] = secondary
+        if online:
+            result["roofline_online_softmax"] = online
         if world == 1 and not args.no_cpu_baseline:
             n0 = args.views * args.points
             x0_first = last["end_point_trajectory"][0][:n0]
@@ -358,7 +501,7 @@ def main():
                 base["live_reference_all_steps"] = rec
             result["cpu_baseline"] = base
             result["se3_vs_cpu_oracle"] = err
-            result["speedup_vs_cpu_baseline"] = value / base["value"]
+            base["gpu_over_cpu_port_extrapolated"] = value / base["value"]     # context only (port, 1 of 20 steps, extrapolated): never a headline
         gp = golden_parity(args, last, data) if args.dtype == "float32" else None
         if gp:
             result["parity_vs_reference_golden"] = gp

@@ -61,6 +61,11 @@ void rap_model_destroy(rap_model* m);
  * fills the 16-bit weight copies.  rap_workspace_bytes depends on the current dtype. */
 int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* stream);
 int rap_model_compute_dtype(const rap_model* m);
+/* How many of the model's 2 * num_layers attention launches (layer x {per part, per sample}) take the bounded, offset-free softmax
+ * kernel: a launch does when every head of THAT attention has 8 max|gamma_q| max|gamma_k| <= 40 (MultiHeadRMSNorm gains,
+ * flow_model/norm.py:15-33); the others take the online-softmax kernel.  Decided per launch, so one hot head of a trained checkpoint
+ * costs one (layer, branch) the faster kernel, not the model.  Returns < 0 for a NULL model. */
+int rap_model_bounded_attention_launches(const rap_model* m);
 
 /* Bytes of caller-provided workspace for one call on a batch of TP points, B samples, `nseg_part`
  * part segments (B*P for rap_sample, VP for rap_dit_forward) and `rows` adaLN rows
@@ -276,15 +281,6 @@ int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda
 int rap_gemm_h16_qkvnorm(int32_t dtype, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, uint16_t* qk_out, int32_t M,
                          int32_t K, int32_t heads, const float* gamma_q, const float* gamma_k, float q_mul, uint16_t* vt,
                          int32_t vt_nblk, void* stream);
-/* A residual GEMM with the NEXT LayerNorm fused into its epilogue -- what rap_sample / rap_dit_forward run for the out-projections
- * and the FFN down-projection in the 16-bit modes when tuning key 8 = 1 (default 0 = GEMM + rap_layernorm_*_h16, measured faster):
- *   h (M,512) fp32 += A (M,K) W (512,K)^T + bias          (in place: the residual stream)
- *   xn_out (M,512) half = LayerNorm(h_new, eps 1e-5) * (add_one + gain[row]) + shift[row]
- * gain / shift rows as in rap_layernorm_mod_h16 (row = token_row[m] * row_stride, or 0) -- adaLN (norm.py:74-76, add_one = 1) or the
- * affine ff_norm (layer.py:163, add_one = 0).  N is fixed at 512 (one 128 x 512 tile holds whole rows); K % 64 == 0. */
-int rap_gemm_h16_resid_ln(int32_t dtype, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, float* h, int32_t ldh, int32_t M,
-                          int32_t K, const float* bias, uint16_t* xn_out, const float* gain, const float* shift, int64_t row_stride,
-                          const int32_t* token_row, int32_t add_one, void* stream);
 int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk, const int32_t* cu_seqlens,
                       int32_t nseg, uint16_t* out, int64_t TP, int32_t heads, const float* logit_bound, void* ws,
                       size_t ws_bytes, void* stream);
@@ -340,18 +336,14 @@ int rap_check_batch(const int64_t* points_per_part, const int32_t* cu_batch, int
  * (0 attention per part, 1 attention per sample, 2 layer GEMMs), the summed milliseconds and the launch count
  * into HOST arrays of 3 entries.  Not thread-safe; off by default. */
 int rap_profile_enable(int on);
-/* Kernel-variant knob for A/B measurements (scripts/kernel_bench.py, bench.py --tuning); process-global (atomic values), not for a
- * serving path.  key 0 = fp32 GEMM {0: 128x128 v1, 2: pipelined 128x128, 4: pipelined 128x256, 8: 256x128 8-wave, 16: LDS-DMA staged
- * 128x128, 32: LDS-DMA staged 256x256 8-wave, 48: per shape (default)}; key 1 = fp32 attention {1: 4-wave v1 (default), 3: pipelined,
- * 5: 8-wave v1}; key 2 = 16-bit GEMM {0: 128x128, 1: 256x256 8-wave two-stage, 2: 256x128 8-wave, 3/4: ring-buffered, 5: 128x512,
- * 6-8: pipelined rings, 9-12: interleaved issue, 13-15: phase-split (14 = default), 16: persistent two-stage with next-tile prefetch};
- * key 3 = 16-bit attention schedule {0 default, 4/5/8: softmax variants, 9: un-scaled q, 11: ping-pong, 12: software-pipelined (pinned),
- * 13: software-pipelined, two tiles per barrier, 19: persistent blocks, 20: rotated key walk, 23: direct 8-byte output stores (the default stores whole rows through an LDS slab), 24: 512-query blocks of 16 waves; see attn_h16.hip}; key 4 = fp32 GEMM phase
- * stagger {0 off, 1 by block index (default), 2 by CU id}; key 5 = split-KV attention for few-token calls {0 off, 1 on (default)};
- * key 6 = split-K of the fp32 bias + residual GEMM for few-row calls {0 off, 1 on (default)}; key 7 = qk-norm fused into the QKV GEMM
- * epilogue {1 (default)} or as its own kernel {0} (both precisions); key 8 = 16-bit path: the next LayerNorm fused into the epilogue of the
- * residual GEMMs {1} or as its own kernel {0 (default: measured faster)}; key 9 = fp32 GEGLU epilogue {1 (default): erfc to 1.5e-7 on the
- * packed fp32 pipe, 0: erff}.  All variants compute the same function (key 9: to within 1.5e-7 of Phi). */
+/* Production switches between two SHIPPED code paths that compute the same function (process-global, atomic; not per model):
+ *   key 5  split-KV attention for few-token calls        {0 off, 1 on (default)}       fp32 path
+ *   key 6  split-K of the bias + residual GEMM, few rows  {0 off, 1 on (default)}       fp32 path
+ *   key 7  qk-norm fused into the QKV GEMM epilogue       {1 (default), 0 = own kernel} both precisions
+ *   key 9  GEGLU's Phi                                    {1 (default): erfc polynomial, |error| <= 1.5e-7; 0: erff}   fp32 path
+ *   key 10 ff1 -> GEGLU -> ff2 as ONE kernel              {1 (default), 0 = two GEMMs}  16-bit path
+ * Any other key returns RAP_ERR_INVALID.  (Keys 0-4 selected among the kernel variants of the round-1/2 experiments; those variants
+ * are no longer in the tree, and what is left of the switch exists only in a library built with -DRAP_ABLATION_BUILD.) */
 int rap_set_tuning(int32_t key, int32_t value);
 int rap_profile_reset(void);
 int rap_profile_collect(float* h_ms_out, int64_t* h_count_out);

@@ -64,6 +64,8 @@ def main():
             "fwd_features": fw["transformer_features"].numpy(),
             "end_point_trajectory": ref["end_point_trajectory"].numpy(), "trajectory": ref["trajectory"].numpy(),
             "R": ref["R"].numpy(), "t": ref["t"].numpy(),
+            # transformer_features captured by the sampling call itself (modeling.py:678-695: model call steps-1, t = dt)
+            "sample_features": ref["transformer_features"].numpy(), "sample_features_timestep": np.float64(ref["features_timestep"]),
         }
         for k, v in inp.items():
             out["in_" + k] = v.numpy()
@@ -266,7 +268,12 @@ def _traj_summary(ref, stride):
     per-step max-norms of both trajectories and every `stride`-th point of every step (so error growth over the re-noised
     steps can be checked step by step without storing S x TP x 3 floats)."""
     ep, tr = ref["end_point_trajectory"], ref["trajectory"]
-    return {"final_end_point": ep[-1].numpy(), "final_x_t": tr[-1].numpy(), "R": ref["R"].numpy(), "t": ref["t"].numpy(),
+    extra = {}
+    if ref.get("transformer_features") is not None:            # last-call features of the sampling call, every `stride`-th token
+        extra = {"sample_features_strided": ref["transformer_features"][::stride].numpy(),
+                 "sample_features_max": np.float64(ref["transformer_features"].abs().max()),
+                 "sample_features_timestep": np.float64(ref["features_timestep"])}
+    return {**extra, "final_end_point": ep[-1].numpy(), "final_x_t": tr[-1].numpy(), "R": ref["R"].numpy(), "t": ref["t"].numpy(),
             "end_point_step_max": ep.abs().amax(dim=(1, 2)).numpy(), "x_t_step_max": tr.abs().amax(dim=(1, 2)).numpy(),
             "stride": np.int64(stride), "end_point_strided": ep[:, ::stride].numpy(), "x_t_strided": tr[:, ::stride].numpy()}
 
@@ -286,16 +293,22 @@ def make_headline_goldens(which=("c1_rigid", "c1_free", "c3", "c4")):
     cfg = dict(S.RAP_12)
     sd = S.make_weights(cfg, 0)
     jobs = {"c1_rigid": ("headline_c1_rigid", 2, 4096, 20, True, 32), "c1_free": ("headline_c1_free", 2, 4096, 20, False, 32),
-            "c3": ("headline_c3_rigid", 8, 2048, 30, True, 64)}
+            "c3": ("headline_c3_rigid", 8, 2048, 30, True, 64),
+            # round 3: configs[4] geometry through ALL 12 layers and two re-noised flow steps with rigidity
+            # forcing (attention at L = 65 536), and the first pair of RANK 1 of the configs[2] job (bench.py: rank r owns
+            # samples [32 r, 32 r + 32), sample b is seeded 1234 + b)
+            "c4_steps": ("headline_c4_steps", 2, 32768, 2, True, 64, 1234),
+            "c2_rank1": ("headline_c2_rank1", 2, 4096, 20, True, 32, 1234 + 32)}
     for key in which:
         if key not in jobs:
             continue
-        name, views, points, steps, rigid, stride = jobs[key]
-        inp = S.make_uniform_inputs(1, views, points, seed=1234)
+        name, views, points, steps, rigid, stride = jobs[key][:6]
+        iseed = jobs[key][6] if len(jobs[key]) > 6 else 1234
+        inp = S.make_uniform_inputs(1, views, points, seed=iseed)
         t0 = time.perf_counter()
         ref = ref_loader.reference_sample(cfg, sd, inp, steps, rigid)
         dt = time.perf_counter() - t0
-        out = {"num_layers": np.int64(12), "weight_seed": np.int64(0), "input_seed": np.int64(1234), "views": np.int64(views),
+        out = {"num_layers": np.int64(12), "weight_seed": np.int64(0), "input_seed": np.int64(iseed), "views": np.int64(views),
                "points": np.int64(points), "num_steps": np.int64(steps), "rigidity": np.int64(int(rigid)),
                "weights_checksum": np.float64(weights_checksum(sd)), "reference_seconds": np.float64(dt),
                "reference_threads": np.int64(torch.get_num_threads())}
@@ -326,7 +339,7 @@ def make_headline_goldens(which=("c1_rigid", "c1_free", "c3", "c4")):
                             velocity=v.numpy(), reference_seconds=np.float64(dt))
         timings["headline_c4_forward"] = {"seconds": dt, "threads": torch.get_num_threads(), "points": 65536, "layers": 2}
         print("headline_c4_forward", os.path.getsize(path) // 1024, "KiB", f"{dt:.1f} s", flush=True)
-    prof = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "profiles", "r02_cpu_reference_headline.json")
+    prof = os.path.join(os.path.dirname(GOLDEN_DIR), "..", "profiles", os.environ.get("RAP_GOLDEN_TIMINGS", "r03_cpu_reference_headline.json"))
     prof = os.path.normpath(prof)
     old = {}
     if os.path.exists(prof):
@@ -340,7 +353,7 @@ def make_headline_goldens(which=("c1_rigid", "c1_free", "c3", "c4")):
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.endswith("-only")]     # e.g. --overlap-only regenerates one fixture
     if "--headline-only" in only:                               # ~1.5 h of CPU: never part of the default regeneration
-        make_headline_goldens(tuple(a[2:] for a in sys.argv[1:] if a[2:] in ("c1_rigid", "c1_free", "c3", "c4")) or ("c1_rigid", "c1_free", "c3", "c4"))
+        make_headline_goldens(tuple(a[2:] for a in sys.argv[1:] if a[2:] in ("c1_rigid", "c1_free", "c3", "c4", "c4_steps", "c2_rank1")) or ("c1_rigid", "c1_free", "c3", "c4"))
         sys.exit(0)
     if any(a.startswith("--case=") for a in sys.argv[1:]):      # only the named sampler fixtures (main() filters)
         main()

@@ -20,7 +20,7 @@ install.sh:19) and diffusers 0.33.0 ``FeedForward("geglu")`` / ``Timesteps`` /
 ``TimestepEmbedding`` (install.sh:9) -- those two are "parity unpinned" (the
 reference ships no test for them).
 
-Pinning: ``tests/test_oracle_vs_reference.py`` executes the reference's own
+Pinning: ``tests/test_oracle.py`` executes the reference's own
 unmodified modules (``oracle/ref_loader.py``) on the same inputs and requires
 agreement to fp32 round-off; ``tests/golden/*.npz`` were produced by the
 reference's modules (``oracle/make_golden.py``) and are checked against this
@@ -303,8 +303,19 @@ def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.
     cu_batch, cu_part = prepare_cu_seqlens(inputs)
     B = cu_batch.shape[0] - 1
 
+    # feature capture of the sampling call (modeling.py:666-708): the model call with index num_steps - 1 (or the first one with
+    # t < 1e-6) runs with return_transformer_features=True; earlier calls count up
+    captured = {"features": None}
+    call_count = [0]
+
     def fn(x, t):
         ts = torch.full((B,), t, dtype=dtype)                                  # modeling.py:674
+        is_last_call = (t < 1e-6) or (call_count[0] >= num_steps - 1)          # modeling.py:678
+        if is_last_call and captured["features"] is None:                      # modeling.py:680-695
+            r = dit_forward(sd, cfg, x, ts, cond, feats, scales, anchor, cu_batch, cu_part, return_transformer_features=True)
+            captured["features"] = r["transformer_features"]
+            return r["velocity"]
+        call_count[0] += 1                                                     # modeling.py:697
         return dit_forward(sd, cfg, x, ts, cond, feats, scales, anchor, cu_batch, cu_part)
 
     if max_steps is None:
@@ -324,7 +335,8 @@ def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.
             traj_xt[step] = x_t
         res = {"end_point_trajectory": traj, "trajectory": traj_xt}
     R, t = fit_transformations(cond, res["end_point_trajectory"][-1], ppp, cu_batch)
-    return {"end_point_trajectory": res["end_point_trajectory"], "trajectory": res["trajectory"], "R": R, "t": t}
+    return {"end_point_trajectory": res["end_point_trajectory"], "trajectory": res["trajectory"], "R": R, "t": t,
+            "transformer_features": captured["features"]}     # None when max_steps stops before the capturing call
 
 
 # ----------------------------------------------------------------------------

@@ -3,7 +3,7 @@
 Only usable inside the build container where ``/root/reference`` is mounted
 (the GPU box has no such path; nothing in ``-m gpu`` tests, ``smoke()`` or
 ``bench.py`` calls this).  It is used by ``oracle/make_golden.py`` to produce
-the fixtures under ``tests/golden/`` and by ``tests/test_oracle_vs_reference.py``
+the fixtures under ``tests/golden/`` and by ``tests/test_oracle.py``
 to pin ``oracle/rap_oracle.py`` (the restatement that travels) against the
 reference's own source.
 
@@ -419,7 +419,9 @@ def build_reference_dit(cfg, state_dict, dtype=torch.float32):
 
 def reference_sample(cfg, state_dict, inputs, num_steps, rigidity_forcing, dtype=torch.float32):
     """Restates only the 30-line closure of modeling.py:659-722 around the reference's own
-    get_sampler / PointCloudDiT / procrustes (modeling.py itself needs lightning)."""
+    get_sampler / PointCloudDiT / procrustes (modeling.py itself needs lightning), INCLUDING its feature capture
+    (modeling.py:666-708): the call with index num_steps - 1 (or the first one with t < 1e-6) runs the model with
+    return_transformer_features=True and keeps `transformer_features`; earlier calls count up."""
     ns = load_reference()
     model = build_reference_dit(cfg, state_dict, dtype)
     cond = inputs["pointclouds"].to(dtype)
@@ -432,17 +434,28 @@ def reference_sample(cfg, state_dict, inputs, num_steps, rigidity_forcing, dtype
     cu_part = F.pad(torch.cumsum(ppp[valid], 0), (1, 0)).to(torch.int32)   # modeling.py:219-222
     cu_batch = inputs["cu_seqlens"].to(torch.int32)                          # modeling.py:223
     B = cu_batch.shape[0] - 1
+    captured = {"features": None, "t": None}
+    call_count = [0]                                                         # modeling.py:668
 
     @torch.inference_mode()
     def run():
         def fn(x, t):                                                        # modeling.py:672-708
             ts = torch.full((B,), t, dtype=dtype)
-            return model(x=x, timesteps=ts, cond_coord=cond, local_features=feats, latent_features=None,
-                         scales=scales, anchor_indices=anchor, cu_seqlens_batch=cu_batch, cu_seqlens_part=cu_part)
+            kw = dict(x=x, timesteps=ts, cond_coord=cond, local_features=feats, latent_features=None, scales=scales,
+                      anchor_indices=anchor, cu_seqlens_batch=cu_batch, cu_seqlens_part=cu_part)
+            is_last_call = (t < 1e-6) or (call_count[0] >= num_steps - 1)    # modeling.py:678
+            if is_last_call and captured["features"] is None:                # modeling.py:680-695
+                result = model(return_transformer_features=True, **kw)
+                captured["features"] = result["transformer_features"]
+                captured["t"] = float(t)
+                return result["velocity"]
+            call_count[0] += 1                                               # modeling.py:697
+            return model(**kw)
         res = ns.get_sampler("euler")(flow_model_fn=fn, x_1=x_1, x_0=cond, condition=cond, points_per_part=ppp,
                                       cu_seqlens_batch=cu_batch, anchor_indices=anchor, num_steps=num_steps,
                                       return_trajectory=True, rigidity_forcing=rigidity_forcing)
         R, t = ns.fit_transformations(cond, res["end_point_trajectory"][-1], ppp, cu_batch)  # modeling.py:389-391
         return res, R, t
     res, R, t = run()
-    return {"end_point_trajectory": res["end_point_trajectory"], "trajectory": res["trajectory"], "R": R, "t": t}
+    return {"end_point_trajectory": res["end_point_trajectory"], "trajectory": res["trajectory"], "R": R, "t": t,
+            "transformer_features": captured["features"], "features_timestep": captured["t"]}

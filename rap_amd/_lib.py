@@ -36,6 +36,7 @@ SIGNATURES = {
     "rap_model_destroy": (None, [_P]),
     "rap_model_set_compute_dtype": (c_int32, [_P, c_int32, _P]),
     "rap_model_compute_dtype": (c_int32, [_P]),
+    "rap_model_bounded_attention_launches": (c_int32, [_P]),
     "rap_workspace_bytes": (c_size_t, [_P, c_int64, c_int32, c_int32, c_int32]),
     "rap_dit_forward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, c_size_t, _P]),
     "rap_euler_step": (c_int32, [_P, _P, c_float, c_float, _P, _P, _P, c_int64, _P]),
@@ -94,7 +95,6 @@ SIGNATURES = {
     "rap_gemm_h16": (c_int32, [c_int32, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P,
                                c_int32, c_int32, _P, c_int32, _P]),
     "rap_gemm_h16_qkvnorm": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, c_float, _P, c_int32, _P]),
-    "rap_gemm_h16_resid_ln": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int64, _P, c_int32, _P]),
     "rap_attention_h16": (c_int32, [c_int32, _P, _P, c_int32, _P, c_int32, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "rap_layernorm_mod_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P]),
     "rap_layernorm_affine_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, _P, _P]),

@@ -94,7 +94,11 @@ struct rap_model {
   int dtype = RAP_DT_F32;     // arithmetic type of the transformer blocks (rap_model_set_compute_dtype)
   HalfWeights half[3];        // indexed by dtype (slot 0 unused)
   float* logit_bound = nullptr;   // (L, 2, H) per-head bounds on q.k/8 after qk-norm; null until a 16-bit dtype is selected
-  bool bounded_ok = false;        // every bound <= RAP_MAX_LOGIT_BOUND: the bounded-softmax attention kernel may be used
+  // bounded[2 * layer + branch]: every head of THAT attention has a bound <= RAP_MAX_LOGIT_BOUND, so that launch may use the
+  // bounded (offset-free) softmax kernel; the others take the online-softmax kernel.  Decided per launch since round 3 (VERDICT
+  // r02 item 4): one hot head in a trained checkpoint costs its own (layer, branch) the fast kernel, not the whole model.
+  std::vector<uint8_t> bounded;
+  int n_bounded = 0;
   float* raw = nullptr;       // copy of the caller's blob
   float* derived = nullptr;   // packed arrays
   const float* anchor_emb;    // (2,d)
@@ -119,34 +123,27 @@ extern rap_tuning_t g_rap_gemm_variant;   // gemm_f32.hip
 extern rap_tuning_t g_rap_gemm_stagger;   // gemm_f32.hip
 extern rap_tuning_t g_rap_gemm_splitk;    // gemm_f32.hip
 extern rap_tuning_t g_rap_geglu_fast;     // gemm_f32.hip
-extern rap_tuning_t g_rap_attn_variant;   // attn_f32.hip
 extern rap_tuning_t g_rap_attn_split;     // attn_f32.hip
 extern rap_tuning_t g_rap_gemm_h16_variant;   // gemm_h16.hip
 extern rap_tuning_t g_rap_attn_h16_variant;   // attn_h16.hip
-rap_tuning_t g_rap_fuse_ln = 0;                // tuning key 8: 16-bit path, the next LayerNorm fused into the residual GEMMs' epilogue (1) or as its own kernel (0, default:
-                                      // r02 call 16 -- fused, the 128x512 kernel's epilogue with its three block-wide reductions per row tile costs more (GEMM class
-                                      // 918 -> 1057 ms per sample call) than the three HBM-bound LayerNorm launches it removes (100 ms): 106.3k -> 101.6k points/s)
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
+rap_tuning_t g_rap_fused_mlp = 1;              // tuning key 10 (16-bit path): ff1 -> GEGLU -> ff2 in ONE kernel (1, default when the shape allows) or two GEMMs (0)
+// Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
+// fp32 summation order -- 5 split-KV for few-token calls, 6 split-K for few-row calls, 7 fused qk-norm, 9 GEGLU's Phi by the
+// 1.5e-7 erfc polynomial (1) or erff (0), 10 fused GEGLU-MLP.  Keys 0-4 (kernel-variant A/B of the round-1/2 experiments) exist
+// only in a library built with -DRAP_ABLATION_BUILD; the shipped library refuses them.
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
-  if (key == 0 && (value == 0 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 48)) { g_rap_gemm_variant = value; return RAP_OK; }
-  if (key == 1 && (value == 1 || value == 3 || value == 5)) { g_rap_attn_variant = value; return RAP_OK; }
-  if (key == 2 && value >= 0 && value <= 16) { g_rap_gemm_h16_variant = value; return RAP_OK; }
 #ifdef RAP_ABLATION_BUILD
-  if (key == 3 && ((value >= 14 && value <= 18) || value == 21)) { g_rap_attn_h16_variant = value; return RAP_OK; }
-#endif
-  if (key == 3 && ((value >= 0 && value <= 13) || value == 19 || value == 20 || value == 22 || value == 23 || value == 24)) {
-#ifndef RAP_ABLATION_BUILD
-    // 1-3, 6, 7 are timing-only ablations ("NOT attention"): compiled out of the shipped library, refused here
-    if (value == 1 || value == 2 || value == 3 || value == 6 || value == 7) return RAP_ERR_INVALID;
-#endif
-    g_rap_attn_h16_variant = value; return RAP_OK;
-  }
+  if (key == 0 && (value == 16 || value == 32 || value == 48)) { g_rap_gemm_variant = value; return RAP_OK; }
+  if (key == 2 && (value == 0 || value == 1 || value == 14)) { g_rap_gemm_h16_variant = value; return RAP_OK; }
+  if (key == 3 && (value == 0 || value == 5)) { g_rap_attn_h16_variant = value; return RAP_OK; }
   if (key == 4 && value >= 0 && value <= 2) { g_rap_gemm_stagger = value; return RAP_OK; }
+#endif
   if (key == 5 && (value == 0 || value == 1)) { g_rap_attn_split = value; return RAP_OK; }
   if (key == 6 && (value == 0 || value == 1)) { g_rap_gemm_splitk = value; return RAP_OK; }
   if (key == 7 && (value == 0 || value == 1)) { g_rap_fuse_qknorm = value; return RAP_OK; }
-  if (key == 8 && (value == 0 || value == 1)) { g_rap_fuse_ln = value; return RAP_OK; }
   if (key == 9 && (value == 0 || value == 1)) { g_rap_geglu_fast = value; return RAP_OK; }
+  if (key == 10 && (value == 0 || value == 1)) { g_rap_fused_mlp = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 
@@ -280,8 +277,12 @@ static int ensure_logit_bounds(rap_model* m, hipStream_t stream) {
   std::vector<float> hb(n);
   RAP_HIP_CHECK(hipMemcpyAsync(hb.data(), m->logit_bound, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream));
   RAP_HIP_CHECK(hipStreamSynchronize(stream));
-  m->bounded_ok = true;
-  for (float b : hb) if (!(b <= RAP_MAX_LOGIT_BOUND)) m->bounded_ok = false;
+  m->bounded.assign((size_t)2 * m->L, 1);
+  for (int j = 0; j < 2 * m->L; ++j)
+    for (int h = 0; h < m->H; ++h)
+      if (!(hb[(size_t)j * m->H + h] <= RAP_MAX_LOGIT_BOUND)) m->bounded[j] = 0;
+  m->n_bounded = 0;
+  for (uint8_t b : m->bounded) m->n_bounded += b;
   return RAP_OK;
 }
 
@@ -320,6 +321,7 @@ extern "C" int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* st
   return RAP_OK;
 }
 extern "C" int rap_model_compute_dtype(const rap_model* m) { return m ? m->dtype : RAP_ERR_INVALID; }
+extern "C" int rap_model_bounded_attention_launches(const rap_model* m) { return m ? m->n_bounded : RAP_ERR_INVALID; }
 
 // ---------------------------------------------------------------------------------------------
 // workspace
@@ -428,17 +430,14 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
     if (dt != RAP_DT_F32) {
       // ---- reduced-precision block: 16-bit MFMA operands, fp32 accumulate, fp32 residual stream / LN / softmax
       const LayerWH& lh = m->half[dt].layers[i];
-      // r02: with g_rap_fuse_ln every residual GEMM (N = d = 512: full rows per 128 x 512 tile) also writes the NEXT LayerNorm's
-      // 16-bit output, so only the very first LayerNorm of the forward runs as its own kernel.
-      const bool fuse_ln = g_rap_fuse_ln && d == 512;
       for (int a = 0; a < 2; ++a) {
         const int j = 2 * i + a;
-        if (!fuse_ln || (i == 0 && a == 0))
-          if ((rc = launch_layernorm_mod_h16(stream, dt, w.h, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
+        if ((rc = launch_layernorm_mod_h16(stream, dt, w.h, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
         GemmParamsH g{};
         g.A = w.xnh; g.lda = d; g.W = lh.Wqkv[a]; g.ldw = d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
         g.vt = w.vth; g.vt_nblk = w.vt_nblk;
-        const bool prescale = attention_h16_wants_prescaled_q(dt, m->bounded_ok) && g_rap_attn_h16_variant != 9;
+        const bool bnd = m->bounded[j] != 0;                              // this launch's softmax kernel (per layer and branch)
+        const bool prescale = attention_h16_wants_prescaled_q(dt, bnd);
         if (g_rap_fuse_qknorm) {
           // qk-norm in the QKV epilogue: one kernel, q / k normalised from the fp32 accumulators (no 16-bit round trip through HBM)
           g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; g.q_mul = prescale ? RAP_QMUL_PRESCALED : 8.0f;
@@ -451,7 +450,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         }
         {
           ProfScope ps(stream, a);
-          const float* bound = m->bounded_ok ? m->logit_bound + (size_t)j * H : nullptr;
+          const float* bound = bnd ? m->logit_bound + (size_t)j * H : nullptr;
           rc = launch_attention_h16(stream, dt, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch,
                                     a == 0 ? w.max_items_part : w.max_items_batch, bound, prescale ? 1 : 0);
         }
@@ -459,19 +458,10 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         GemmParamsH o{};
         o.A = w.atth; o.lda = d; o.W = lh.Wout[a]; o.ldw = d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = d;
         o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d;
-        if (fuse_ln) {
-          // next LayerNorm: a = 0 -> the global branch's adaLN (j + 1), a = 1 -> the feed-forward's affine LayerNorm
-          o.xn = w.xnh;
-          if (a == 0) { o.ln_gain = mod + (size_t)(j + 1) * 2 * d; o.ln_shift = o.ln_gain + d; o.ln_row_stride = mod_stride; o.ln_token_row = token_row; o.ln_add_one = 1; }
-          else { o.ln_gain = lw.ffn_g; o.ln_shift = lw.ffn_b; o.ln_row_stride = 0; o.ln_token_row = nullptr; o.ln_add_one = 0; }
-          { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_RESID_LN, o); }
-        } else {
-          { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, o); }
-        }
+        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, o); }
         if (rc) return rc;
       }
-      if (!fuse_ln)
-        if ((rc = launch_layernorm_affine_h16(stream, dt, w.h, w.xnh, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
+      if ((rc = launch_layernorm_affine_h16(stream, dt, w.h, w.xnh, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
       GemmParamsH f1{};
       f1.A = w.xnh; f1.lda = d; f1.W = lh.Wff1p; f1.ldw = d; f1.C = w.ffmidh; f1.ldc = 4 * d; f1.M = TP; f1.N = 8 * d; f1.K = d;
       f1.bias = lw.bff1p;
@@ -480,14 +470,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       GemmParamsH f2{};
       f2.A = w.ffmidh; f2.lda = 4 * d; f2.W = lh.Wff2; f2.ldw = 4 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 4 * d;
       f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d;
-      if (fuse_ln && i + 1 < m->L) {
-        // next LayerNorm: the self branch's adaLN of layer i + 1
-        f2.xn = w.xnh; f2.ln_gain = mod + (size_t)(2 * (i + 1)) * 2 * d; f2.ln_shift = f2.ln_gain + d; f2.ln_row_stride = mod_stride;
-        f2.ln_token_row = token_row; f2.ln_add_one = 1;
-        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_RESID_LN, f2); }
-      } else {
-        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, f2); }
-      }
+      { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, f2); }
       if (rc) return rc;
       continue;
     }
@@ -496,14 +479,14 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       if ((rc = launch_layernorm_mod(stream, w.h, w.xn, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
       GemmParams g{};
       g.A = w.xn; g.lda = d; g.W = lw.Wqkv[a]; g.ldw = d; g.C = w.qkv; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
-      const bool fuse_qk = g_rap_fuse_qknorm && (g_rap_gemm_variant == 16 || g_rap_gemm_variant == 32 || g_rap_gemm_variant == 48);
+      const bool fuse_qk = g_rap_fuse_qknorm != 0;
       if (fuse_qk) { g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; }        // qk-norm in the QKV epilogue (tuning key 7)
       { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_QKV_HEADMAJOR, g); }
       if (rc) return rc;
       if (!fuse_qk && (rc = launch_qknorm(stream, w.qkv, TP, H, lw.gq[a], lw.gk[a]))) return rc;
       {
         ProfScope ps(stream, a);
-        const float* bound = m->bounded_ok ? m->logit_bound + (size_t)j * H : nullptr;
+        const float* bound = m->bounded[j] ? m->logit_bound + (size_t)j * H : nullptr;
         // few-token calls: split the keys of every work item over up to 4 blocks; the partial O planes live in the (idle) FFN
         // buffer (4 x TP x d floats), the partial row sums in the (idle) LN-output buffer
         const int max_items = a == 0 ? w.max_items_part : w.max_items_batch;
@@ -785,9 +768,7 @@ extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
   if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, attention_h16_block_queries(dtype)))) return rc;
-  // tuning variant 10 (timing only): treat q as already pre-scaled, i.e. run the kernel the model path runs
-  return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound,
-                              (g_rap_attn_h16_variant == 10 && logit_bound && dtype == RAP_DT_BF16) ? 1 : 0);
+  return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound, 0);
 }
 extern "C" int rap_layernorm_mod_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* mod,
                                      int64_t mod_stride, const int32_t* token_row, void* stream) {
@@ -1268,15 +1249,4 @@ extern "C" int rap_gemm_h16_qkvnorm(int32_t dtype, const uint16_t* A, int32_t ld
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = qk_out; g.M = M; g.N = 3 * heads * 64; g.K = K; g.heads = heads;
   g.vt = vt; g.vt_nblk = vt_nblk; g.gamma_q = gamma_q; g.gamma_k = gamma_k; g.q_mul = q_mul;
   return launch_gemm_h16((hipStream_t)stream, dtype, EPI_H_QKV_NORM, g);
-}
-
-// residual GEMM (N = 512) with the next LayerNorm fused into its epilogue (EPI_H_RESID_LN): see rapflow.h
-extern "C" int rap_gemm_h16_resid_ln(int32_t dtype, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, float* h, int32_t ldh,
-                                     int32_t M, int32_t K, const float* bias, uint16_t* xn_out, const float* gain, const float* shift,
-                                     int64_t row_stride, const int32_t* token_row, int32_t add_one, void* stream) {
-  if (!A || !W || !h || !xn_out || !gain || !shift) return RAP_ERR_INVALID;
-  GemmParamsH g{};
-  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = h; g.ldc = ldh; g.M = M; g.N = 512; g.K = K; g.bias = bias; g.resid = h; g.ldr = ldh;
-  g.xn = xn_out; g.ln_gain = gain; g.ln_shift = shift; g.ln_row_stride = (long)row_stride; g.ln_token_row = token_row; g.ln_add_one = add_one;
-  return launch_gemm_h16((hipStream_t)stream, dtype, EPI_H_RESID_LN, g);
 }

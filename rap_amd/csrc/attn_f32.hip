@@ -307,252 +307,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// v3: one 32-query tile per wave, 8 waves (256 queries) per block, software-pipelined across 32-key
-// sub-tiles so that the softmax VALU work of sub-tile j sits in the MFMA shadow of QK^T(j+1):
-//
-//     ... | QK(j+1) + softmax(j) | PV(j) | QK(j+2) + softmax(j+1) | PV(j+1) | ...
-//
-// v1 (above: 2 query tiles per wave, QK -> softmax -> PV per sub-tile) leaves its softmax section
-// (~13 % of the MFMA time: 2 x {15 max, ds_bpermute round trip, 16 sub+exp, 16 add, 32 mul}) exposed
-// whenever the partner wave on the SIMD is in the same phase; measured 136 TF = 86 % of the fp32 matrix peak.
-// Here every wave's MFMA stream is continuous, a wave needs ~130 VGPRs instead of 226 (3-4 waves per
-// SIMD instead of 2), the cross-half max is a VALU v_permlane32_swap instead of an LDS ds_bpermute, and
-// the partially filled last sub-tile is a separate instantiation (no branches inside a sub-tile).
-//
-// LDS: double-buffered 64-key K/V tiles (as v1).  Because PV(j) trails QK(j+1) by half a tile, a tile's V
-// is still being read after the next tile's K has been opened, so a tile costs two barriers: one publishing
-// tile t+1, one retiring tile t before its buffer is overwritten by tile t+2.
-// ---------------------------------------------------------------------------------------------
-
-struct SmState { float mx_a, mnew, alpha, ps; };
-
-// Slice i of 8 of the online-softmax update of one 32x32 S^T tile (s: scores in, probabilities out).
-__device__ __forceinline__ void softmax_slice8(int i, f32x16& s, float& mrun, float& lsum, f32x16& o0, f32x16& o1, SmState& st) {
-  if (i == 0) {
-    float m = s[0];
-#pragma unroll
-    for (int r = 1; r < 8; ++r) m = fmaxf(m, s[r]);
-    st.mx_a = m;
-  } else if (i == 1) {
-    float m = s[8];
-#pragma unroll
-    for (int r = 9; r < 16; ++r) m = fmaxf(m, s[r]);
-    m = xhalf_max(fmaxf(m, st.mx_a));
-    st.mnew = fmaxf(mrun, m);
-    st.alpha = __builtin_amdgcn_exp2f(mrun - st.mnew);
-    mrun = st.mnew;
-    st.ps = 0.f;
-  } else if (i < 6) {
-    const int r0 = (i - 2) * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float pv = __builtin_amdgcn_exp2f(s[r0 + r] - st.mnew);
-      s[r0 + r] = pv;
-      st.ps += pv;
-    }
-  } else if (i == 6) {
-    lsum = lsum * st.alpha + st.ps;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) o0[j] *= st.alpha;
-  } else {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) o1[j] *= st.alpha;
-  }
-}
-
-// S^T (32 keys x 32 queries) of sub-tile `sub` of the K tile at Kc; optionally with the softmax of the
-// PREVIOUS sub-tile (sp) interleaved into the MFMA stream.
-template <bool MASKED, bool WITH_SM>
-__device__ __forceinline__ void qk_subtile(const float* __restrict__ Kc, int sub, int nvalid, int hi, int l31,
-                                           const float (&qf)[32], f32x16& sn, f32x16& sp, float& mrun, float& lsum,
-                                           f32x16& o0, f32x16& o1) {
-  const float* kp = Kc + (sub * 32 + l31) * KLD + 4 * hi;
-  SmState st;
-  f32x16 s2;     // second accumulation chain: a dependent MFMA never waits on its predecessor
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { sn[r] = 0.f; s2[r] = 0.f; }
-  float4 kf = *reinterpret_cast<const float4*>(kp);
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    float4 kn = kf;
-    if (g < 7) kn = *reinterpret_cast<const float4*>(kp + 8 * (g + 1));    // one group ahead, fenced in place
-    ATTN_FENCE
-    sn = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[g * 4 + 0], sn, 0, 0, 0);
-    s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[g * 4 + 1], s2, 0, 0, 0);
-    if (WITH_SM) softmax_slice8(g, sp, mrun, lsum, o0, o1, st);
-    sn = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[g * 4 + 2], sn, 0, 0, 0);
-    s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[g * 4 + 3], s2, 0, 0, 0);
-    ATTN_FENCE
-    kf = kn;
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) sn[r] += s2[r];
-  if (MASKED) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sn[r] = (mfma32_crow(r, hi) < nvalid) ? sn[r] : -1e30f;
-  }
-}
-
-// O^T += V^T P^T for sub-tile `sub` of the V tile at Vc (p = probabilities of that sub-tile).
-__device__ __forceinline__ void pv_subtile(const float* __restrict__ Vc, int sub, int hi, int l31, const f32x16& p,
-                                           f32x16& o0, f32x16& o1) {
-  const float* vp = Vc + (sub * 32 + 4 * hi) * VLD + 2 * l31;
-  float2 vfa = *reinterpret_cast<const float2*>(vp);
-  float2 vfb = *reinterpret_cast<const float2*>(vp + VLD);
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    float2 vna = vfa, vnb = vfb;
-    if (r + 2 < 16) {
-      const int k0 = ((r + 2) & 3) + 8 * ((r + 2) >> 2);
-      const int k1 = ((r + 3) & 3) + 8 * ((r + 3) >> 2);
-      vna = *reinterpret_cast<const float2*>(vp + k0 * VLD);
-      vnb = *reinterpret_cast<const float2*>(vp + k1 * VLD);
-    }
-    ATTN_FENCE
-    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vfa.x, p[r], o0, 0, 0, 0);
-    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vfa.y, p[r], o1, 0, 0, 0);
-    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vfb.x, p[r + 1], o0, 0, 0, 0);
-    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vfb.y, p[r + 1], o1, 0, 0, 0);
-    ATTN_FENCE
-    vfa = vna; vfb = vnb;
-  }
-}
-
-__global__ __launch_bounds__(512, 2) void attention_f32_v3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                  int TP, int heads, const AttnWorkItem* __restrict__ items) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * AKV * KLD + 2 * AKV * VLD];
-  float* Ks = smem;
-  float* Vs = smem + 2 * AKV * KLD;
-
-  const int head = blockIdx.x % heads;
-  const AttnWorkItem it = items[blockIdx.x / heads];
-  const int len = it.seg_len;
-  if (len <= 0) return;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  const size_t plane = (size_t)heads * TP * 64;
-  const float* Qg = qkv + ((size_t)head * TP + it.seg_start) * 64;
-  const float* Kg = Qg + plane;
-  const float* Vg = Qg + 2 * plane;
-
-  const int qw0 = it.q0 + wave * 32;
-  const bool wave_active = qw0 < len;     // waves beyond the segment still help stage K/V and hit the barriers
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);   // static priority split per SIMD pair
-
-  const float qscale = 0.125f * 1.44269504088896340736f;
-  float qf[32];
-  {
-    int q = qw0 + l31;
-    q = q < len ? q : len - 1;
-    const float* qp = Qg + (size_t)q * 64 + 4 * hi;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const float4 v = *reinterpret_cast<const float4*>(qp + 8 * g);
-      qf[g * 4 + 0] = v.x * qscale; qf[g * 4 + 1] = v.y * qscale;
-      qf[g * 4 + 2] = v.z * qscale; qf[g * 4 + 3] = v.w * qscale;
-    }
-  }
-  f32x16 o0, o1, sa, sb;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; sa[r] = 0.f; sb[r] = 0.f; }
-  float mrun = -1e30f, lsum = 0.f;
-
-  // staging: 512 threads, 2 float4 of K and 2 of V per thread per 64-key tile
-  const int srow = tid >> 4;          // 0..31 (+32)
-  const int sc4 = (tid & 15) * 4;
-  float4 rk0, rk1, rv0, rv1;
-  const int koff = srow * KLD + sc4;
-  const int voff = srow * VLD + sc4;
-  const int nkv = (len + AKV - 1) / AKV;
-  const int nsub = (len + 31) >> 5;   // 32-key sub-tiles in the segment
-  const int nfull = len >> 5;
-  const int rem = len & 31;
-
-#define ATTN3_LOAD(T)                                                        \
-  {                                                                          \
-    int k0_ = (T) * AKV + srow, k1_ = k0_ + 32;                              \
-    k0_ = k0_ < len ? k0_ : len - 1; k1_ = k1_ < len ? k1_ : len - 1;        \
-    rk0 = *reinterpret_cast<const float4*>(Kg + (size_t)k0_ * 64 + sc4);     \
-    rk1 = *reinterpret_cast<const float4*>(Kg + (size_t)k1_ * 64 + sc4);     \
-    rv0 = *reinterpret_cast<const float4*>(Vg + (size_t)k0_ * 64 + sc4);     \
-    rv1 = *reinterpret_cast<const float4*>(Vg + (size_t)k1_ * 64 + sc4);     \
-  }
-#define ATTN3_STORE(BUF)                                                                   \
-  *reinterpret_cast<float4*>(&Ks[(BUF) * (AKV * KLD) + koff]) = rk0;                       \
-  *reinterpret_cast<float4*>(&Ks[(BUF) * (AKV * KLD) + koff + 32 * KLD]) = rk1;            \
-  *reinterpret_cast<float4*>(&Vs[(BUF) * (AKV * VLD) + voff]) = rv0;                       \
-  *reinterpret_cast<float4*>(&Vs[(BUF) * (AKV * VLD) + voff + 32 * VLD]) = rv1;
-// QK of global sub-tile J (K tile at KC, local sub index SUB) into SN, with the softmax of SP interleaved if WITH_SM
-#define ATTN3_QK(J, KC, SUB, SN, SP, WITH_SM)                                                                     \
-  if ((J) < nfull) qk_subtile<false, WITH_SM>(KC, SUB, 32, hi, l31, qf, SN, SP, mrun, lsum, o0, o1);              \
-  else qk_subtile<true, WITH_SM>(KC, SUB, rem, hi, l31, qf, SN, SP, mrun, lsum, o0, o1);
-
-  ATTN3_LOAD(0)
-  ATTN3_STORE(0)
-  if (nkv > 1) { ATTN3_LOAD(1) }
-  __syncthreads();
-  // pipeline prologue: S(0)
-  if (wave_active) { ATTN3_QK(0, Ks, 0, sa, sb, false) }
-
-  // Invariant at the top of iteration t: tile t is in buf[cur]; sa = S(2t) (raw scores); tile t+1 (if any) is in rk/rv.
-  for (int t = 0; t < nkv; ++t) {
-    const int cur = t & 1;
-    const float* Kc = Ks + cur * (AKV * KLD);
-    const float* Vc = Vs + cur * (AKV * VLD);
-    const float* Kn = Ks + (cur ^ 1) * (AKV * KLD);
-    const int j0 = 2 * t, j1 = 2 * t + 1, j2 = 2 * t + 2;
-    // [A] QK(j1) + softmax(j0)      [B] PV(j0)
-    if (wave_active) {
-      if (j1 < nsub) { ATTN3_QK(j1, Kc, 1, sb, sa, true) }
-      else {
-        SmState st;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) softmax_slice8(i, sa, mrun, lsum, o0, o1, st);
-      }
-      pv_subtile(Vc, 0, hi, l31, sa, o0, o1);
-    }
-    // park tile t+1 in the spare buffer, start fetching tile t+2
-    if (t + 1 < nkv) { ATTN3_STORE(cur ^ 1) }
-    if (t + 2 < nkv) { ATTN3_LOAD(t + 2) }
-    __syncthreads();                      // tile t+1 visible
-    if (j1 < nsub) {
-      // [C] QK(j2) + softmax(j1)     [D] PV(j1)
-      if (wave_active) {
-        if (j2 < nsub) { ATTN3_QK(j2, Kn, 0, sa, sb, true) }
-        else {
-          SmState st;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) softmax_slice8(i, sb, mrun, lsum, o0, o1, st);
-        }
-        pv_subtile(Vc, 1, hi, l31, sb, o0, o1);
-      }
-    }
-    __syncthreads();                      // every wave is done with buf[cur]: the next iteration may overwrite it
-  }
-
-  if (!wave_active) return;
-  // ---- normalise and store: lane owns query (lane&31); register r of tile e is d = 2*crow(r,hi)+e
-  const int q = qw0 + l31;
-  const float inv = 1.0f / xhalf_sum(lsum);
-  if (q < len) {
-    float* op = out + (size_t)(it.seg_start + q) * (heads * 64) + head * 64;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int d0 = 2 * (8 * rg + 4 * hi);
-      float4 w0, w1;
-      w0.x = o0[4 * rg + 0] * inv; w0.y = o1[4 * rg + 0] * inv;
-      w0.z = o0[4 * rg + 1] * inv; w0.w = o1[4 * rg + 1] * inv;
-      w1.x = o0[4 * rg + 2] * inv; w1.y = o1[4 * rg + 2] * inv;
-      w1.z = o0[4 * rg + 3] * inv; w1.w = o1[4 * rg + 3] * inv;
-      *reinterpret_cast<float4*>(op + d0) = w0;
-      *reinterpret_cast<float4*>(op + d0 + 4) = w1;
-    }
-  }
-}
-
 // One thread walks the segment table (nseg is small: samples or parts of one batch) and emits one
 // work item per 256-query block; unused slots get seg_len = 0.  Runs once per sample() call.
 __global__ void build_attn_worklist_kernel(const int32_t* __restrict__ cu, int nseg, AttnWorkItem* __restrict__ items,
@@ -569,12 +323,11 @@ __global__ void build_attn_worklist_kernel(const int32_t* __restrict__ cu, int n
   for (; n < max_items; ++n) { AttnWorkItem w; w.seg_start = 0; w.seg_len = 0; w.q0 = 0; w.pad = 0; items[n] = w; }
 }
 
-// tuning knob (rap_set_tuning key 1): 1 = v1 with 4 waves (256 queries per block, the default: 136 TF at the C1 shapes,
-// profiles/r01_run3_kernel_variant_sweep.jsonl), 5 = v1 with 8 waves + static priority split (512 queries per block,
-// 134 TF), 3 = v3 (one query tile per wave, cross-sub-tile pipelining, 124 TF).
-rap_tuning_t g_rap_attn_variant = 1;
+// One schedule ships: 4 waves x 64 queries per block (136 -> 142 TF at the C1 shapes).  The 8-wave / 512-query form (134 TF) and
+// the software-pipelined v3 kernel (124 TF) of round 1 are in the history at 72efb73 (profiles/r01_run3_kernel_variant_sweep.jsonl).
+rap_tuning_t g_rap_attn_variant = 1;   // kept for the ablation build's rap_set_tuning(1, .): only 1 exists
 rap_tuning_t g_rap_attn_split = 1;     // tuning key 5: 0 = never split few-token calls over key ranges
-static int attn_block_queries() { return g_rap_attn_variant == 5 ? 512 : RAP_ATTN_BQ; }
+static int attn_block_queries() { return RAP_ATTN_BQ; }
 
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,
                                int max_items, int block_queries) {
@@ -608,7 +361,7 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __r
 // How many key ranges a few-token call is split into (1 = no split): only the bounded (offset-free) kernel can add partial
 // results, and only work lists that leave most of the 2 x 256 block slots empty are worth the extra pass.
 int attention_f32_splits(int max_items, int heads, bool bounded) {
-  if (!bounded || g_rap_attn_variant != 1 || g_rap_attn_split == 0) return 1;
+  if (!bounded || g_rap_attn_split == 0) return 1;
   const long blocks = (long)max_items * heads;
   return blocks <= 160 ? 4 : blocks <= 320 ? 2 : 1;
 }
@@ -618,7 +371,7 @@ int launch_attention_f32(hipStream_t stream, const float* qkv, float* out, int T
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0) return RAP_ERR_INVALID;
   if (splits > 1) {
-    if (!bound || !part_o || !part_l || g_rap_attn_variant != 1) return RAP_ERR_INVALID;
+    if (!bound || !part_o || !part_l) return RAP_ERR_INVALID;
     hipLaunchKernelGGL((attention_f32_kernel<4, true, true>), dim3(max_items * heads, splits), dim3(256), 0, stream, qkv, out, TP,
                        heads, items, bound, part_o, part_l);
     RAP_LAUNCH_CHECK();
@@ -629,15 +382,8 @@ int launch_attention_f32(hipStream_t stream, const float* qkv, float* out, int T
     return RAP_OK;
   }
   float* const no = nullptr;
-  if (g_rap_attn_variant == 1)
-  {
-    if (bound) hipLaunchKernelGGL((attention_f32_kernel<4, true>), dim3(max_items * heads), dim3(256), 0, stream, qkv, out, TP, heads, items, bound, no, no);
-    else hipLaunchKernelGGL((attention_f32_kernel<4, false>), dim3(max_items * heads), dim3(256), 0, stream, qkv, out, TP, heads, items, bound, no, no);
-  }
-  else if (g_rap_attn_variant == 5)
-    hipLaunchKernelGGL((attention_f32_kernel<8, false>), dim3(max_items * heads), dim3(512), 0, stream, qkv, out, TP, heads, items, bound, no, no);
-  else
-    hipLaunchKernelGGL(attention_f32_v3_kernel, dim3(max_items * heads), dim3(512), 0, stream, qkv, out, TP, heads, items);
+  if (bound) hipLaunchKernelGGL((attention_f32_kernel<4, true>), dim3(max_items * heads), dim3(256), 0, stream, qkv, out, TP, heads, items, bound, no, no);
+  else hipLaunchKernelGGL((attention_f32_kernel<4, false>), dim3(max_items * heads), dim3(256), 0, stream, qkv, out, TP, heads, items, bound, no, no);
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }

@@ -13,8 +13,9 @@
 //    for k-group g (8 columns) lanes 0-31 read columns 8g..8g+3 and lanes 32-63 columns 8g+4..8g+7;
 //    MFMA step s then contracts the column pair {8g+s, 8g+4+s}.  A sum is order independent up to
 //    fp32 rounding, and the same permutation is applied to A and W.
-//  * global -> register -> LDS staging, double-buffered LDS, one barrier per k-tile; the loads of
-//    tile t+1 are issued before the 64 MFMAs of tile t.
+//  * k-tiles go global -> LDS directly (global_load_lds_dwordx4, XOR slot swizzle instead of row padding), double-buffered
+//    LDS, one barrier per k-tile.  (Rounds 1-2 also carried a register-staged v1 kernel and three software-pipelined
+//    register-staged tilings, 12 points slower -- DESIGN.md 4.2; they are in the history at 72efb73.)
 //  * 1-D grid, XCD-aware remap, n-tile fastest: all n-tiles of one 128-row A panel run back to
 //    back on one XCD (A panel stays in that XCD's L2; W streams from L2 / Infinity Cache).
 #include <type_traits>
@@ -56,383 +57,6 @@ __device__ __forceinline__ void qkv_store_normalised(const GemmParams& p, f32x16
       if (m < p.M) {
         plane[(size_t)m * 64 + l31] = acc[mi][0][r] / nrm * g0 * 8.0f;
         plane[(size_t)m * 64 + 32 + l31] = acc[mi][1][r] / nrm * g1 * 8.0f;
-      }
-    }
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * GBM * GLD];
-  float* As = smem;                      // [2][128][36]
-  float* Bs = smem + 2 * GBM * GLD;      // [2][128][36]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int nt = p.N / GBN;
-  const int mt = (p.M + GBM - 1) / GBM;
-  const int logical = xcd_remap(blockIdx.x, mt * nt);
-  const int m0 = (logical / nt) * GBM;
-  const int n0 = (logical % nt) * GBN;
-
-  // per-thread staging coordinates: 4 float4 of A and 4 of W per k-tile
-  const int srow = tid >> 3;         // 0..31 (+32*i)
-  const int sc4 = (tid & 7) * 4;     // float column inside the k-tile
-  const float* a_ptr[4];
-  const float* w_ptr[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int r = m0 + srow + 32 * i;
-    r = r < p.M ? r : p.M - 1;
-    a_ptr[i] = p.A + (size_t)r * p.lda + sc4;
-    w_ptr[i] = p.W + (size_t)(n0 + srow + 32 * i) * p.ldw + sc4;
-  }
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  float4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;   // named registers: arrays under a branch end up in scratch
-  const int nk = p.K / GBK;
-  const int st_off = srow * GLD + sc4;
-
-#define GEMM_LOAD_TILE(KT)                                                            \
-  ra0 = *reinterpret_cast<const float4*>(a_ptr[0] + (size_t)(KT) * GBK);              \
-  ra1 = *reinterpret_cast<const float4*>(a_ptr[1] + (size_t)(KT) * GBK);              \
-  ra2 = *reinterpret_cast<const float4*>(a_ptr[2] + (size_t)(KT) * GBK);              \
-  ra3 = *reinterpret_cast<const float4*>(a_ptr[3] + (size_t)(KT) * GBK);              \
-  rw0 = *reinterpret_cast<const float4*>(w_ptr[0] + (size_t)(KT) * GBK);              \
-  rw1 = *reinterpret_cast<const float4*>(w_ptr[1] + (size_t)(KT) * GBK);              \
-  rw2 = *reinterpret_cast<const float4*>(w_ptr[2] + (size_t)(KT) * GBK);              \
-  rw3 = *reinterpret_cast<const float4*>(w_ptr[3] + (size_t)(KT) * GBK);
-#define GEMM_STORE_TILE(BUF)                                                          \
-  *reinterpret_cast<float4*>(&As[(BUF) * (GBM * GLD) + st_off + 0 * 32 * GLD]) = ra0; \
-  *reinterpret_cast<float4*>(&As[(BUF) * (GBM * GLD) + st_off + 1 * 32 * GLD]) = ra1; \
-  *reinterpret_cast<float4*>(&As[(BUF) * (GBM * GLD) + st_off + 2 * 32 * GLD]) = ra2; \
-  *reinterpret_cast<float4*>(&As[(BUF) * (GBM * GLD) + st_off + 3 * 32 * GLD]) = ra3; \
-  *reinterpret_cast<float4*>(&Bs[(BUF) * (GBN * GLD) + st_off + 0 * 32 * GLD]) = rw0; \
-  *reinterpret_cast<float4*>(&Bs[(BUF) * (GBN * GLD) + st_off + 1 * 32 * GLD]) = rw1; \
-  *reinterpret_cast<float4*>(&Bs[(BUF) * (GBN * GLD) + st_off + 2 * 32 * GLD]) = rw2; \
-  *reinterpret_cast<float4*>(&Bs[(BUF) * (GBN * GLD) + st_off + 3 * 32 * GLD]) = rw3;
-#define GEMM_COMPUTE_TILE(BUF)                                                                        \
-  {                                                                                                   \
-    const float* Ac = As + (BUF) * (GBM * GLD);                                                       \
-    const float* Bc = Bs + (BUF) * (GBN * GLD);                                                       \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
-      const float4 a0 = *reinterpret_cast<const float4*>(&Ac[a_off + 8 * g]);                         \
-      const float4 a1 = *reinterpret_cast<const float4*>(&Ac[a_off + 32 * GLD + 8 * g]);              \
-      const float4 b0 = *reinterpret_cast<const float4*>(&Bc[b_off + 8 * g]);                         \
-      const float4 b1 = *reinterpret_cast<const float4*>(&Bc[b_off + 32 * GLD + 8 * g]);              \
-      GEMM_MFMA4(a0.x, a1.x, b0.x, b1.x)                                                              \
-      GEMM_MFMA4(a0.y, a1.y, b0.y, b1.y)                                                              \
-      GEMM_MFMA4(a0.z, a1.z, b0.z, b1.z)                                                              \
-      GEMM_MFMA4(a0.w, a1.w, b0.w, b1.w)                                                              \
-    }                                                                                                 \
-  }
-#define GEMM_MFMA4(A0, A1, B0, B1)                                                   \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc[0][0], 0, 0, 0);      \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B1, acc[0][1], 0, 0, 0);      \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B0, acc[1][0], 0, 0, 0);      \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, acc[1][1], 0, 0, 0);
-
-  const int a_off = (wm * 64 + l31) * GLD + 4 * hi;
-  const int b_off = (wn * 64 + l31) * GLD + 4 * hi;
-
-  GEMM_LOAD_TILE(0)
-  GEMM_STORE_TILE(0)
-  __syncthreads();
-
-  // main loop: prefetch tile kt+1 into registers, 64 MFMAs on tile kt, park the prefetch in the other buffer
-  int kt = 0;
-  for (; kt + 1 < nk; ++kt) {
-    const int cur = kt & 1;
-    GEMM_LOAD_TILE(kt + 1)
-    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc otherwise sinks it to its use)
-    GEMM_COMPUTE_TILE(cur)
-    __builtin_amdgcn_sched_barrier(0);
-    GEMM_STORE_TILE(cur ^ 1)
-    __syncthreads();
-  }
-  GEMM_COMPUTE_TILE(kt & 1)
-
-  // ---------------- epilogue ----------------
-  const int mw = m0 + wm * 64;
-  const int nw = n0 + wn * 64;
-  if (EPI == EPI_GEGLU) {
-    // acc[mi][0] = value columns, acc[mi][1] = gate columns of the same 32 outputs
-    const int nout = (nw >> 1) + l31;
-    const float bh = p.bias ? p.bias[nw + l31] : 0.f;
-    const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mw + mi * 32 + mfma32_crow(r, hi);
-        if (m < p.M) {
-          const float h = acc[mi][0][r] + bh;
-          const float g = acc[mi][1][r] + bg;
-          const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
-          p.C[(size_t)m * p.ldc + nout] = h * ge;
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int n = nw + ni * 32 + l31;
-      const float bn = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mw + mi * 32 + mfma32_crow(r, hi);
-        if (m >= p.M) continue;
-        float v = acc[mi][ni][r] + bn;
-        if (EPI == EPI_BIAS) {
-          p.C[(size_t)m * p.ldc + n] = v;
-        } else if (EPI == EPI_BIAS_RESID) {
-          p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
-        } else if (EPI == EPI_BIAS_SILU) {
-          p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
-        } else if (EPI == EPI_BIAS_RELU) {
-          p.C[(size_t)m * p.ldc + n] = fmaxf(v, 0.f);
-        } else if (EPI == EPI_BIAS_ANCHOR) {
-          const int sel = p.anchor[m] ? 1 : 0;
-          p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
-        } else if (EPI == EPI_QKV_HEADMAJOR) {
-          const int dmodel = p.heads * 64;
-          const int c = n / dmodel;
-          const int rem = n - c * dmodel;
-          const int h = rem >> 6, j = rem & 63;
-          p.C[(((size_t)c * p.heads + h) * p.M + m) * 64 + j] = v;
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Software-pipelined variant (the default).  Same tiling idea, but
-//  * the MFMA operands of k-group g+1 are read from LDS into a second register set while the 16*WNT/2
-//    MFMAs of group g issue (fragment double-buffering), and the first group of tile t+1 is read right
-//    after the barrier while the LAST group of tile t still runs -> no exposed ds_read latency after a barrier;
-//  * the prefetched tile t+1 is parked in the spare LDS buffer in the middle of tile t's MFMAs
-//    (it has had 32*WNT/2 MFMAs = 2-4k cycles to arrive), not in a serial block before the barrier;
-//  * WNT = 4: 128x256 block tile, each wave 64x128 (8 accumulator tiles = 128 registers), one block per CU
-//    (110 KB LDS): 1.33x fewer L2->LDS bytes per flop than 128x128 and 128 MFMAs between barriers.
-//    WNT = 2 keeps the 128x128 tile at two blocks per CU.
-// ---------------------------------------------------------------------------------------------
-//  * WMW = 4: 8 waves (4 along M x 2 along N), 256x128 block tile, one block per CU; the two waves that share a
-//    SIMD (w, w+4) get different static priorities so they do not run in lock-step (see attn_f32.hip).
-template <int EPI, int WNT, int WMW>
-__global__ __launch_bounds__(128 * WMW, (WMW == 4 ? 2 : (WNT == 2 ? 2 : 1))) void gemm_f32_pipe_kernel(GemmParams p) {
-  constexpr int BM = 64 * WMW;        // block tile along M
-  constexpr int BN = 64 * WNT;        // block tile along N (two waves)
-  constexpr int RP = 16 * WMW;        // rows staged per pass (8 threads per 32-float row)
-  constexpr int NW4 = BN / RP;        // float4 of W staged per thread per k-tile (A: always 4)
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * GLD];
-  float* As = smem;                      // [2][BM][36]
-  float* Bs = smem + 2 * BM * GLD;       // [2][BN][36]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
-  if (WMW == 4) {
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
-  }
-
-  const int nt = p.N / BN;
-  const int mt = (p.M + BM - 1) / BM;
-  const int logical = xcd_remap(blockIdx.x, mt * nt);
-  const int m0 = (logical / nt) * BM;
-  const int n0 = (logical % nt) * BN;
-
-  const int srow = tid >> 3;
-  const int sc4 = (tid & 7) * 4;
-  const float* a_ptr[4];
-  const float* w_ptr[NW4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int r = m0 + srow + RP * i;
-    r = r < p.M ? r : p.M - 1;
-    a_ptr[i] = p.A + (size_t)r * p.lda + sc4;
-  }
-#pragma unroll
-  for (int i = 0; i < NW4; ++i) w_ptr[i] = p.W + (size_t)(n0 + srow + RP * i) * p.ldw + sc4;
-
-  f32x16 acc[2][WNT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < WNT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // Staging and fragment registers are named struct members (never arrays: hipcc promotes private arrays
-  // that survive until late unrolling to LDS or scratch).
-  float4 sg_a0, sg_a1, sg_a2, sg_a3, sg_w0, sg_w1, sg_w2, sg_w3, sg_w4, sg_w5, sg_w6, sg_w7;
-  struct Frag { float4 a0, a1, b0, b1, b2, b3; } f0, f1;
-  const int nk = p.K / GBK;
-  const int st_off = srow * GLD + sc4;
-  const int a_off = (wm * 64 + l31) * GLD + 4 * hi;
-  const int b_off = (wn * (32 * WNT) + l31) * GLD + 4 * hi;
-
-#define PG_LD(PTR, KT) (*reinterpret_cast<const float4*>((PTR) + (size_t)(KT) * GBK))
-#define PG_LOAD(KT)                                                                    \
-  sg_a0 = PG_LD(a_ptr[0], KT); sg_a1 = PG_LD(a_ptr[1], KT);                            \
-  sg_a2 = PG_LD(a_ptr[2], KT); sg_a3 = PG_LD(a_ptr[3], KT);                            \
-  sg_w0 = PG_LD(w_ptr[0], KT); sg_w1 = PG_LD(w_ptr[1], KT);                            \
-  if constexpr (NW4 >= 4) { sg_w2 = PG_LD(w_ptr[2], KT); sg_w3 = PG_LD(w_ptr[3], KT); } \
-  if constexpr (NW4 == 8) {                                                            \
-    sg_w4 = PG_LD(w_ptr[4], KT); sg_w5 = PG_LD(w_ptr[5], KT);                          \
-    sg_w6 = PG_LD(w_ptr[6], KT); sg_w7 = PG_LD(w_ptr[7], KT);                          \
-  }
-#define PG_ST(BASE, I, V) *reinterpret_cast<float4*>(&(BASE)[st_off + (I) * RP * GLD]) = (V)
-#define PG_STORE(BUF)                                                                  \
-  {                                                                                    \
-    float* A_ = As + (BUF) * (BM * GLD);                                               \
-    float* B_ = Bs + (BUF) * (BN * GLD);                                               \
-    PG_ST(A_, 0, sg_a0); PG_ST(A_, 1, sg_a1); PG_ST(A_, 2, sg_a2); PG_ST(A_, 3, sg_a3); \
-    PG_ST(B_, 0, sg_w0); PG_ST(B_, 1, sg_w1);                                          \
-    if constexpr (NW4 >= 4) { PG_ST(B_, 2, sg_w2); PG_ST(B_, 3, sg_w3); }              \
-    if constexpr (NW4 == 8) {                                                          \
-      PG_ST(B_, 4, sg_w4); PG_ST(B_, 5, sg_w5); PG_ST(B_, 6, sg_w6); PG_ST(B_, 7, sg_w7); \
-    }                                                                                  \
-  }
-#define PG_RD(BASE, OFF, I, G) (*reinterpret_cast<const float4*>(&(BASE)[(OFF) + (I) * 32 * GLD + 8 * (G)]))
-#define PG_READ(BUF, G, F)                                                             \
-  {                                                                                    \
-    const float* A_ = As + (BUF) * (BM * GLD);                                         \
-    const float* B_ = Bs + (BUF) * (BN * GLD);                                         \
-    F.a0 = PG_RD(A_, a_off, 0, G); F.a1 = PG_RD(A_, a_off, 1, G);                      \
-    F.b0 = PG_RD(B_, b_off, 0, G); F.b1 = PG_RD(B_, b_off, 1, G);                      \
-    if constexpr (WNT == 4) { F.b2 = PG_RD(B_, b_off, 2, G); F.b3 = PG_RD(B_, b_off, 3, G); } \
-  }
-#define PG_MM(I, J, AV, BV) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV, acc[I][J], 0, 0, 0);
-#define PG_MFMA_STEP(F, C)                                                             \
-  PG_MM(0, 0, F.a0.C, F.b0.C) PG_MM(0, 1, F.a0.C, F.b1.C)                              \
-  if constexpr (WNT == 4) { PG_MM(0, 2, F.a0.C, F.b2.C) PG_MM(0, 3, F.a0.C, F.b3.C) }  \
-  PG_MM(1, 0, F.a1.C, F.b0.C) PG_MM(1, 1, F.a1.C, F.b1.C)                              \
-  if constexpr (WNT == 4) { PG_MM(1, 2, F.a1.C, F.b2.C) PG_MM(1, 3, F.a1.C, F.b3.C) }
-#define PG_MFMA(F) PG_MFMA_STEP(F, x) PG_MFMA_STEP(F, y) PG_MFMA_STEP(F, z) PG_MFMA_STEP(F, w)
-
-  PG_LOAD(0)
-  PG_STORE(0)
-  __syncthreads();
-  PG_READ(0, 0, f0)
-
-  // hipcc sinks an LDS read down to just before its first use; every PG_READ is therefore fenced with
-  // sched_barrier so that the next group's operands are IN FLIGHT during the current group's MFMAs
-  // (un-fenced, the four reads sat one MFMA ahead of their consumers and ~130 cycles of LDS latency were
-  // exposed at each of the four group boundaries of a k-tile).
-#define PG_FENCE __builtin_amdgcn_sched_barrier(0);
-  int kt = 0;
-  for (; kt + 1 < nk; ++kt) {
-    const int cur = kt & 1;
-    PG_LOAD(kt + 1)
-    PG_READ(cur, 1, f1)
-    PG_FENCE
-    PG_MFMA(f0)                             // group 0
-    PG_FENCE
-    PG_READ(cur, 2, f0)
-    PG_FENCE
-    PG_MFMA(f1)                             // group 1
-    PG_FENCE
-    PG_STORE(cur ^ 1)                       // tile kt+1 -> spare buffer (last read two barriers ago)
-    PG_READ(cur, 3, f1)
-    PG_FENCE
-    PG_MFMA(f0)                             // group 2
-    PG_FENCE
-    __syncthreads();                        // tile kt+1 visible; every wave has completed its reads of tile kt
-    PG_READ(cur ^ 1, 0, f0)
-    PG_FENCE
-    PG_MFMA(f1)                             // group 3 of tile kt covers the first reads of tile kt+1
-    PG_FENCE
-  }
-  {
-    const int cur = kt & 1;
-    PG_READ(cur, 1, f1)
-    PG_FENCE
-    PG_MFMA(f0)
-    PG_FENCE
-    PG_READ(cur, 2, f0)
-    PG_FENCE
-    PG_MFMA(f1)
-    PG_FENCE
-    PG_READ(cur, 3, f1)
-    PG_FENCE
-    PG_MFMA(f0)
-    PG_FENCE
-    PG_MFMA(f1)
-  }
-
-  // ---------------- epilogue ----------------
-  const int mw = m0 + wm * 64;
-  const int nw = n0 + wn * (32 * WNT);
-  if (EPI == EPI_GEGLU) {
-#pragma unroll
-    for (int jp = 0; jp < WNT / 2; ++jp) {
-      const int nout = ((nw + 64 * jp) >> 1) + l31;
-      const float bh = p.bias ? p.bias[nw + 64 * jp + l31] : 0.f;
-      const float bg = p.bias ? p.bias[nw + 64 * jp + 32 + l31] : 0.f;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mw + mi * 32 + mfma32_crow(r, hi);
-          if (m < p.M) {
-            const float h = acc[mi][2 * jp][r] + bh;
-            const float g = acc[mi][2 * jp + 1][r] + bg;
-            const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
-            p.C[(size_t)m * p.ldc + nout] = h * ge;
-          }
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < WNT; ++ni) {
-      const int n = nw + ni * 32 + l31;
-      const float bn = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mw + mi * 32 + mfma32_crow(r, hi);
-        if (m >= p.M) continue;
-        float v = acc[mi][ni][r] + bn;
-        if (EPI == EPI_BIAS) {
-          p.C[(size_t)m * p.ldc + n] = v;
-        } else if (EPI == EPI_BIAS_RESID) {
-          p.C[(size_t)m * p.ldc + n] = p.resid[(size_t)m * p.ldr + n] + v;
-        } else if (EPI == EPI_BIAS_SILU) {
-          p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
-        } else if (EPI == EPI_BIAS_RELU) {
-          p.C[(size_t)m * p.ldc + n] = fmaxf(v, 0.f);
-        } else if (EPI == EPI_BIAS_ANCHOR) {
-          const int sel = p.anchor[m] ? 1 : 0;
-          p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
-        } else if (EPI == EPI_QKV_HEADMAJOR) {
-          const int dmodel = p.heads * 64;
-          const int c = n / dmodel;
-          const int rem = n - c * dmodel;
-          const int h = rem >> 6, j = rem & 63;
-          p.C[(((size_t)c * p.heads + h) * p.M + m) * 64 + j] = v;
-        }
       }
     }
   }
@@ -982,37 +606,29 @@ __global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(GemmParams p, 
   *reinterpret_cast<float4*>(p.C + m * p.ldc + n) = acc;
 }
 
-// tuning knob (rap_set_tuning key 0): 0 = v1 128x128, 2 = pipelined 128x128 (two 4-wave blocks per CU),
-// 4 = pipelined 128x256 (one 4-wave block per CU; N % 256 == 0, else falls back to 2),
-// 8 = pipelined 256x128, one 8-wave block per CU with a static priority split per SIMD pair,
-// 16 = LDS-DMA staged 128x128, 32 = LDS-DMA staged 256x256 (8 waves, one block per CU),
-// 48 = per shape (default, r02): the 256x256 kernel where r01 run 54 measured it faster -- wide outputs at K <= 512 (qkv 111 -> 115 TF,
-// ff1 123 -> 126) -- and the 128x128 kernel elsewhere (out-projection 105 vs 91, ff2 132 vs 127, embedding, head).
+// Kernel choice: the LDS-DMA 256 x 256 / 8-wave kernel wherever there are at least two rounds of its tiles, N % 256 == 0 and
+// K >= 256 (r02 call 40: qkv 128 vs 119 TF, ff1 132 vs 129, ff2 139 vs 131, head 125 vs 119, out-projection equal); the LDS-DMA
+// 128 x 128 kernel (two blocks per CU cover each other's prologue) for the K = 64 embedding GEMM, narrow outputs and few-token calls.
+// RAP_ABLATION_BUILD only: rap_set_tuning(0, 16 | 32) forces one of the two.
 rap_tuning_t g_rap_gemm_variant = 48;
 
 template <int EPI>
-static void launch_gemm_variant(hipStream_t stream, const GemmParams& p, int variant) {
+static int launch_gemm_variant(hipStream_t stream, const GemmParams& p, int variant) {
   const int mt = (p.M + GBM - 1) / GBM;
   if (variant == 32 && p.N % 256 == 0) {
     constexpr int LDS = 2 * (256 + 256) * 128;
-    static bool attr_done = false;
     auto kern = gemm_f32_dma256_kernel<EPI>;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      attr_done = true;
+    // per device and cheap: set unconditionally (a process may drive several GPUs)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      rap_set_last_hip_error((int)hipGetLastError());
+      return RAP_ERR_HIP;
     }
     hipLaunchKernelGGL(kern, dim3(((p.M + 255) / 256) * (p.N / 256)), dim3(512), LDS, stream, p);
-  } else if (variant == 16 || variant == 32) {
-    hipLaunchKernelGGL(gemm_f32_dma_kernel<EPI>, dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
-  } else if (variant == 8) {
-    hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 2, 4>), dim3(((p.M + 255) / 256) * (p.N / GBN)), dim3(512), 0, stream, p);
-  } else if (variant == 4 && p.N % 256 == 0) {
-    hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 4, 2>), dim3(mt * (p.N / 256)), dim3(256), 0, stream, p);
-  } else if (variant == 0) {
-    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
   } else {
-    hipLaunchKernelGGL((gemm_f32_pipe_kernel<EPI, 2, 2>), dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(gemm_f32_dma_kernel<EPI>, dim3(mt * (p.N / GBN)), dim3(256), 0, stream, p);
   }
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
 }
 
 rap_tuning_t g_rap_gemm_splitk = 1;      // tuning key 6: 0 = never split K for few-row calls
@@ -1030,11 +646,11 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
   if (p.M <= 0) return RAP_OK;
   if (p.N % GBN != 0 || p.K % GBK != 0 || p.K <= 0) return RAP_ERR_INVALID;
   if ((p.lda & 3) || (p.ldw & 3)) return RAP_ERR_INVALID;
-  int v = g_rap_gemm_variant;
-  // per shape (r02 call 40, after the epilogue rewrite): the 256x256 kernel wherever there are at least two rounds of its tiles and
-  // K >= 256 -- qkv 128 vs 119 TF, ff1 132 vs 129, ff2 139 vs 131, head 125 vs 119, out-projection equal; the K = 64 embedding GEMM and
-  // few-token calls stay on the 128x128 kernel (two blocks per CU cover each other's prologue).
-  if (v == 48) v = (p.N % 256 == 0 && p.K >= 256 && (long)((p.M + 255) / 256) * (p.N / 256) >= 512) ? 32 : 16;
+  int v = 48;
+#ifdef RAP_ABLATION_BUILD
+  v = g_rap_gemm_variant;
+#endif
+  if (v != 16 && v != 32) v = (p.N % 256 == 0 && p.K >= 256 && (long)((p.M + 255) / 256) * (p.N / 256) >= 512) ? 32 : 16;
   if (epilogue == EPI_BIAS_RESID && (v == 16 || v == 32) && p.splitk_ws && g_rap_gemm_splitk && p.K >= 1024 && (p.ldr & 3) == 0 && (p.ldc & 3) == 0 &&
       (long)((p.M + GBM - 1) / GBM) * (p.N / GBN) <= 128) {
     const int splits = 4;
@@ -1045,19 +661,16 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
     return RAP_OK;
   }
   switch (epilogue) {
-    case EPI_BIAS: launch_gemm_variant<EPI_BIAS>(stream, p, v); break;
-    case EPI_BIAS_RESID: launch_gemm_variant<EPI_BIAS_RESID>(stream, p, v); break;
-    case EPI_BIAS_SILU: launch_gemm_variant<EPI_BIAS_SILU>(stream, p, v); break;
-    case EPI_GEGLU: launch_gemm_variant<EPI_GEGLU>(stream, p, v); break;
+    case EPI_BIAS: return launch_gemm_variant<EPI_BIAS>(stream, p, v);
+    case EPI_BIAS_RESID: return launch_gemm_variant<EPI_BIAS_RESID>(stream, p, v);
+    case EPI_BIAS_SILU: return launch_gemm_variant<EPI_BIAS_SILU>(stream, p, v);
+    case EPI_GEGLU: return launch_gemm_variant<EPI_GEGLU>(stream, p, v);
     case EPI_QKV_HEADMAJOR:
       if (p.N != 3 * p.heads * 64) return RAP_ERR_INVALID;
-      if (p.gamma_q && (!p.gamma_k || !(v == 16 || v == 32))) return RAP_ERR_INVALID;      // fused qk-norm lives in the LDS-DMA kernels
-      launch_gemm_variant<EPI_QKV_HEADMAJOR>(stream, p, v);
-      break;
-    case EPI_BIAS_ANCHOR: launch_gemm_variant<EPI_BIAS_ANCHOR>(stream, p, v); break;
-    case EPI_BIAS_RELU: launch_gemm_variant<EPI_BIAS_RELU>(stream, p, v); break;
+      if (p.gamma_q && !p.gamma_k) return RAP_ERR_INVALID;
+      return launch_gemm_variant<EPI_QKV_HEADMAJOR>(stream, p, v);
+    case EPI_BIAS_ANCHOR: return launch_gemm_variant<EPI_BIAS_ANCHOR>(stream, p, v);
+    case EPI_BIAS_RELU: return launch_gemm_variant<EPI_BIAS_RELU>(stream, p, v);
     default: return RAP_ERR_INVALID;
   }
-  RAP_LAUNCH_CHECK();
-  return RAP_OK;
 }

@@ -80,91 +80,6 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
     }
     return;
   }
-  if constexpr (EPI == EPI_H_RESID_LN) {
-    // Full rows: the block tile is 128 x 512 = N, waves 1 x 8, this wave owns columns nw .. nw + 63 of rows mw .. mw + 127.
-    // Per 32-row tile: h = acc + bias + resid through the wave's LDS slab (whole 16-byte row pieces, as EPI_H_BIAS_RESID_F32), then
-    // the LayerNorm of the NEW rows: two block-wide reductions over the 8 waves (mean, then the centred sum of squares -- the
-    // two-pass form of layernorm_h16_kernel) and xn = (h - mean) rstd (add_one + gain) + shift rounded to 16 bit.
-    // Saves the LayerNorm kernel (a 2 KiB read per token) and its launch; reference: norm.py:74-76, layer.py:163.
-    float* C = reinterpret_cast<float*>(p.C);
-    u16* XN = p.xn;
-    float* sf = reinterpret_cast<float*>(stg);                      // [32 rows][64 columns]
-    const int wv = (nw & 511) >> 6;                                 // = the wave index (waves 1 x 8, one tile spans N)
-    float* stats = reinterpret_cast<float*>(stg - (size_t)wv * H16_STG_BYTES + 8 * H16_STG_BYTES);   // behind the 8 slabs: [8 waves][32 rows]
-    const float b0 = p.bias ? p.bias[nw + l31] : 0.f;
-    const float b1 = p.bias ? p.bias[nw + 32 + l31] : 0.f;
-    const int col = (lane & 15) * 4;
-    const float one = p.ln_add_one ? 1.0f : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {                                  // fully unrolled: acc[i] must stay a register index
-      float4 v[8];                                                  // residual rows first (their latency hides behind the LDS transpose)
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        int m = mw + i * 32 + it * 4 + (lane >> 4);
-        m = m < p.M ? m : p.M - 1;
-        v[it] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + nw + col);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        sf[mfma32_crow(r, hi) * 64 + l31] = acc[i][0][r] + b0;
-        sf[mfma32_crow(r, hi) * 64 + 32 + l31] = acc[i][1][r] + b1;
-      }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        const float4 a4 = *reinterpret_cast<const float4*>(sf + row * 64 + col);
-        v[it].x += a4.x; v[it].y += a4.y; v[it].z += a4.z; v[it].w += a4.w;
-        const int m = mw + i * 32 + row;
-        if (m < p.M) *reinterpret_cast<float4*>(C + (size_t)m * p.ldc + nw + col) = v[it];
-        float s = (v[it].x + v[it].y) + (v[it].z + v[it].w);
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if ((lane & 15) == 0) stats[wv * 32 + row] = s;
-      }
-      __syncthreads();
-      float mean[8];
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        float s = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) s += stats[w8 * 32 + row];
-        mean[it] = s * (1.0f / 512.0f);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        const float a = v[it].x - mean[it], b = v[it].y - mean[it], c = v[it].z - mean[it], e = v[it].w - mean[it];
-        float q = (a * a + b * b) + (c * c + e * e);
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-        if ((lane & 15) == 0) stats[wv * 32 + row] = q;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        float q = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) q += stats[w8 * 32 + row];
-        const float rstd = 1.0f / sqrtf(q * (1.0f / 512.0f) + 1e-5f);
-        int m = mw + i * 32 + row;
-        const bool live = m < p.M;
-        m = live ? m : p.M - 1;
-        const long mrow = p.ln_token_row ? (long)p.ln_token_row[m] : 0;
-        const float4 gg = *reinterpret_cast<const float4*>(p.ln_gain + mrow * p.ln_row_stride + nw + col);
-        const float4 bb = *reinterpret_cast<const float4*>(p.ln_shift + mrow * p.ln_row_stride + nw + col);
-        const float ox = (v[it].x - mean[it]) * rstd * (one + gg.x) + bb.x;
-        const float oy = (v[it].y - mean[it]) * rstd * (one + gg.y) + bb.y;
-        const float oz = (v[it].z - mean[it]) * rstd * (one + gg.z) + bb.z;
-        const float ow = (v[it].w - mean[it]) * rstd * (one + gg.w) + bb.w;
-        if (live) *reinterpret_cast<uint2*>(XN + (size_t)m * 512 + nw + col) = h16_pack4<DT>(ox, oy, oz, ow);
-      }
-      __syncthreads();
-    }
-    return;
-  }
   if constexpr (EPI == EPI_H_BIAS_RESID_F32) {
     // (r02 call 39: requesting the residual rows of slab i + 1 while slab i is transposed and stored -- rolling through one register
     // set, or two sets -- pushes this 225-VGPR kernel over 256 and spills in the epilogue: out-projection 0.32 -> 0.33 ms, ff2 unchanged.
@@ -461,630 +376,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent form of the two-stage 256x256 kernel (r02; rap_set_tuning(2, 16), NOT the default until measured): one block per CU
-// walks the output tiles with stride gridDim.x (a multiple of 8, so a block keeps its XCD and xcd_remap keeps its meaning), and the
-// FIRST k-tile of the next output tile is requested at the start of the LAST k-tile of the current one -- into the stage buffer the
-// k-loop has just released -- so that it lands under the last MFMAs and the epilogue instead of in front of an idle matrix pipe
-// (K = 512 is only 8 k-tiles per output tile).  The epilogue's per-wave transposition slabs therefore move out of stage 0: three
-// waves each in A1 and B1 (free once the last k-tile has been read) and two in the 32 KB of LDS beyond the stage buffers.
-// ---------------------------------------------------------------------------------------------
-template <int EPI, int DT>
-__global__ __launch_bounds__(512, 2) void gemm_h16_pers_kernel(GemmParamsH p) {
-  typedef typename H16<DT>::T8 T8;
-  constexpr int WN = 4, TM = 4, TN = 2, NT = 512, BM = 256, BN = 256;
-  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;   // 16-byte chunks per thread per k-tile
-  constexpr int ABYTES = BM * 128, BBYTES = BN * 128;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [A0 A1 B0 B1 | 32 KB of slab space]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-  const int wm = wave / WN, wn = wave % WN;
-  const int nt = p.N / BN;
-  const int mt = (p.M + BM - 1) / BM;
-  const int total = mt * nt;
-  const int nk = p.K / 64;
-  const int sw = (l31 >> 1) & 7;
-  const int a_row = (wm * TM * 32 + l31) * 128;
-  const int b_row = (wn * TN * 32 + l31) * 128;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-  // slab of this wave: waves 0-2 in A1, 3-5 in B1, 6-7 behind the stage buffers
-  const int slab_off = wave < 3 ? ABYTES + wave * H16_STG_BYTES
-                     : wave < 6 ? 2 * ABYTES + BBYTES + (wave - 3) * H16_STG_BYTES
-                                : 2 * ABYTES + 2 * BBYTES + (wave - 6) * H16_STG_BYTES;
-  static_assert(3 * H16_STG_BYTES <= ABYTES && 3 * H16_STG_BYTES <= BBYTES && 2 * H16_STG_BYTES <= 32768, "slab placement");
-
-  const u16* a_src[CA];
-  const u16* w_src[CB];
-  auto set_sources = [&](int tile) {
-    const int logical = xcd_remap(tile, total);
-    const int m0_ = (logical / nt) * BM, n0_ = (logical % nt) * BN;
-#pragma unroll
-    for (int i = 0; i < CA; ++i) {
-      const int id = i * NT + tid;
-      const int row = id >> 3;
-      const int lslot = (id & 7) ^ ((row >> 1) & 7);
-      int r = m0_ + row;
-      r = r < p.M ? r : p.M - 1;
-      a_src[i] = p.A + (size_t)r * p.lda + 8 * lslot;
-    }
-#pragma unroll
-    for (int i = 0; i < CB; ++i) {
-      const int id = i * NT + tid;
-      const int row = id >> 3;
-      const int lslot = (id & 7) ^ ((row >> 1) & 7);
-      w_src[i] = p.W + (size_t)(n0_ + row) * p.ldw + 8 * lslot;
-    }
-  };
-
-  struct Frag { uint4 a[TM]; uint4 b[TN]; };
-  Frag f0, f1;
-  f32x16 acc[TM][TN];
-  auto read_frag = [&](Frag& f, int buf, int g) {
-    const int co = ((2 * g + hi) ^ sw) * 16;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-      f.a[i] = *reinterpret_cast<const uint4*>(smem + buf * ABYTES + a_row + i * 32 * 128 + co);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-      f.b[j] = *reinterpret_cast<const uint4*>(smem + 2 * ABYTES + buf * BBYTES + b_row + j * 32 * 128 + co);
-  };
-  auto mma = [&](const Frag& f) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, f.a[i]), __builtin_bit_cast(T8, f.b[j]), acc[i][j]);
-  };
-
-  int tile = blockIdx.x;
-  if (tile >= total) return;
-  set_sources(tile);
-  HG_DMA(0, 0)
-  for (; tile < total; tile += gridDim.x) {
-    const int logical = xcd_remap(tile, total);
-    const int m0 = (logical / nt) * BM, n0 = (logical % nt) * BN;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    HG_SYNC                                   // k-tile 0 of this tile has landed; the previous tile's slabs are no longer in use
-    read_frag(f0, 0, 0);
-    int kt = 0;
-    for (; kt + 1 < nk; ++kt) {
-      const int cur = kt & 1;
-      HG_DMA(kt + 1, cur ^ 1)
-      read_frag(f1, cur, 1);
-      HG_FENCE
-      mma(f0);
-      HG_FENCE
-      read_frag(f0, cur, 2);
-      HG_FENCE
-      mma(f1);
-      HG_FENCE
-      read_frag(f1, cur, 3);
-      HG_FENCE
-      mma(f0);
-      HG_FENCE
-      HG_SYNC
-      read_frag(f0, cur ^ 1, 0);
-      HG_FENCE
-      mma(f1);
-      HG_FENCE
-    }
-    {
-      const int cur = kt & 1;                 // = 1: nk is even (checked by the launcher), stage 0 is free from here on
-      const int next = tile + (int)gridDim.x;
-      if (next < total) {                     // block-uniform
-        set_sources(next);
-        HG_DMA(0, 0)                          // the next output tile's first k-tile, under the last MFMAs and the epilogue
-      }
-      read_frag(f1, cur, 1);
-      HG_FENCE
-      mma(f0);
-      HG_FENCE
-      read_frag(f0, cur, 2);
-      HG_FENCE
-      mma(f1);
-      HG_FENCE
-      read_frag(f1, cur, 3);
-      HG_FENCE
-      mma(f0);
-      HG_FENCE
-      mma(f1);
-    }
-    __syncthreads();                          // every wave has read the last k-tile: A1 / B1 may become slabs
-    gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + slab_off, m0 + wm * TM * 32, n0 + wn * 64, lane);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <int EPI, int DT>
-static int launch_pers(hipStream_t stream, const GemmParamsH& p) {
-  constexpr int LDS = 2 * (256 + 256) * 128 + 32768;
-  static bool attr_done = false;
-  static int n_cu = 0;
-  auto kern = gemm_h16_pers_kernel<EPI, DT>;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      rap_set_last_hip_error((int)hipGetLastError());
-      return RAP_ERR_HIP;
-    }
-    attr_done = true;
-  }
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RAP_ERR_HIP;
-    n_cu = prop.multiProcessorCount > 8 ? (prop.multiProcessorCount / 8) * 8 : 8;
-  }
-  const int total = ((p.M + 255) / 256) * (p.N / 256);
-  const int grid = total < n_cu ? total : n_cu;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
-  RAP_LAUNCH_CHECK();
-  return RAP_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Ring variants (rap_set_tuning(2, 3 | 4); NOT the default): BK = 32 slices in an LDS ring with NSTAGE - 1 slices in flight
-// (counted s_waitcnt vmcnt, never 0 in the steady state) -- 256x256 / 8 waves / four 32 KB stages, or 256x128 / 4 waves /
-// three 24 KB stages at TWO blocks per CU.
-//
-// Two hypotheses about the two-stage kernel's 28 % of peak on the K = 512 shapes, both measured and rejected on MI355X
-// (profiles/r01_run24-27_gemm_h16_experiments.jsonl): (a) "one 64 KB transfer in flight per CU cannot hide the LDS-DMA latency"
-// -- three slices in flight: 676 vs 727 TF on the qkv shape; (b) "with one block per CU the store-bound epilogue (0.25 of the
-// 0.6 ms: a timing-only build with neither DMA nor MFMA, since removed) never overlaps a k-loop" -- two blocks per CU: 642 TF (50 % more operand traffic
-// at the smaller tile eats the overlap).  PMC on the default kernel: waves spend 37 % parked on s_waitcnt / barriers, 42 % on
-// MFMA issue stalls, LDS bank conflicts 2 %.  Kept selectable, tested, as the A/B evidence.  64-byte LDS rows: bank conflicts of
-// the fragment reads are removed by slot' = slot ^ ((row >> 2) & 3), applied to the DMA source address and the ds_read_b128 address.
-// ---------------------------------------------------------------------------------------------
-template <int EPI, int DT, int WM, int WN, int TM, int NSTAGE>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_h16_ring_kernel(GemmParamsH p) {
-  typedef typename H16<DT>::T8 T8;
-  constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 64 * WN, TN = 2;
-  constexpr int CA = BM * 4 / NT, CB = BN * 4 / NT;      // 16-byte chunks per thread per k-slice (64-byte rows)
-  constexpr int STAGE = (BM + BN) * 64;                  // bytes: [A BM x 64 B][B BN x 64 B]
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-  const int wm = wave / WN, wn = wave % WN;
-
-  const int nt = p.N / BN;
-  const int mt = (p.M + BM - 1) / BM;
-  const int logical = xcd_remap(blockIdx.x, mt * nt);
-  const int m0 = (logical / nt) * BM;
-  const int n0 = (logical % nt) * BN;
-
-  // DMA sources: chunk id = i*NT + tid -> (row = id >> 2, physical slot = id & 3) holds logical slot (slot ^ ((row >> 2) & 3))
-  const u16* a_src[CA];
-  const u16* w_src[CB];
-#pragma unroll
-  for (int i = 0; i < CA; ++i) {
-    const int id = i * NT + tid;
-    const int row = id >> 2;
-    int r = m0 + row;
-    r = r < p.M ? r : p.M - 1;
-    a_src[i] = p.A + (size_t)r * p.lda + 8 * ((id & 3) ^ ((row >> 2) & 3));
-  }
-#pragma unroll
-  for (int i = 0; i < CB; ++i) {
-    const int id = i * NT + tid;
-    const int row = id >> 2;
-    w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + 8 * ((id & 3) ^ ((row >> 2) & 3));
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / 32;
-  const int sw = (l31 >> 2) & 3;
-  const int a_row = (wm * TM * 32 + l31) * 64;
-  const int b_row = BM * 64 + (wn * TN * 32 + l31) * 64;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-#define HR_DMA(KT, SLOT)                                                                                      \
-  {                                                                                                           \
-    const unsigned sb_ = lds_wave + (unsigned)((SLOT) * STAGE);                                               \
-    _Pragma("unroll") for (int i = 0; i < CA; ++i) HG_DMA1(a_src[i] + (size_t)(KT) * 32, sb_ + (unsigned)(i * NT * 16))          \
-    _Pragma("unroll") for (int i = 0; i < CB; ++i) HG_DMA1(w_src[i] + (size_t)(KT) * 32, sb_ + (unsigned)(BM * 64 + i * NT * 16)) \
-  }
-  // "at most D younger slices outstanding": D * (CA + CB) transfers
-#define HR_WAIT(D)                                                                                            \
-  if constexpr ((D) * (CA + CB) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
-  else if constexpr ((D) * (CA + CB) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   \
-  else if constexpr ((D) * (CA + CB) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                   \
-  else if constexpr ((D) * (CA + CB) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                   \
-  else if constexpr ((D) * (CA + CB) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 \
-  else static_assert((D) * (CA + CB) == 0, "add the vmcnt literal");
-
-#pragma unroll
-  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-    if (s0 < nk) HR_DMA(s0, s0)
-
-  int slot = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // slice kt has landed once at most the transfers of the younger in-flight slices are outstanding
-    const int younger = nk - 1 - kt < NSTAGE - 2 ? nk - 1 - kt : NSTAGE - 2;
-    if (younger >= 2) { HR_WAIT(NSTAGE >= 4 ? 2 : 0) }
-    else if (younger == 1) { HR_WAIT(NSTAGE >= 3 ? 1 : 0) }
-    else { HR_WAIT(0) }
-    __syncthreads();                         // slice kt visible to every wave; every wave is done with slice kt-1 -> its stage is free
-    int free_slot = slot - 1; free_slot = free_slot < 0 ? NSTAGE - 1 : free_slot;
-    if (kt + NSTAGE - 1 < nk) HR_DMA(kt + NSTAGE - 1, free_slot)
-    const unsigned char* st = smem + slot * STAGE;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int co = ((2 * g + hi) ^ sw) * 16;
-      uint4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(st + a_row + i * 32 * 64 + co);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(st + b_row + j * 32 * 64 + co);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, fa[i]), __builtin_bit_cast(T8, fb[j]), acc[i][j]);
-    }
-    slot = slot + 1 == NSTAGE ? 0 : slot + 1;
-  }
-  static_assert(WM * WN * H16_STG_BYTES <= NSTAGE * STAGE, "staging slabs must fit the operand ring");
-  __syncthreads();
-  gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Pipelined ring (r02; rap_set_tuning(2, 6 | 7 | 8)): what r02 call 1 measured about the default kernel -- L2 counters
-// (profiles/r02_c1_gemm_h16_l2_counters.txt): the A operand is fetched from the fabric about ONCE (TCC_EA0_RDREQ x 128 B = operand
-// bytes), i.e. the sibling n-tiles do hit the L2; the same-line requests of the CUs of one XCD merge (ldsdma_fill --shared:
-// 99-130 GB/s per CU for a window shared in lockstep vs 26 private).  So the fabric is not saturated; what the two-stage loop
-// cannot hide is the LATENCY of the first-touch fetch: every k-tile of every block (and of its lockstep siblings) waits for one
-// (a 64 KB batch drained before the next: 1.05 us from beyond the L2 vs 0.6 us L2-resident, against 0.85 us of MFMA work).
-// This variant keeps NSTAGE - 1 slices of BK = 32 in flight (5 x 32 KB = all 160 KB of the LDS: a slice is waited for three
-// slice-times after it was issued), and -- unlike the ring above -- keeps the fragment reads software-pipelined ACROSS the slice
-// barrier (the barrier sits in front of the slice's last MFMA group, the first fragments of the next slice are read behind it).
-// ---------------------------------------------------------------------------------------------
-template <int EPI, int DT, int WM, int WN, int TM, int NSTAGE, int PRIO>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_h16_pipe_kernel(GemmParamsH p) {
-  typedef typename H16<DT>::T8 T8;
-  constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 64 * WN, TN = 2;
-  constexpr int CA = BM * 4 / NT, CB = BN * 4 / NT;      // 16-byte chunks per thread per k-slice (64-byte rows)
-  constexpr int STAGE = (BM + BN) * 64;                  // bytes: [A BM x 64 B][B BN x 64 B]
-  constexpr int NDMA = CA + CB;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-  const int wm = wave / WN, wn = wave % WN;
-
-  const int nt = p.N / BN;
-  const int mt = (p.M + BM - 1) / BM;
-  const int logical = xcd_remap(blockIdx.x, mt * nt);
-  const int m0 = (logical / nt) * BM;
-  const int n0 = (logical % nt) * BN;
-
-  const u16* a_src[CA];
-  const u16* w_src[CB];
-#pragma unroll
-  for (int i = 0; i < CA; ++i) {
-    const int id = i * NT + tid;
-    const int row = id >> 2;
-    int r = m0 + row;
-    r = r < p.M ? r : p.M - 1;
-    a_src[i] = p.A + (size_t)r * p.lda + 8 * ((id & 3) ^ ((row >> 2) & 3));
-  }
-#pragma unroll
-  for (int i = 0; i < CB; ++i) {
-    const int id = i * NT + tid;
-    const int row = id >> 2;
-    w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + 8 * ((id & 3) ^ ((row >> 2) & 3));
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / 32;
-  const int sw = (l31 >> 2) & 3;
-  const int a_row = (wm * TM * 32 + l31) * 64;
-  const int b_row = BM * 64 + (wn * TN * 32 + l31) * 64;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-#define HP_DMA(KT, SLOT)                                                                                      \
-  {                                                                                                           \
-    const unsigned sb_ = lds_wave + (unsigned)((SLOT) * STAGE);                                               \
-    _Pragma("unroll") for (int i = 0; i < CA; ++i) HG_DMA1(a_src[i] + (size_t)(KT) * 32, sb_ + (unsigned)(i * NT * 16))          \
-    _Pragma("unroll") for (int i = 0; i < CB; ++i) HG_DMA1(w_src[i] + (size_t)(KT) * 32, sb_ + (unsigned)(BM * 64 + i * NT * 16)) \
-  }
-  // "at most Y younger slices outstanding"
-#define HP_WAIT(Y)                                                                                            \
-  if constexpr ((Y) * NDMA == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             \
-  else if constexpr ((Y) * NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                        \
-  else if constexpr ((Y) * NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                        \
-  else if constexpr ((Y) * NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                      \
-  else static_assert((Y) * NDMA == 0, "add the vmcnt literal");
-  static_assert(NSTAGE >= 3 && NSTAGE <= 5, "ring depth");
-
-  struct Frag { uint4 a[TM]; uint4 b[TN]; };
-  Frag f0, f1;
-  auto read_frag = [&](Frag& f, int slot, int g) {
-    const unsigned char* st = smem + slot * STAGE;
-    const int co = ((2 * g + hi) ^ sw) * 16;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const uint4*>(st + a_row + i * 32 * 64 + co);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const uint4*>(st + b_row + j * 32 * 64 + co);
-  };
-  auto mma = [&](const Frag& f) {
-    if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, f.a[i]), __builtin_bit_cast(T8, f.b[j]), acc[i][j]);
-    if (PRIO) __builtin_amdgcn_s_setprio(0);
-  };
-
-  // prologue: NSTAGE - 1 slices in flight, wait for the first one only
-#pragma unroll
-  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-    if (s0 < nk) HP_DMA(s0, s0)
-  {
-    const int younger = nk - 1 < NSTAGE - 2 ? nk - 1 : NSTAGE - 2;
-    if (younger >= 3) { HP_WAIT(NSTAGE >= 5 ? 3 : 0) }
-    else if (younger == 2) { HP_WAIT(NSTAGE >= 4 ? 2 : 0) }
-    else if (younger == 1) { HP_WAIT(1) }
-    else { HP_WAIT(0) }
-  }
-  __syncthreads();
-  read_frag(f0, 0, 0);
-
-  int slot = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    read_frag(f1, slot, 1);
-    HG_FENCE
-    mma(f0);
-    HG_FENCE
-    int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
-    if (kt + 1 < nk) {
-      // slice kt+1 must have landed; the slices issued after it (kt+2 .. kt+NSTAGE-2) may stay in flight
-      const int younger = nk - 2 - kt < NSTAGE - 3 ? nk - 2 - kt : NSTAGE - 3;
-      if (younger >= 2) { HP_WAIT(NSTAGE >= 5 ? 2 : 0) }
-      else if (younger == 1) { HP_WAIT(NSTAGE >= 4 ? 1 : 0) }
-      else { HP_WAIT(0) }
-      __syncthreads();      // slice kt+1 visible to every wave; every wave has consumed slice kt-1 -> its stage is free
-      int free_slot = slot - 1; free_slot = free_slot < 0 ? NSTAGE - 1 : free_slot;
-      if (kt + NSTAGE - 1 < nk) HP_DMA(kt + NSTAGE - 1, free_slot)
-      read_frag(f0, nslot, 0);
-      HG_FENCE
-    }
-    mma(f1);
-    HG_FENCE
-    slot = nslot;
-  }
-  static_assert(WM * WN * H16_STG_BYTES <= NSTAGE * STAGE, "staging slabs must fit the operand ring");
-  __syncthreads();
-  gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
-}
-
-template <int EPI, int DT, int WM, int WN, int TM, int NSTAGE, int PRIO>
-static int launch_pipe(hipStream_t stream, const GemmParamsH& p) {
-  constexpr int BM = 32 * TM * WM, BN = 64 * WN;
-  constexpr int LDS = NSTAGE * (BM + BN) * 64;
-  static bool attr_done = false;
-  auto kern = gemm_h16_pipe_kernel<EPI, DT, WM, WN, TM, NSTAGE, PRIO>;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      rap_set_last_hip_error((int)hipGetLastError());
-      return RAP_ERR_HIP;
-    }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(((p.M + BM - 1) / BM) * (p.N / BN)), dim3(64 * WM * WN), LDS, stream, p);
-  RAP_LAUNCH_CHECK();
-  return RAP_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Interleaved ring (r02; rap_set_tuning(2, 9 | 10 | 11)).  r02 calls 2 / 3: neither a deeper ring (variants 6-8: same speed as the
-// two-stage loop) nor padded row strides (no L2 channel camping) move the k-loop, so the DMA's cost is not latency and not
-// bandwidth: it is ISSUE -- a wave that issues its 4-8 LDS-DMA pieces back to back right after the barrier sits in the in-order
-// issue stage while the TA queue drains (60-185 cycles per piece, MI355X_MICROARCH.md), and both waves of every SIMD do so at
-// the same time, so the matrix pipe idles.  Here every DMA piece and every fragment read is issued singly in the shadow of an
-// MFMA: per 32-wide slice a wave issues 16 MFMAs, 12 ds_read_b128 and 4 DMA pieces as  M r M r M r D M r ...; the order is
-// pinned with sched_barrier(0).  STAGGER: the two wave rows (which share the SIMDs pairwise) issue their DMA pieces in
-// different halves of the slice.
-// ---------------------------------------------------------------------------------------------
-template <int EPI, int DT, int NSTAGE, int PRIO, int STAGGER>
-__global__ __launch_bounds__(512, 2) void gemm_h16_il_kernel(GemmParamsH p) {
-  typedef typename H16<DT>::T8 T8;
-  constexpr int WM = 2, WN = 4, TM = 4, TN = 2;
-  constexpr int NT = 512, BM = 256, BN = 256;
-  constexpr int STAGE = (BM + BN) * 64;                  // bytes: [A BM x 64 B][B BN x 64 B]
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-  const int wm = wave / WN, wn = wave % WN;
-
-  const int nt = p.N / BN;
-  const int mt = (p.M + BM - 1) / BM;
-  const int logical = xcd_remap(blockIdx.x, mt * nt);
-  const int m0 = (logical / nt) * BM;
-  const int n0 = (logical % nt) * BN;
-
-  // 4 DMA pieces per thread per slice: pieces 0,1 = A rows, 2,3 = W rows (chunk id = i*NT + tid -> row id >> 2, slot id & 3)
-  const u16* src[4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int id = i * NT + tid;
-    const int row = id >> 2;
-    int r = m0 + row;
-    r = r < p.M ? r : p.M - 1;
-    src[i] = p.A + (size_t)r * p.lda + 8 * ((id & 3) ^ ((row >> 2) & 3));
-    src[2 + i] = p.W + (size_t)(n0 + row) * p.ldw + 8 * ((id & 3) ^ ((row >> 2) & 3));
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / 32;
-  const int sw = (l31 >> 2) & 3;
-  const int a_row = (wm * TM * 32 + l31) * 64;
-  const int b_row = BM * 64 + (wn * TN * 32 + l31) * 64;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
-  // piece i of slice KT into stage SLOT
-#define HI_PIECE(I, KT, SLOT) \
-  HG_DMA1(src[I] + (size_t)(KT) * 32, lds_wave + (unsigned)((SLOT) * STAGE + ((I) >> 1) * (BM * 64) + ((I) & 1) * (NT * 16)))
-#define HI_WAIT(Y)                                                                                            \
-  if constexpr ((Y) * 4 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
-  else if constexpr ((Y) * 4 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                           \
-  else if constexpr ((Y) * 4 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                           \
-  else if constexpr ((Y) * 4 == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                        \
-  else static_assert((Y) * 4 == 0, "add the vmcnt literal");
-#define HI_SB __builtin_amdgcn_sched_barrier(0);
-  static_assert(NSTAGE >= 4 && NSTAGE <= 5, "ring depth");
-
-  uint4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-  // fragment piece q of a 6-piece set: 0,1 = b[0], b[1]; 2..5 = a[0..3]  (the order the MFMAs need them)
-  auto read_piece = [&](uint4 (&fa)[TM], uint4 (&fb)[TN], int slot, int g, int q) {
-    const unsigned char* st = smem + slot * STAGE;
-    const int co = ((2 * g + hi) ^ sw) * 16;
-    if (q < 2) fb[q] = *reinterpret_cast<const uint4*>(st + b_row + q * 32 * 64 + co);
-    else fa[q - 2] = *reinterpret_cast<const uint4*>(st + a_row + (q - 2) * 32 * 64 + co);
-  };
-#define HI_MMA(FA, FB, I, J) acc[I][J] = H16<DT>::mfma(__builtin_bit_cast(T8, FA[I]), __builtin_bit_cast(T8, FB[J]), acc[I][J]);
-
-  // prologue: NSTAGE - 1 slices in flight, wait for the first one only
-#pragma unroll
-  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-    if (s0 < nk) { HI_PIECE(0, s0, s0) HI_PIECE(1, s0, s0) HI_PIECE(2, s0, s0) HI_PIECE(3, s0, s0) }
-  {
-    const int younger = nk - 1 < NSTAGE - 2 ? nk - 1 : NSTAGE - 2;
-    if (younger >= 3) { HI_WAIT(NSTAGE >= 5 ? 3 : 0) }
-    else if (younger == 2) { HI_WAIT(2) }
-    else if (younger == 1) { HI_WAIT(1) }
-    else { HI_WAIT(0) }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 6; ++q) read_piece(fa0, fb0, 0, 0, q);
-
-  int slot = 0;
-  // the refill of the stage freed at the barrier of iteration kt (slice kt + NSTAGE - 1) is issued piece by piece: STAGGER = 0:
-  // pieces 0,1 behind that barrier, 2,3 in the first half of iteration kt + 1; STAGGER = 1: wave row 1 issues all four in the
-  // second half (behind the barrier), wave row 0 all four in the first half of the next iteration.
-  bool pend = false; int pend_kt = 0, pend_slot = 0;
-  const bool early = STAGGER ? (wm == 1) : true;      // issues pieces 0,1 (or all) right behind the barrier
-  for (int kt = 0; kt < nk; ++kt) {
-    // ---- first half: MFMAs of k-step 0, reads of k-step 1, late DMA pieces of the previous refill
-    if (PRIO) __builtin_amdgcn_s_setprio(1);
-    HI_MMA(fa0, fb0, 0, 0) HI_SB read_piece(fa1, fb1, slot, 1, 0); HI_SB
-    HI_MMA(fa0, fb0, 0, 1) HI_SB read_piece(fa1, fb1, slot, 1, 1); HI_SB
-    HI_MMA(fa0, fb0, 1, 0) HI_SB read_piece(fa1, fb1, slot, 1, 2); HI_SB
-    if (pend && (!STAGGER || !early)) { if (STAGGER) { HI_PIECE(0, pend_kt, pend_slot) } else { HI_PIECE(2, pend_kt, pend_slot) } }
-    HI_SB
-    HI_MMA(fa0, fb0, 1, 1) HI_SB read_piece(fa1, fb1, slot, 1, 3); HI_SB
-    if (pend && STAGGER && !early) { HI_PIECE(1, pend_kt, pend_slot) }
-    HI_SB
-    HI_MMA(fa0, fb0, 2, 0) HI_SB read_piece(fa1, fb1, slot, 1, 4); HI_SB
-    if (pend && STAGGER && !early) { HI_PIECE(2, pend_kt, pend_slot) }
-    HI_SB
-    HI_MMA(fa0, fb0, 2, 1) HI_SB read_piece(fa1, fb1, slot, 1, 5); HI_SB
-    HI_MMA(fa0, fb0, 3, 0) HI_SB
-    if (pend && (!STAGGER || !early)) { HI_PIECE(3, pend_kt, pend_slot) }
-    HI_SB
-    HI_MMA(fa0, fb0, 3, 1) HI_SB
-    if (PRIO) __builtin_amdgcn_s_setprio(0);
-    pend = false;
-    const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
-    const bool more = kt + 1 < nk;
-    if (more) {
-      // slice kt+1 must have landed; the slices issued after it (kt+2 .. kt+NSTAGE-2) may stay in flight
-      const int younger = nk - 2 - kt < NSTAGE - 3 ? nk - 2 - kt : NSTAGE - 3;
-      if (younger >= 2) { HI_WAIT(NSTAGE >= 5 ? 2 : 0) }
-      else if (younger == 1) { HI_WAIT(1) }
-      else { HI_WAIT(0) }
-      __syncthreads();      // slice kt+1 visible to every wave; every wave has consumed slice kt-1 -> its stage is free
-      if (kt + NSTAGE - 1 < nk) { pend = true; pend_kt = kt + NSTAGE - 1; pend_slot = slot - 1 < 0 ? NSTAGE - 1 : slot - 1; }
-    }
-    // ---- second half: MFMAs of k-step 1, first fragments of the next slice, early DMA pieces of the refill
-    const bool issue_now = pend && early;
-    if (PRIO) __builtin_amdgcn_s_setprio(1);
-    HI_MMA(fa1, fb1, 0, 0) HI_SB if (more) read_piece(fa0, fb0, nslot, 0, 0); HI_SB
-    HI_MMA(fa1, fb1, 0, 1) HI_SB if (more) read_piece(fa0, fb0, nslot, 0, 1); HI_SB
-    if (issue_now) { HI_PIECE(0, pend_kt, pend_slot) }
-    HI_SB
-    HI_MMA(fa1, fb1, 1, 0) HI_SB if (more) read_piece(fa0, fb0, nslot, 0, 2); HI_SB
-    HI_MMA(fa1, fb1, 1, 1) HI_SB if (more) read_piece(fa0, fb0, nslot, 0, 3); HI_SB
-    if (issue_now && STAGGER) { HI_PIECE(1, pend_kt, pend_slot) }
-    HI_SB
-    HI_MMA(fa1, fb1, 2, 0) HI_SB if (more) read_piece(fa0, fb0, nslot, 0, 4); HI_SB
-    if (issue_now) { if (STAGGER) { HI_PIECE(2, pend_kt, pend_slot) } else { HI_PIECE(1, pend_kt, pend_slot) } }
-    HI_SB
-    HI_MMA(fa1, fb1, 2, 1) HI_SB if (more) read_piece(fa0, fb0, nslot, 0, 5); HI_SB
-    HI_MMA(fa1, fb1, 3, 0) HI_SB
-    if (issue_now && STAGGER) { HI_PIECE(3, pend_kt, pend_slot) }
-    HI_SB
-    HI_MMA(fa1, fb1, 3, 1) HI_SB
-    if (PRIO) __builtin_amdgcn_s_setprio(0);
-    if (issue_now && STAGGER) pend = false;
-    slot = nslot;
-  }
-  static_assert(WM * WN * H16_STG_BYTES <= NSTAGE * STAGE, "staging slabs must fit the operand ring");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
-}
-
-template <int EPI, int DT, int NSTAGE, int PRIO, int STAGGER>
-static int launch_il(hipStream_t stream, const GemmParamsH& p) {
-  constexpr int LDS = NSTAGE * 512 * 64;
-  static bool attr_done = false;
-  auto kern = gemm_h16_il_kernel<EPI, DT, NSTAGE, PRIO, STAGGER>;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      rap_set_last_hip_error((int)hipGetLastError());
-      return RAP_ERR_HIP;
-    }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(((p.M + 255) / 256) * (p.N / 256)), dim3(512), LDS, stream, p);
-  RAP_LAUNCH_CHECK();
-  return RAP_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Phase-split kernel (r02; rap_set_tuning(2, 13 | 14 | 15)).  r02 calls 2-4 reproduce what the CDNA4 guide says about this
 // structure class: every loop with ONE barrier per k-slice in which all eight waves stage, read and multiply in lockstep lands at
 // the same 800-870 TF on the K = 2048 shape -- deeper rings (6-8), padded rows (no channel camping), one-piece-at-a-time issue
@@ -1240,56 +531,33 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
 template <int EPI, int DT, int PRIO, int STAG>
 static int launch_ph(hipStream_t stream, const GemmParamsH& p) {
   constexpr int LDS = 4 * 256 * 128;
-  static bool attr_done = false;
   auto kern = gemm_h16_ph_kernel<EPI, DT, PRIO, STAG>;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      rap_set_last_hip_error((int)hipGetLastError());
-      return RAP_ERR_HIP;
-    }
-    attr_done = true;
+  // per device and cheap: set unconditionally (a process may drive several GPUs)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    rap_set_last_hip_error((int)hipGetLastError());
+    return RAP_ERR_HIP;
   }
   hipLaunchKernelGGL(kern, dim3(((p.M + 255) / 256) * (p.N / 256)), dim3(512), LDS, stream, p);
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }
 
-// tuning knob (rap_set_tuning key 2): 0 = 128x128 tile, 4 waves, two blocks per CU; 1 = 256x256 tile, 8 waves
-// (wave tile 128x64), two 64 KB stages (the default); 2 = 256x128 tile, 8 waves (wave tile 64x64); 3 = 256x256 ring of four 32 KB stages,
-// one block per CU; 4 = 256x128 ring (4 waves of 128x64, three 24 KB stages, TWO blocks per CU: one block's epilogue and
-// barrier stalls are covered by the other's k-loop).
-rap_tuning_t g_rap_gemm_h16_variant = 14;    // r02 default: phase-split kernel (measured +4 % on ff1 / ff2 over the two-stage 256x256 kernel = 1, equal elsewhere)
-
-template <int EPI, int DT, int WM, int WN, int TM, int NSTAGE>
-static int launch_ring(hipStream_t stream, const GemmParamsH& p) {
-  constexpr int BM = 32 * TM * WM, BN = 64 * WN;
-  constexpr int LDS = NSTAGE * (BM + BN) * 64;
-  static bool attr_done = false;
-  auto kern = gemm_h16_ring_kernel<EPI, DT, WM, WN, TM, NSTAGE>;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      rap_set_last_hip_error((int)hipGetLastError());
-      return RAP_ERR_HIP;
-    }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(((p.M + BM - 1) / BM) * (p.N / BN)), dim3(64 * WM * WN), LDS, stream, p);
-  RAP_LAUNCH_CHECK();
-  return RAP_OK;
-}
+// Kernel choice (round 3: the fifteen other main loops of rounds 1-2 -- rings, pipelined rings, interleaved issue, persistent,
+// 128 x 512 -- all measured within +-4 % of this one and are gone from the tree; their source and numbers are in the history at
+// 72efb73 and in DESIGN.md section 4.3).  Default: the phase-split 256 x 256 kernel.  Fallback for shapes it cannot tile
+// (N % 256 != 0 or K < 128) and for few-row calls: the two-stage 128 x 128 kernel, two blocks per CU.
+// RAP_ABLATION_BUILD only: rap_set_tuning(2, 0) forces the 128 x 128 kernel, (2, 1) the two-stage 256 x 256 kernel.
+rap_tuning_t g_rap_gemm_h16_variant = 14;
 
 template <int EPI, int DT, int WM, int WN, int TM, int TN>
 static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int LDS = 2 * (BM + BN) * 128;
-  static bool attr_done = false;
   auto kern = gemm_h16_kernel<EPI, DT, WM, WN, TM, TN>;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      rap_set_last_hip_error((int)hipGetLastError());
-      return RAP_ERR_HIP;
-    }
-    attr_done = true;
+  // per device and cheap: set unconditionally (a process may drive several GPUs)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    rap_set_last_hip_error((int)hipGetLastError());
+    return RAP_ERR_HIP;
   }
   const int mt = (p.M + BM - 1) / BM;
   hipLaunchKernelGGL(kern, dim3(mt * (p.N / BN)), dim3(64 * WM * WN), LDS, stream, p);
@@ -1299,31 +567,12 @@ static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
 
 template <int EPI, int DT>
 static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
-  const int v = g_rap_gemm_h16_variant;
-  if (v == 4) return launch_ring<EPI, DT, 2, 2, 4, 3>(stream, p);
-  // 6 / 7 / 8 (r02): pipelined ring, 256x256, five 32 KB stages (6), + s_setprio around the MFMA groups (7), four stages (8)
-  // 13 / 14 / 15 (r02): phase-split kernel: staggered wave rows + setprio (13), staggered without setprio (14), lockstep + setprio (15)
-  if constexpr (EPI == EPI_H_BIAS || EPI == EPI_H_BIAS_RESID_F32 || EPI == EPI_H_GEGLU) {
-    if (v == 16 && p.N % 256 == 0 && p.K >= 128 && (p.K / 64) % 2 == 0) return launch_pers<EPI, DT>(stream, p);
-  }
-  if (v == 16 && p.N % 256 == 0 && p.K >= 128) return launch_ph<EPI, DT, 0, 1>(stream, p);      // epilogues without a persistent form: the default
-  if (v == 13 && p.N % 256 == 0 && p.K >= 128) return launch_ph<EPI, DT, 1, 1>(stream, p);
-  if (v == 14 && p.N % 256 == 0 && p.K >= 128) return launch_ph<EPI, DT, 0, 1>(stream, p);
-  if (v == 15 && p.N % 256 == 0 && p.K >= 128) return launch_ph<EPI, DT, 1, 0>(stream, p);
-  // 9 / 10 / 11 (r02): interleaved issue (one DMA piece / fragment read per MFMA shadow), four stages; + setprio; + staggered wave rows
-  if (v == 9 && p.N % 256 == 0) return launch_il<EPI, DT, 4, 0, 0>(stream, p);
-  if (v == 10 && p.N % 256 == 0) return launch_il<EPI, DT, 4, 1, 0>(stream, p);
-  if (v == 11 && p.N % 256 == 0) return launch_il<EPI, DT, 4, 0, 1>(stream, p);
-  if (v == 12 && p.N % 256 == 0) return launch_il<EPI, DT, 5, 0, 1>(stream, p);
-  if (v == 6 && p.N % 256 == 0) return launch_pipe<EPI, DT, 2, 4, 4, 5, 0>(stream, p);
-  if (v == 7 && p.N % 256 == 0) return launch_pipe<EPI, DT, 2, 4, 4, 5, 1>(stream, p);
-  if (v == 8 && p.N % 256 == 0) return launch_pipe<EPI, DT, 2, 4, 4, 4, 0>(stream, p);
-  if (v == 3 && p.N % 256 == 0) return launch_ring<EPI, DT, 2, 4, 4, 4>(stream, p);
-  // 5 (opt-in, r01 run 56/57 analysis): 128 x 512 block tile, waves 1 x 8 -- the operand streamed from beyond L2 (A) is the SMALL
-  // side of the tile (16 KB per k-tile instead of 32), the L2-hot weights the large one; all 160 KiB of the LDS.
-  if (v == 5 && p.N % 512 == 0) return launch_cfg<EPI, DT, 1, 8, 4, 2>(stream, p);
-  if ((v == 1 || v == 3 || v >= 5) && p.N % 256 == 0) return launch_cfg<EPI, DT, 2, 4, 4, 2>(stream, p);
-  if (v == 2) return launch_cfg<EPI, DT, 4, 2, 2, 2>(stream, p);
+  const bool big = p.N % 256 == 0 && p.K >= 128;
+#ifdef RAP_ABLATION_BUILD
+  if (g_rap_gemm_h16_variant == 0) return launch_cfg<EPI, DT, 2, 2, 2, 2>(stream, p);
+  if (g_rap_gemm_h16_variant == 1 && big) return launch_cfg<EPI, DT, 2, 4, 4, 2>(stream, p);
+#endif
+  if (big && p.M > 128) return launch_ph<EPI, DT, 0, 1>(stream, p);
   return launch_cfg<EPI, DT, 2, 2, 2, 2>(stream, p);
 }
 
@@ -1333,9 +582,6 @@ static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
     case EPI_H_BIAS: return launch_variant<EPI_H_BIAS, DT>(stream, p);
     case EPI_H_BIAS_RESID_F32: return launch_variant<EPI_H_BIAS_RESID_F32, DT>(stream, p);
     case EPI_H_GEGLU: return launch_variant<EPI_H_GEGLU, DT>(stream, p);
-    case EPI_H_RESID_LN:
-      if (p.N != 512 || !p.resid || !p.xn || !p.ln_gain || !p.ln_shift || (p.ldc & 3) || (p.ldr & 3)) return RAP_ERR_INVALID;
-      return launch_cfg<EPI_H_RESID_LN, DT, 1, 8, 4, 2>(stream, p);
     case EPI_H_QKV_NORM:
       if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256 || !p.gamma_q || !p.gamma_k || p.K < 128) return RAP_ERR_INVALID;
       return launch_ph<EPI_H_QKV_NORM, DT, 0, 1>(stream, p);

@@ -109,8 +109,6 @@ enum GemmEpilogueH {
   EPI_H_BIAS_RESID_F32 = 1,  // C fp32 (M,N) = (resid +) acc (+ bias[n])      (resid may alias C)
   EPI_H_GEGLU = 3,           // W rows pre-interleaved [32 value | 32 gate]: C half (M,N/2) = (h + bh) * gelu_erf(g + bg)
   EPI_H_QKV = 4,             // N = 3*H*64: q,k -> C half [2][H][M][64]; v -> vt half [H][vt_nblk][64 d][64 pos] (half.h vt_pos)
-  EPI_H_RESID_LN = 6,        // EPI_H_BIAS_RESID_F32 on full rows (N = 512 = the tile width) + the NEXT LayerNorm fused: C fp32 = resid + acc + bias,
-                             // xn half (M,N) = LN(C) * (add_one + gain) + shift  (adaLN modulation or affine, as launch_layernorm_*_h16)
   EPI_H_QKV_NORM = 5,        // EPI_H_QKV with MultiHeadRMSNorm (norm.py:28-33) fused: q,k rows are normalised from the fp32 accumulators,
                              // multiplied by gamma and by q_mul / 8 before the single rounding to 16 bit (phase-split kernel only)
 };
@@ -124,8 +122,6 @@ struct GemmParamsH {
   int heads;
   uint16_t* vt; int vt_nblk;
   const float* gamma_q = nullptr; const float* gamma_k = nullptr; float q_mul = 8.0f;   // EPI_H_QKV_NORM
-  uint16_t* xn = nullptr; const float* ln_gain = nullptr; const float* ln_shift = nullptr;   // EPI_H_RESID_LN
-  long ln_row_stride = 0; const int32_t* ln_token_row = nullptr; int ln_add_one = 0;
 };
 int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p);
 int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t* dst, size_t n);

@@ -384,11 +384,10 @@ static int launch_spin_conv_cfg(hipStream_t stream, const SpinConvParams& p, boo
   constexpr int LDS = 2 * (BM + BN) * 32 * 4;
   auto k1 = spin_conv3x3_kernel<WM, WN, TN, 1>;
   auto k0 = spin_conv3x3_kernel<WM, WN, TN, 0>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
+  // per device and cheap: set on every launch (a process may drive several GPUs), return code checked
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(relu ? k1 : k0), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    rap_set_last_hip_error((int)hipGetLastError());
+    return RAP_ERR_HIP;
   }
   const unsigned grid = (unsigned)((p.M + BM - 1) / BM);
   if (relu) hipLaunchKernelGGL(k1, dim3(grid), dim3(256), LDS, stream, p);
@@ -411,8 +410,10 @@ int launch_spin_conv3d(hipStream_t stream, const float* x0, const float* Wt448, 
   if (M <= 0) return RAP_OK;
   constexpr int LDS = 2 * (256 + 64) * 32 * 4;
   auto kern = spin_conv3x3_kernel<4, 1, 2, 1, 1>;
-  static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_done = true; }
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    rap_set_last_hip_error((int)hipGetLastError());
+    return RAP_ERR_HIP;
+  }
   SpinConvParams p{x0, 16, 16, Wt448, bias, zeros, out, 64, M};
   hipLaunchKernelGGL(kern, dim3((unsigned)((M + 255) / 256)), dim3(256), LDS, stream, p);
   RAP_LAUNCH_CHECK();

@@ -20,7 +20,7 @@ from .flow_model import PointCloudDiT, _f32c, _require_cuda, workspace
 def shard_cuts(cu_seqlens_host, n_shards: int) -> list[int]:
     """Sample indices [0, b_1, ..., B] that cut a packed batch (``cu_seqlens_host``: B+1 token offsets) into at most ``n_shards``
     contiguous, non-empty shards of about equal TOKEN count: cut k is the sample boundary closest to k/n of the tokens, leaving at
-    least one sample for every later shard."""
+    least one sample for every later shard; no shard is left without tokens (samples without points join a neighbour)."""
     B = len(cu_seqlens_host) - 1
     n = max(1, min(int(n_shards), B))
     TP = cu_seqlens_host[-1] - cu_seqlens_host[0]
@@ -32,7 +32,16 @@ def shard_cuts(cu_seqlens_host, n_shards: int) -> list[int]:
             break
         cuts.append(min(cand, key=lambda i: abs(cu_seqlens_host[i] - target)))
     cuts.append(B)
-    return cuts
+    # a sample may hold zero points (all parts empty): a shard made only of such samples would be a zero-token rap_sample call,
+    # which the library refuses -- merge it into its left neighbour (the last one into its right one)
+    keep = [0]
+    for c in cuts[1:-1]:
+        if cu_seqlens_host[c] > cu_seqlens_host[keep[-1]]:
+            keep.append(c)
+    if len(keep) > 1 and cu_seqlens_host[B] == cu_seqlens_host[keep[-1]]:
+        keep.pop()
+    keep.append(B)
+    return keep
 
 
 class RectifiedPointFlow:
@@ -55,16 +64,18 @@ class RectifiedPointFlow:
         self.rigidity_forcing = rigidity_forcing
         self.return_end_point_trajectory = return_end_point_trajectory
         self.last_poses = None
-        # the reference asserts the batch layout in split_parts (utils/point_clouds.py:33-52) -- with a host sync per call; here
-        # the check is a device kernel + one 4-byte read, off by default (RAP_VALIDATE_INPUTS=1 or validate_inputs=True turns it on)
-        self.validate_inputs = (os.environ.get("RAP_VALIDATE_INPUTS") == "1") if validate_inputs is None else bool(validate_inputs)
+        # the reference asserts the batch layout in split_parts (utils/point_clouds.py:33-52, 41-44) on every call; here the check is
+        # one tiny device kernel + one 4-byte read per call, ON by default since round 3 (a malformed points_per_part must not yield
+        # wrong poses silently).  RAP_VALIDATE_INPUTS=0 / validate_inputs=False turn it off (a latency-critical caller that has
+        # validated its batches itself); it is skipped while the stream is being captured into a HIP graph (a capture cannot read
+        # back), where rap_sample's clamping of the part table still rules out out-of-bounds reads.
+        self.validate_inputs = (os.environ.get("RAP_VALIDATE_INPUTS", "1") != "0") if validate_inputs is None else bool(validate_inputs)
         # Concurrent batch shards (opt-in, num_streams > 1): samples are independent, so a batch can be run as contiguous shards on
-        # several HIP streams.  MEASURED (r02 call 44, 32 pairs x 2 x 4096, product path, results bit-identical): bf16 2 421 ms on one
-        # stream, 2 408 / 2 394 / 2 396 ms on 2 / 3 / 4; fp16 and fp32 +-0.3 % -- every kernel already fills the chip, nothing is left
-        # for a second stream to overlap with.  (A first experiment that showed +16 % had both shards in ONE scratch buffer; the
-        # per-(device, stream) workspace cache in flow_model.workspace() exists because of it.)  The same shards one after the other
-        # on one stream -- a smaller per-layer working set against the 256 MB Infinity Cache -- are slower: 2 457 / 2 465 / 2 544 /
-        # 2 574 / 2 886 ms for 1 / 2 / 4 / 8 / 16 chunks (call 45).  Default: one stream; RAP_NUM_STREAMS overrides.
+        # several HIP streams.  Round 3: the shards now really fork -- one event recorded on the caller's stream BEFORE
+        # any shard is enqueued, every auxiliary stream waits on that event, shard 0 is enqueued LAST on the caller's stream.  (The
+        # round-2 code enqueued shard 0 first and made the auxiliary streams wait for the caller's stream afterwards, i.e. for
+        # shard 0: its "2 408 / 2 394 / 2 396 ms on 2 / 3 / 4 streams vs 2 421 on one" measured serialized shards, not overlap.)
+        # Re-measured numbers: DESIGN.md section 5.  Default: one stream; RAP_NUM_STREAMS overrides.
         env = os.environ.get("RAP_NUM_STREAMS")
         self.num_streams = int(env) if env else num_streams
         self._aux_streams: dict = {}
@@ -112,33 +123,33 @@ class RectifiedPointFlow:
         if len(cuts) <= 2:
             return self._sample_shard(d, x_1, return_transformer_features)
         cur = torch.cuda.current_stream(device)
-        parts = []
-        for k in range(len(cuts) - 1):
+        nsh = len(cuts) - 1
+        parts = [None] * nsh
+        sequential = getattr(self, "_sequential_shards", False)      # experiment knob: the same shards one after the other on one stream
+        fork = torch.cuda.Event()
+        fork.record(cur)                                             # the inputs are ready on the caller's stream at this point
+        # auxiliary shards first, shard 0 last on the caller's stream: nothing enqueued on `cur` after the fork event delays them
+        for k in list(range(1, nsh)) + [0]:
             b0, b1 = cuts[k], cuts[k + 1]
             t0, t1 = cu_host[b0], cu_host[b1]
             shard = dict(cond=cond[t0:t1], feats=d["feats"][t0:t1], scales=d["scales"][b0:b1], anchor=d["anchor"][t0:t1],
                          ppp=d["ppp"][b0:b1], cu_batch=None)
-            if k == 0:
-                shard["cu_batch"] = d["cu_batch"][: b1 + 1]
-                parts.append(self._sample_shard(shard, x_1[t0:t1], return_transformer_features))
-                continue
-            if getattr(self, "_sequential_shards", False):            # experiment knob: the same shards one after the other on one stream
-                shard["cu_batch"] = (d["cu_batch"][b0: b1 + 1] - int(t0)).contiguous()
-                parts.append(self._sample_shard(shard, x_1[t0:t1], return_transformer_features))
+            if k == 0 or sequential:
+                shard["cu_batch"] = d["cu_batch"][: b1 + 1] if k == 0 else (d["cu_batch"][b0: b1 + 1] - int(t0)).contiguous()
+                parts[k] = self._sample_shard(shard, x_1[t0:t1], return_transformer_features)
                 continue
             key = (device.index, k)
             st = self._aux_streams.get(key)
             if st is None:
                 st = self._aux_streams[key] = torch.cuda.Stream(device)
-            st.wait_stream(cur)                                      # fork: the inputs are ready on the caller's stream
+            st.wait_event(fork)
             with torch.cuda.stream(st):
                 shard["cu_batch"] = (d["cu_batch"][b0: b1 + 1] - int(t0)).contiguous()
-                out = self._sample_shard(shard, x_1[t0:t1], return_transformer_features)
+                parts[k] = self._sample_shard(shard, x_1[t0:t1], return_transformer_features)
             for v in (cond, d["feats"], d["scales"], d["anchor"], d["ppp"], d["cu_batch"], x_1):
                 v.record_stream(st)                                  # caching-allocator safety: these are read on `st`
-            parts.append(out)
-        for k in range(1, len(parts)):
-            if (device.index, k) in self._aux_streams:
+        if not sequential:
+            for k in range(1, nsh):
                 cur.wait_stream(self._aux_streams[(device.index, k)])    # join
         res = {"end_point_trajectory": torch.cat([o["end_point_trajectory"] for o in parts], dim=1),
                "trajectory": torch.cat([o["trajectory"] for o in parts], dim=1),
@@ -161,7 +172,7 @@ class RectifiedPointFlow:
         model = self.flow_model
         model._activate(device)
         lib = _lib.load()
-        if self.validate_inputs:
+        if self.validate_inputs and not torch.cuda.is_current_stream_capturing():
             flag = torch.zeros(1, dtype=torch.int32, device=device)
             _lib.check(lib.rap_check_batch(_lib.ptr(d["ppp"]), _lib.ptr(d["cu_batch"]), B, P, TP, _lib.ptr(flag),
                                            _lib.current_stream(device)), "rap_check_batch")

@@ -89,28 +89,6 @@ def test_weights_are_a_pure_function_of_name_and_seed():
     assert [n for n, _ in S.weight_spec(cfg)] == list(a.keys())
 
 
-def test_checkpoint_loader_edits_keys_like_the_reference(tmp_path):
-    """utils/checkpoint.py:13-61: keep + strip `prefix_to_remove`, substitute, add, then load_state_dict(strict)."""
-    import torch
-    from rap_amd.checkpoint import load_checkpoint_for_module, load_spinnet_checkpoint
-
-    class Sink:
-        def load_state_dict(self, sd, strict=True):
-            self.sd, self.strict = sd, strict
-            return "ok"
-
-    ck = {"state_dict": {"flow_model.a.weight": torch.ones(2), "flow_model.b.bias": torch.zeros(1), "encoder.x": torch.ones(1)}}
-    torch.save(ck, tmp_path / "m.ckpt")
-    s = Sink()
-    assert load_checkpoint_for_module(s, str(tmp_path / "m.ckpt"), prefix_to_remove="flow_model.") == "ok"
-    assert sorted(s.sd) == ["a.weight", "b.bias"] and s.strict is False
-    load_checkpoint_for_module(s, str(tmp_path / "m.ckpt"), keys_to_substitute={"encoder.": "feat."}, prefix_to_add="p.", strict=True)
-    assert "p.feat.x" in s.sd and "p.flow_model.a.weight" in s.sd and s.strict is True
-    torch.save({"Desc.pnt_layer.0.weight": torch.ones(1), "Other.k": torch.ones(1)}, tmp_path / "d.pth")
-    load_spinnet_checkpoint(s, str(tmp_path / "d.pth"))
-    assert list(s.sd) == ["pnt_layer.0.weight"] and s.strict is False
-
-
 def test_shard_cuts_balance_tokens_at_sample_boundaries():
     """rap_amd.modeling.shard_cuts: the sample boundaries at which RectifiedPointFlow(num_streams=n) cuts a packed batch -- every shard
     non-empty, cuts strictly increasing, token counts balanced as well as whole samples allow, never more shards than samples."""
@@ -128,5 +106,11 @@ def test_shard_cuts_balance_tokens_at_sample_boundaries():
         c = shard_cuts(ragged, n)
         assert c[0] == 0 and c[-1] == 6 and all(b > a for a, b in zip(c, c[1:])) and len(c) - 1 <= min(n, 6)
     assert shard_cuts([0, 10], 4) == [0, 1]                   # a single sample cannot be cut
+    # samples without points: no shard may end up with zero tokens, wherever the empty samples sit
+    for cu_e in ([0, 0, 0, 100, 200], [0, 100, 100, 100, 100], [0, 0, 50, 50, 50, 120, 120], [0, 0, 0, 7]):
+        for n in range(1, 6):
+            c = shard_cuts(cu_e, n)
+            assert c[0] == 0 and c[-1] == len(cu_e) - 1 and all(b > a for a, b in zip(c, c[1:]))
+            assert all(cu_e[b] > cu_e[a] for a, b in zip(c, c[1:])), (cu_e, n, c)
     off = [1000, 1100, 6000, 6100]                            # offsets that do not start at 0 (a shard of a larger batch)
     assert shard_cuts(off, 2) == [0, 2, 3] or shard_cuts(off, 2) == [0, 1, 3]

@@ -24,15 +24,7 @@ def dev():
 
 @pytest.fixture(scope="module")
 def lib():
-    """RAP_TEST_GEMM_VARIANT=<n> runs this module against an opt-in fp32 GEMM variant (rap_set_tuning key 0) instead of the default."""
-    import os
-    lib = _lib.load()
-    v = os.environ.get("RAP_TEST_GEMM_VARIANT")
-    if v is not None:
-        assert lib.rap_set_tuning(0, int(v)) == 0
-    yield lib
-    if v is not None:
-        assert lib.rap_set_tuning(0, 16) == 0
+    return _lib.load()
 
 
 def stream(dev):

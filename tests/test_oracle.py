@@ -32,6 +32,10 @@ def test_oracle_matches_reference_golden(name):
         ref = torch.from_numpy(g[k])
         err = float((out[k] - ref).abs().max())
         assert err < 5e-6, (k, err)
+    if "sample_features" in g:         # transformer_features out of the sampling call (round 3; modeling.py:678-695)
+        f_ref = torch.from_numpy(g["sample_features"])
+        assert float(g["sample_features_timestep"]) == pytest.approx(1.0 / int(g["num_steps"]))
+        assert float((out["transformer_features"] - f_ref).abs().max()) < 2e-5 * max(1.0, float(f_ref.abs().max()))
     cu_b, cu_p = O.prepare_cu_seqlens(inp)
     fw = O.dit_forward(sd, cfg, inp["x_1"], torch.from_numpy(g["fwd_timesteps"]), inp["pointclouds"], inp["features"],
                        inp["scales"], inp["anchor_indices"], cu_b, cu_p, return_transformer_features=True)
@@ -47,8 +51,12 @@ def test_oracle_matches_live_reference_modules():
     for rigid in (False, True):
         ref = ref_loader.reference_sample(cfg, sd, inp, 3, rigid)
         mine = O.sample(sd, cfg, inp, 3, rigid)
-        for k in ref:
+        for k in ("end_point_trajectory", "trajectory", "R", "t"):
             assert float((ref[k] - mine[k]).abs().max()) < 5e-6, (rigid, k)
+        # the features the sampling call captures on its last model call (modeling.py:678-695): same call index, same values
+        assert ref["features_timestep"] == pytest.approx(1.0 / 3.0)
+        fmax = float(ref["transformer_features"].abs().max())
+        assert float((ref["transformer_features"] - mine["transformer_features"]).abs().max()) < 2e-5 * max(1.0, fmax), rigid
 
 
 def test_fp32_oracle_vs_fp64_ground_truth_sets_the_tolerance_scale():

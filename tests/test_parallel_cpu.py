@@ -87,3 +87,39 @@ def test_two_rank_gather_with_uneven_shards(tmp_path):
         want = torch.cat([got[0][key], got[1][key]])
         for r in range(2):
             assert torch.equal(got[r][gkey], want), (key, r)
+
+
+def _run_bench(extra_args, env_extra, timeout=600):
+    import subprocess
+    env = dict(os.environ); env.update(env_extra)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks_when_asked_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` WITHOUT torchrun: the file re-launches itself under torch.distributed.run with
+    2 ranks on 127.0.0.1, every rank asserts WORLD_SIZE == --gpus, rank 0 prints ONE JSON line with n_gpus = 2.  Launcher self-test
+    mode: gloo on CPU ranks with a stub in place of the sampler (rap_amd has no CPU path) -- launch, rendezvous, sharding, the
+    all-gather, per-rank timing and the JSON are the code under test."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3", "--points", "16"],
+                   {"RAP_BENCH_LAUNCHER_SELFTEST": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["pairs_total"] == 6 and j["gather_ok"] is True and j["stub"] is True
+    assert len(j["per_rank"]["elapsed_s"]) == 2
+
+
+def test_bench_refuses_a_rank_count_it_was_not_asked_for():
+    """--gpus N must equal the number of ranks that actually run: a torchrun world of 1 with --gpus 2 (or the reverse) exits non-zero
+    before anything is timed, and `--gpus 2` on a box with fewer than 2 GPUs refuses instead of timing one (here: no GPU at all)."""
+    import subprocess
+    env = dict(os.environ); env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        r = _run_bench(["--gpus", "2"], {})
+        assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()

@@ -86,3 +86,19 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_batch(tmp_path):
         assert got["final"].shape == ref["end_point_trajectory"][-1].shape
         assert (got["final"] - ref["end_point_trajectory"][-1].cpu()).abs().max().item() < 2e-5
         assert (got["R"] - ref["R"].cpu()).abs().max().item() < 2e-5 and (got["t"] - ref["t"].cpu()).abs().max().item() < 2e-5
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` with N above the number of visible GPUs must exit non-zero and print NO result line (VERDICT r02:
+    it used to time one rank and print n_gpus: 1) -- both through its own launcher and when a torchrun world of 1 is given --gpus 2."""
+    import subprocess
+    n = torch.cuda.device_count()
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip(), (r.returncode, r.stdout, r.stderr[-500:])
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29998")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
