@@ -93,6 +93,8 @@ def parse_args():
                          "bfloat16 = the per-GPU shard of configs[2]; float16 = the reference's shipped GPU precision")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="rap_set_tuning(KEY, VALUE) before the run (A/B experiments; recorded in config.tuning)")
+    ap.add_argument("--residual-dtype", default=None, choices=["auto", "float32", "float16"],
+                    help="storage of the residual stream in the 16-bit modes (default: rap_amd's default, see PointCloudDiT)")
     ap.add_argument("--gamma-scale", type=float, default=3.0,
                     help="multiplier on the seeded q/k-norm gains for the extra 'roofline_online_softmax' leg (1 warm-up + 2 timed sample "
                          "calls per precision; 0 = skip the leg)")
@@ -288,7 +290,9 @@ def main():
         """W untimed + K timed sample calls with the transformer blocks in `dtype`; returns (elapsed, prof, last, flow)."""
         model = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
                                       num_heads=cfg["num_heads"], local_feat_dim=cfg["local_feat_dim"],
-                                      attn_dtype=dtype, compute_dtype=dtype)
+                                      attn_dtype=dtype, compute_dtype=dtype, residual_dtype=args.residual_dtype)
+        run_mode.residual_dtype = {0: "float32", 2: "float16"}[0] if dtype == "float32" else (
+            model.residual_dtype if model.residual_dtype != "auto" else ("float16" if dtype == "bfloat16" else "float32"))
         model.load_state_dict(scaled_gains(gamma_scale))
         model.to(dev)
         run_mode.bounded_launches = lib.rap_model_bounded_attention_launches(model._handle)
@@ -407,7 +411,8 @@ def main():
         secondary = {
             "dtype": "bf16", "value": pts_per_rank * world * args.steps / e2, "unit": "points/s", "ms_per_step": 1e3 * e2 / args.steps,
             "host_call_ms_per_step": run_mode.host_enqueue_ms,
-            "workload": "same batch, bf16 MFMA transformer blocks (fp32 accumulate / residual / LN / softmax / head)",
+            "workload": f"same batch, bf16 MFMA transformer blocks (fp32 accumulate / LN statistics / softmax / head; residual stream held in {run_mode.residual_dtype})",
+            "residual_stream": run_mode.residual_dtype,
             "roofline": roofline_of("bfloat16", p2, run_mode.prof_region_s), "streams": run_mode.streams,
             "bounded_attention_launches": f"{run_mode.bounded_launches} of {2 * args.layers}",
             "deviation_from_fp32_path": {"final_cloud_max_abs": float((a - b).abs().max()),

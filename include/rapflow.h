@@ -66,6 +66,14 @@ int rap_model_compute_dtype(const rap_model* m);
  * flow_model/norm.py:15-33); the others take the online-softmax kernel.  Decided per launch, so one hot head of a trained checkpoint
  * costs one (layer, branch) the faster kernel, not the model.  Returns < 0 for a NULL model. */
 int rap_model_bounded_attention_launches(const rap_model* m);
+/* Storage type of the residual stream in the 16-bit compute modes: 0 = fp32 (default), 2 = fp16.  With fp16 the stream between the
+ * layer kernels is held the way the reference's own "16-mixed" inference holds it (nn.Linear outputs are 16-bit under autocast and
+ * flow_model/layer.py:155-164 adds them): every residual sum is formed in fp32 from the GEMM's fp32 accumulators and rounded once,
+ * LayerNorm statistics stay fp32, the head (fp32 in the reference too, point_cloud_dit.py:183-184) reads an fp32 image of it.
+ * Halves the HBM bytes of the two N = 512 GEMMs and the three LayerNorms of a layer.  Ignored while the compute dtype is fp32.
+ * rap_workspace_bytes depends on it.  Not a per-call switch: set it before the first call like the compute dtype. */
+int rap_model_set_residual_dtype(rap_model* m, int32_t dtype);
+int rap_model_residual_dtype(const rap_model* m);
 
 /* Bytes of caller-provided workspace for one call on a batch of TP points, B samples, `nseg_part`
  * part segments (B*P for rap_sample, VP for rap_dit_forward) and `rows` adaLN rows
@@ -261,6 +269,8 @@ int rap_adaln_table(const rap_model* m, const float* t, int32_t rows, float* scr
 /* ---- reduced-precision kernel-level entry points (dtype 1 = bf16, 2 = fp16; 16-bit tensors as uint16_t*) ---- */
 int rap_convert_h16(int32_t dtype, const float* src, uint16_t* dst, int64_t n, void* stream);
 /* C = A (M,K) W(N,K)^T, fp32 accumulate.  epilogue: 0 C half = acc + bias; 1 C fp32 = (resid +) acc + bias;
+ * 6 C fp16 = fp16(resid + acc + bias) with `resid` pointing at an FP16 (M,N) matrix (required; row stride ldr; may alias C): the residual GEMM
+ * of the 16-bit residual stream, one rounding of the fp32 sum, fp16 whatever the operand dtype;
  * 3 GEGLU on value/gate-interleaved W (C half (M,N/2)); 4 qkv split: q,k -> C half [2][H][M][64], v -> vt, the
  * TRANSPOSED image [H][vt_nblk][64 d][64 pos] the attention kernel consumes: token t sits in block t >> 6 at
  * pos = (t & 51) | ((t & 4) << 1) | ((t & 8) >> 1); vt_nblk * 64 >= M rounded up to 256; rows >= M are written as 0. */
@@ -341,7 +351,8 @@ int rap_profile_enable(int on);
  *   key 6  split-K of the bias + residual GEMM, few rows  {0 off, 1 on (default)}       fp32 path
  *   key 7  qk-norm fused into the QKV GEMM epilogue       {1 (default), 0 = own kernel} both precisions
  *   key 9  GEGLU's Phi                                    {1 (default): erfc polynomial, |error| <= 1.5e-7; 0: erff}   fp32 path
- *   key 10 ff1 -> GEGLU -> ff2 as ONE kernel              {1 (default), 0 = two GEMMs}  16-bit path
+ *   key 11 persistent 16-bit GEMM (one block per CU walks {1 (default), 0 = one 256 x 256 tile per block}   16-bit path
+ *          its XCD's tiles; full-tile shapes only)
  * Any other key returns RAP_ERR_INVALID.  (Keys 0-4 selected among the kernel variants of the round-1/2 experiments; those variants
  * are no longer in the tree, and what is left of the switch exists only in a library built with -DRAP_ABLATION_BUILD.) */
 int rap_set_tuning(int32_t key, int32_t value);

@@ -31,16 +31,23 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+ABLATION_LIB = os.path.join(CSRC, "librapflow_ablation.so")
+
+
+def build(force: bool = False, verbose: bool = False, ablation: bool = False) -> str:
+    """ablation=True: a SECOND library, librapflow_ablation.so, compiled with -DRAP_ABLATION_BUILD (kernel-variant switches and
+    timestamp hooks for scripts/; never loaded by rap_amd itself)."""
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
+    flags = FLAGS + (["-DRAP_ABLATION_BUILD"] if ablation else [])
+    lib = ABLATION_LIB if ablation else LIB
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", ".abl.o" if ablation else ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([hipcc, *flags, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -53,10 +60,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ablation="--ablation" in sys.argv))

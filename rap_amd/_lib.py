@@ -37,6 +37,8 @@ SIGNATURES = {
     "rap_model_set_compute_dtype": (c_int32, [_P, c_int32, _P]),
     "rap_model_compute_dtype": (c_int32, [_P]),
     "rap_model_bounded_attention_launches": (c_int32, [_P]),
+    "rap_model_set_residual_dtype": (c_int32, [_P, c_int32]),
+    "rap_model_residual_dtype": (c_int32, [_P]),
     "rap_workspace_bytes": (c_size_t, [_P, c_int64, c_int32, c_int32, c_int32]),
     "rap_dit_forward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, c_size_t, _P]),
     "rap_euler_step": (c_int32, [_P, _P, c_float, c_float, _P, _P, _P, c_int64, _P]),

@@ -92,6 +92,7 @@ struct rap_model {
   rap_model_desc desc;
   int d, L, H, F, E;
   int dtype = RAP_DT_F32;     // arithmetic type of the transformer blocks (rap_model_set_compute_dtype)
+  int resid_dtype = RAP_DT_F32;   // storage type of the residual stream in the 16-bit modes (rap_model_set_residual_dtype): fp32 or fp16
   HalfWeights half[3];        // indexed by dtype (slot 0 unused)
   float* logit_bound = nullptr;   // (L, 2, H) per-head bounds on q.k/8 after qk-norm; null until a 16-bit dtype is selected
   // bounded[2 * layer + branch]: every head of THAT attention has a bound <= RAP_MAX_LOGIT_BOUND, so that launch may use the
@@ -126,11 +127,11 @@ extern rap_tuning_t g_rap_geglu_fast;     // gemm_f32.hip
 extern rap_tuning_t g_rap_attn_split;     // attn_f32.hip
 extern rap_tuning_t g_rap_gemm_h16_variant;   // gemm_h16.hip
 extern rap_tuning_t g_rap_attn_h16_variant;   // attn_h16.hip
+extern rap_tuning_t g_rap_gemm_h16_persistent;   // gemm_h16.hip
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
-rap_tuning_t g_rap_fused_mlp = 1;              // tuning key 10 (16-bit path): ff1 -> GEGLU -> ff2 in ONE kernel (1, default when the shape allows) or two GEMMs (0)
 // Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
 // fp32 summation order -- 5 split-KV for few-token calls, 6 split-K for few-row calls, 7 fused qk-norm, 9 GEGLU's Phi by the
-// 1.5e-7 erfc polynomial (1) or erff (0), 10 fused GEGLU-MLP.  Keys 0-4 (kernel-variant A/B of the round-1/2 experiments) exist
+// 1.5e-7 erfc polynomial (1) or erff (0), 11 persistent 16-bit GEMM.  Keys 0-4 (kernel-variant A/B of the round-1/2 experiments) exist
 // only in a library built with -DRAP_ABLATION_BUILD; the shipped library refuses them.
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
 #ifdef RAP_ABLATION_BUILD
@@ -143,7 +144,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 6 && (value == 0 || value == 1)) { g_rap_gemm_splitk = value; return RAP_OK; }
   if (key == 7 && (value == 0 || value == 1)) { g_rap_fuse_qknorm = value; return RAP_OK; }
   if (key == 9 && (value == 0 || value == 1)) { g_rap_geglu_fast = value; return RAP_OK; }
-  if (key == 10 && (value == 0 || value == 1)) { g_rap_fused_mlp = value; return RAP_OK; }
+  if (key == 11 && (value == 0 || value == 1)) { g_rap_gemm_h16_persistent = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 
@@ -321,6 +322,14 @@ extern "C" int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* st
   return RAP_OK;
 }
 extern "C" int rap_model_compute_dtype(const rap_model* m) { return m ? m->dtype : RAP_ERR_INVALID; }
+// Residual stream of the 16-bit modes: fp32 (default) or fp16 -- what the reference's autocast inference holds (nn.Linear outputs
+// are 16-bit under Lightning "16-mixed", layer.py:155-164 adds them).  Ignored while the compute dtype is fp32.
+extern "C" int rap_model_set_residual_dtype(rap_model* m, int32_t dtype) {
+  if (!m || (dtype != RAP_DT_F32 && dtype != RAP_DT_F16)) return RAP_ERR_INVALID;
+  m->resid_dtype = dtype;
+  return RAP_OK;
+}
+extern "C" int rap_model_residual_dtype(const rap_model* m) { return m ? m->resid_dtype : RAP_ERR_INVALID; }
 extern "C" int rap_model_bounded_attention_launches(const rap_model* m) { return m ? m->n_bounded : RAP_ERR_INVALID; }
 
 // ---------------------------------------------------------------------------------------------
@@ -328,6 +337,7 @@ extern "C" int rap_model_bounded_attention_launches(const rap_model* m) { return
 // ---------------------------------------------------------------------------------------------
 struct Workspace {
   float *base, *h, *xn, *qkv, *att, *ffmid, *ax, *v, *mod, *ada_scratch, *xt, *Rc, *tc, *tgrid;
+  u16* h16;                            // the residual stream when it is held in fp16 (16-bit modes with resid_dtype = fp16; h is then null)
   float *hid1, *hid2, *astatic;        // head hidden layers (T,d), (T,d/2) and the static feature matrix (T,128): aliases
   u16 *xnh, *qkh, *vth, *atth, *ffmidh; // reduced-precision mode: 16-bit activations (xn/qkv/att/ffmid are then unused)
   int vt_nblk;
@@ -345,7 +355,9 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   auto take = [&](size_t bytes) { char* r = basep ? basep + off : nullptr; off += align_up(bytes, 256); return r; };
   const size_t T = (size_t)TP;
   w.base = (float*)take(T * d * 4);
-  w.h = (float*)take(T * d * 4);
+  const bool h16 = m->dtype != RAP_DT_F32 && m->resid_dtype == RAP_DT_F16;
+  w.h = h16 ? nullptr : (float*)take(T * d * 4);
+  w.h16 = h16 ? (u16*)take(T * d * 2) : nullptr;
   w.xn = w.qkv = w.att = w.ffmid = nullptr;
   w.xnh = w.qkh = w.vth = w.atth = w.ffmidh = nullptr;
   w.vt_nblk = 0;
@@ -420,11 +432,16 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
   if ((rc = launch_posenc_x(stream, x_t, w.ax, TP))) return rc;
   {
     GemmParams g{};
-    g.A = w.ax; g.lda = 64; g.W = m->Wx; g.ldw = 64; g.C = w.h; g.ldc = d; g.M = TP; g.N = d; g.K = 64;
+    // 16-bit residual stream: the fp32 embedding lands in the (idle) FFN buffer and is rounded to fp16 once
+    g.A = w.ax; g.lda = 64; g.W = m->Wx; g.ldw = 64; g.C = w.h16 ? w.hid1 : w.h; g.ldc = d; g.M = TP; g.N = d; g.K = 64;
     g.resid = w.base; g.ldr = d;
     if ((rc = launch_gemm_f32(stream, EPI_BIAS_RESID, g))) return rc;
+    if (w.h16 && (rc = launch_convert_h16(stream, RAP_DT_F16, w.hid1, w.h16, (size_t)TP * d))) return rc;
   }
   const int dt = m->dtype;
+  const void* hres = w.h16 ? (const void*)w.h16 : (const void*)w.h;      // the residual stream as the 16-bit LayerNorms read it
+  const int hres_f16 = w.h16 ? 1 : 0;
+  const int epi_resid = w.h16 ? EPI_H_BIAS_RESID_H16 : EPI_H_BIAS_RESID_F32;
   for (int i = 0; i < m->L; ++i) {
     const LayerW& lw = m->layers[i];
     if (dt != RAP_DT_F32) {
@@ -432,7 +449,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       const LayerWH& lh = m->half[dt].layers[i];
       for (int a = 0; a < 2; ++a) {
         const int j = 2 * i + a;
-        if ((rc = launch_layernorm_mod_h16(stream, dt, w.h, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
+        if ((rc = launch_layernorm_mod_h16(stream, dt, hres, hres_f16, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
         GemmParamsH g{};
         g.A = w.xnh; g.lda = d; g.W = lh.Wqkv[a]; g.ldw = d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
         g.vt = w.vth; g.vt_nblk = w.vt_nblk;
@@ -456,21 +473,23 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         }
         if (rc) return rc;
         GemmParamsH o{};
-        o.A = w.atth; o.lda = d; o.W = lh.Wout[a]; o.ldw = d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = d;
-        o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d;
-        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, o); }
+        o.A = w.atth; o.lda = d; o.W = lh.Wout[a]; o.ldw = d; o.ldc = d; o.M = TP; o.N = d; o.K = d;
+        o.bias = lw.bout[a]; o.ldr = d;
+        if (w.h16) { o.C = w.h16; o.resid_h = w.h16; } else { o.C = w.h; o.resid = w.h; }
+        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, epi_resid, o); }
         if (rc) return rc;
       }
-      if ((rc = launch_layernorm_affine_h16(stream, dt, w.h, w.xnh, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
+      if ((rc = launch_layernorm_affine_h16(stream, dt, hres, hres_f16, w.xnh, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
       GemmParamsH f1{};
       f1.A = w.xnh; f1.lda = d; f1.W = lh.Wff1p; f1.ldw = d; f1.C = w.ffmidh; f1.ldc = 4 * d; f1.M = TP; f1.N = 8 * d; f1.K = d;
       f1.bias = lw.bff1p;
       { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_GEGLU, f1); }
       if (rc) return rc;
       GemmParamsH f2{};
-      f2.A = w.ffmidh; f2.lda = 4 * d; f2.W = lh.Wff2; f2.ldw = 4 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 4 * d;
-      f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d;
-      { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, f2); }
+      f2.A = w.ffmidh; f2.lda = 4 * d; f2.W = lh.Wff2; f2.ldw = 4 * d; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 4 * d;
+      f2.bias = lw.bff2; f2.ldr = d;
+      if (w.h16) { f2.C = w.h16; f2.resid_h = w.h16; } else { f2.C = w.h; f2.resid = w.h; }
+      { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, epi_resid, f2); }
       if (rc) return rc;
       continue;
     }
@@ -514,7 +533,14 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
     { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_BIAS_RESID, f2); }
     if (rc) return rc;
   }
-  if (feats_out) {
+  // 16-bit residual stream: the fp32 head (and the caller's transformer_features) read an fp32 image of it -- written into the
+  // caller's feature buffer when there is one, else into the q / k planes (T x 2d 16-bit values = T x d floats, dead after the last attention)
+  const float* h_final = w.h;
+  if (w.h16) {
+    float* img = feats_out ? feats_out : reinterpret_cast<float*>(w.qkh);
+    if ((rc = launch_convert_f16_to_f32(stream, w.h16, img, (size_t)TP * d))) return rc;
+    h_final = img;
+  } else if (feats_out) {
     if (hipMemcpyAsync(feats_out, w.h, (size_t)TP * d * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) {
       rap_set_last_hip_error((int)hipGetLastError());
       return RAP_ERR_HIP;
@@ -522,7 +548,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
   }
   // final_mlp (point_cloud_dit.py:111-117): Lin+SiLU, Lin+SiLU, Lin(no bias)
   GemmParams h0{};
-  h0.A = w.h; h0.lda = d; h0.W = m->hW0; h0.ldw = d; h0.C = w.hid1; h0.ldc = d; h0.M = TP; h0.N = d; h0.K = d; h0.bias = m->hb0;
+  h0.A = h_final; h0.lda = d; h0.W = m->hW0; h0.ldw = d; h0.C = w.hid1; h0.ldc = d; h0.M = TP; h0.N = d; h0.K = d; h0.bias = m->hb0;
   if ((rc = launch_gemm_f32(stream, EPI_BIAS_SILU, h0))) return rc;
   GemmParams h2{};
   h2.A = w.hid1; h2.lda = d; h2.W = m->hW2; h2.ldw = d; h2.C = w.hid2; h2.ldc = d / 2; h2.M = TP; h2.N = d / 2; h2.K = d;
@@ -757,6 +783,7 @@ extern "C" int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, 
   GemmParamsH g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias;
   g.resid = resid; g.ldr = ldr; g.heads = heads; g.vt = vt; g.vt_nblk = vt_nblk;
+  if (epilogue == EPI_H_BIAS_RESID_H16) { g.resid_h = reinterpret_cast<const uint16_t*>(resid); g.resid = nullptr; }   // fp16 residual
   return launch_gemm_h16((hipStream_t)stream, dtype, epilogue, g);
 }
 extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk,
@@ -773,12 +800,12 @@ extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16
 extern "C" int rap_layernorm_mod_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* mod,
                                      int64_t mod_stride, const int32_t* token_row, void* stream) {
   if (!x || !out || !mod) return RAP_ERR_INVALID;
-  return launch_layernorm_mod_h16((hipStream_t)stream, dtype, x, out, (int)TP, d, mod, (long)mod_stride, token_row);
+  return launch_layernorm_mod_h16((hipStream_t)stream, dtype, x, 0, out, (int)TP, d, mod, (long)mod_stride, token_row);
 }
 extern "C" int rap_layernorm_affine_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* gain,
                                         const float* shift, void* stream) {
   if (!x || !out || !gain || !shift) return RAP_ERR_INVALID;
-  return launch_layernorm_affine_h16((hipStream_t)stream, dtype, x, out, (int)TP, d, gain, shift);
+  return launch_layernorm_affine_h16((hipStream_t)stream, dtype, x, 0, out, (int)TP, d, gain, shift);
 }
 extern "C" int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t heads, const float* gamma_q,
                               const float* gamma_k, void* stream) {

@@ -43,6 +43,13 @@ __device__ __forceinline__ float xhalf_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+#define ATTN_DEFER_THR 11.5f   // = 8 in natural-log units: the online softmax rescales only when a row maximum grows by more than e^8
+__device__ __forceinline__ float amax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // NW = waves per block (4: 256 queries, two blocks per CU; 8: 512 queries, one block per CU).  With NW = 8 the
 // two waves that share a SIMD (w and w+4) belong to the SAME block and get different static priorities: with equal
 // priority two identical waves share the matrix pipe fairly, stay in lock-step and hit their softmax (VALU) phases
@@ -224,29 +231,38 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
             lsum[qt] += pa + pb2;
           }
         } else {
-        // ---- online softmax (lane-local except one cross-half max, a VALU v_permlane32_swap)
+        // ---- online softmax (lane-local except one cross-half max, a VALU v_permlane32_swap).  Round 3: row maximum through
+        // v_max3_f32 (8 instead of 15 instructions per 16 scores; hipcc also prepends a canonicalising v_max to every
+        // MFMA-output operand of fmaxf) and a DEFERRED rescale, as the 16-bit kernel has had since r01: the running reference
+        // m of a row moves only when a row of the wave outgrows it by more than 2^11.5 (e^8), so in the steady state a
+        // sub-tile costs no alpha, no 32 multiplies of O and no l * alpha -- p = 2^(s - m) <= 2^11.5 and every sum stays far
+        // inside fp32; softmax is invariant to the reference.  Same function, different rounding pattern.
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          float mx = st[qt][0];
+          float mx = amax3(st[qt][0], st[qt][1], st[qt][2]);
 #pragma unroll
-          for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[qt][r]);
-          mx = xhalf_max(mx);
-          const float mnew = fmaxf(mrun[qt], mx);
-          const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
-          mrun[qt] = mnew;
-          float ps = 0.f;
+          for (int r = 3; r < 15; r += 2) mx = amax3(mx, st[qt][r], st[qt][r + 1]);
+          mx = xhalf_max(fmaxf(mx, st[qt][15]));
+          if (__builtin_amdgcn_ballot_w64(mx > mrun[qt] + ATTN_DEFER_THR) != 0) {       // wave-uniform
+            const float mnew = fmaxf(mrun[qt], mx);
+            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+            mrun[qt] = mnew;
+            lsum[qt] *= alpha;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(st[qt][r] - mnew);
-            st[qt][r] = pv;
-            ps += pv;
+            for (int r = 0; r < 16; ++r) {
+              o[qt][0][r] *= alpha;
+              o[qt][1][r] *= alpha;
+            }
           }
-          lsum[qt] = lsum[qt] * alpha + ps;
+          float pa = 0.f, pb2 = 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            o[qt][0][r] *= alpha;
-            o[qt][1][r] *= alpha;
+          for (int r = 0; r < 16; r += 2) {
+            const float e0 = __builtin_amdgcn_exp2f(st[qt][r] - mrun[qt]);
+            const float e1 = __builtin_amdgcn_exp2f(st[qt][r + 1] - mrun[qt]);
+            st[qt][r] = e0; st[qt][r + 1] = e1;
+            pa += e0; pb2 += e1;
           }
+          lsum[qt] += pa + pb2;
         }
         }
         // ---- O^T += V^T P^T : step r contracts keys {crow(r,0), crow(r,1)} = P register r.  V fragments are

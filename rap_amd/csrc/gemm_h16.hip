@@ -18,6 +18,7 @@
 //    At 16x the fp32 MFMA rate the kernel is L2->LDS bandwidth bound at 128x128 (64 B/clk/CU needed vs ~56
 //    available), hence the 256x256 / 8-wave instantiation for the large shapes.
 //  * 1-D grid, XCD-aware remap, n-tile fastest (A panel stays in one XCD's L2).
+#include <type_traits>
 #include "half.h"
 #include "kernels.h"
 
@@ -111,6 +112,53 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
         if (p.resid) { v.x += rr[it].x; v.y += rr[it].y; v.z += rr[it].z; v.w += rr[it].w; }
         const int m = mw + i * 32 + row;
         if (m < p.M) *reinterpret_cast<float4*>(C + (size_t)m * p.ldc + nw + col) = v;
+      }
+    }
+    return;
+  }
+  if constexpr (EPI == EPI_H_BIAS_RESID_H16) {
+    // The residual GEMMs of the 16-bit residual stream (round 3): C fp16 = fp16(resid_h + acc + bias), the sum formed in fp32 from the
+    // fp32 accumulators and rounded ONCE.  Half the bytes of the fp32 read-modify-write that bounds EPI_H_BIAS_RESID_F32.  fp32
+    // transposition slab as above; a lane then owns 8 consecutive columns of a row: two float4 from the slab, one 16-byte piece of the
+    // fp16 residual in, one 16-byte piece out.  ALL residual pieces of the wave tile (TM x 4 x 16 bytes per lane = 64 VGPRs, the
+    // registers the operand fragments occupied during the k-loop) are requested before the first slab is transposed, so the HBM
+    // latency is paid once per tile, not once per 32-row slab (the fp32 form needs 128 registers for that and spilled, r02 call 39).
+    u16* C = reinterpret_cast<u16*>(p.C);
+    float* sf = reinterpret_cast<float*>(stg);   // [32 rows][68 floats]: 64 columns + 4 pad (the 8-lanes-per-row reads stay off each other's banks)
+    const float b0 = p.bias ? p.bias[nw + l31] : 0.f;
+    const float b1 = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+    // the (L2-hot) bias has landed before the residual requests go out: the slab writes below then wait for nothing, and every
+    // residual piece is waited for with its own counted vmcnt
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int col = (lane & 7) * 8;
+    uint4 rr[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        int m = mw + i * 32 + it * 8 + (lane >> 3);
+        m = m < p.M ? m : p.M - 1;
+        rr[i][it] = *reinterpret_cast<const uint4*>(p.resid_h + (size_t)m * p.ldr + nw + col);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sf[mfma32_crow(r, hi) * 68 + l31] = acc[i][0][r] + b0;
+        sf[mfma32_crow(r, hi) * 68 + 32 + l31] = acc[i][1][r] + b1;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const float4 a0 = *reinterpret_cast<const float4*>(sf + row * 68 + col);
+        const float4 a1 = *reinterpret_cast<const float4*>(sf + row * 68 + col + 4);
+        float rv[8];
+        h16_unpack8<RAP_DT_F16>(rr[i][it], rv);
+        const typename H16<RAP_DT_F16>::T8 o8 = h16_pack8<RAP_DT_F16>(a0.x + rv[0], a0.y + rv[1], a0.z + rv[2], a0.w + rv[3],
+                                                                     a1.x + rv[4], a1.y + rv[5], a1.z + rv[6], a1.w + rv[7]);
+        const int m = mw + i * 32 + row;
+        if (m < p.M) *reinterpret_cast<uint4*>(C + (size_t)m * p.ldc + nw + col) = __builtin_bit_cast(uint4, o8);
       }
     }
     return;
@@ -375,6 +423,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
   gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
 }
 
+#ifdef RAP_ABLATION_BUILD
+// Ablation build only (scripts/gemm_ts.py): s_memrealtime stamps (100 MHz, one counter for the device) of thread 0 of every block of
+// the phase-split kernel -- [block][8]: 0 entry, 1 prologue DMA issued, 2 first k-tile landed (first barrier passed), 3 k-loop done,
+// 4 epilogue done (stores issued), 5 = (XCC_ID << 16) | HW_ID -- to itemise the per-tile overhead the K = 512 shapes lose to.
+__device__ unsigned long long* g_gemm_ts = nullptr;
+extern "C" int rap_debug_gemm_ts(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_ts), &p, sizeof(p)) == hipSuccess ? 0 : -3; }
+#define GEMM_TS(I) if (g_gemm_ts && threadIdx.x == 0) { g_gemm_ts[(size_t)blockIdx.x * 8 + (I)] = __builtin_amdgcn_s_memrealtime(); \
+    if ((I) == 0) g_gemm_ts[(size_t)blockIdx.x * 8 + 5] = ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu); }
+#else
+#define GEMM_TS(I)
+#endif
 // ---------------------------------------------------------------------------------------------
 // Phase-split kernel (r02; rap_set_tuning(2, 13 | 14 | 15)).  r02 calls 2-4 reproduce what the CDNA4 guide says about this
 // structure class: every loop with ONE barrier per k-slice in which all eight waves stage, read and multiply in lockstep lands at
@@ -403,6 +462,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   const int l31 = lane & 31;
   const int wr = wave >> 2, wc = wave & 3;
 
+  GEMM_TS(0)
   const int nt = p.N / 256;
   const int mt = (p.M + 255) / 256;
   const int logical = xcd_remap(blockIdx.x, mt * nt);
@@ -480,8 +540,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   // prologue: tile 0 completely, plus the A half h0 of tile 1 (what phase q3 of "tile -1" would have issued)
 #pragma unroll
   for (int j = 0; j < 8; ++j) PH_PIECE(j, 0, 0)
+  GEMM_TS(1)
   if (nk > 1) { PH_PIECE(0, 1, 1) PH_PIECE(1, 1, 1) PH_VM(2) } else { PH_VM(0) }
   PH_BAR
+  GEMM_TS(2)
   if (STAG && wr == 1) { PH_BAR }          // wave row 1 runs one barrier behind
 
   for (int t = 0; t < nk; ++t) {
@@ -516,6 +578,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
     PH_MMA(1, 0, fb0)
     PH_BAR
   }
+  GEMM_TS(3)
   if (STAG && wr == 0) { PH_BAR }          // equal barrier counts for both wave rows
   static_assert(8 * H16_STG_BYTES <= 2 * STAGE, "staging slabs must fit the operand buffers");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -526,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   } else {
     gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
   }
+  GEMM_TS(4)
 }
 
 template <int EPI, int DT, int PRIO, int STAG>
@@ -542,12 +606,246 @@ static int launch_ph(hipStream_t stream, const GemmParamsH& p) {
   return RAP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the phase-split kernel (round 3).  scripts/gemm_ts.py (s_memrealtime stamps, r03 call 8) itemises a 256 x 256
+// tile of the K = 512 shapes on the kernel above: 2.0-2.8 us from block entry to the first DMA (kernel arguments, tile decode,
+// eight 64-bit source addresses, wave start-up), 1.0-1.2 us until the first k-tile has landed, 14-16 us of k-loop (8 k-tiles at
+// ~52 % of the MFMA peak), 3.5-4.4 us of epilogue, ~1.8 us between a block's last store and the next block's entry: 9-10 us of
+// every 25 us round are not k-loop.  Here ONE block per CU walks the tiles of its XCD (virtual block id v = blockIdx.x + i *
+// gridDim.x, gridDim.x a multiple of 8: xcd_remap keeps its meaning) and treats the k-tiles of consecutive output tiles as ONE
+// stream: the phases of an output tile's last k-tile request the FIRST k-tile of the next output tile exactly as they would request
+// the next k-tile of their own, so the next k-loop starts on data that has landed, without a launch, an argument load or a prologue,
+// and the epilogue's stores drain under it.  Differences from the kernel above:
+//  * sources are a scalar base (tile origin + k offset, SGPRs) plus one 32-bit per-thread byte offset per piece (the saddr form of
+//    global_load_lds): 8 VGPRs instead of 16, nothing to recompute at a tile switch but two scalar pointers; needs M % 256 == 0
+//    (no row clamping);
+//  * the epilogue's per-wave transposition slabs live where no DMA is in flight: the 48 KB behind the A half h0 of the stage that
+//    was read last (that 16 KB is already receiving the k-tile after next) and 32 KB beyond the two stages (160 KB of LDS in all);
+//  * vmcnt is in-order over loads AND stores, so a counted wait after an epilogue would also wait for its stores: everything
+//    the first k-tile of the next output tile reads is therefore confirmed BEFORE the epilogue (vmcnt(2): all but the two pieces of
+//    the k-tile after next), its phases q0-q2 wait for nothing, and q3's usual vmcnt(6) is the first point the stores must have drained.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int DT>
+__global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
+  typedef typename H16<DT>::T8 T8;
+  constexpr int TM = 4;
+  constexpr int ABYTES = 256 * 128, STAGE = 2 * ABYTES;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [stage 0: A B][stage 1: A B][32 KB of epilogue slabs]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nt = p.N / 256;
+  const int total = (p.M / 256) * nt;
+  const int nk = p.K / 64;
+
+  // piece j (0..7) of a stage: LDS chunk id = j * 512 + tid -> LDS row s = id >> 3 (0..255 A, 256..511 W), 16-byte slot id & 7;
+  // voff[j] = byte offset of the piece's source inside the tile's A (j < 4) or W (j >= 4) panel at k = 0
+  unsigned voff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int id = j * 512 + tid;
+    const int s = (id >> 3) & 255;
+    const int lslot = (id & 7) ^ ((s >> 1) & 7);
+    if (j < 4) {
+      const int r = ((s >> 6) & 1) * 128 + (s >> 7) * 64 + (s & 63);       // [h][wr][64 rows] -> wr*128 + h*64 + row
+      voff[j] = (unsigned)(r * p.lda + 8 * lslot) * 2u;
+    } else {
+      const int r = ((s >> 5) & 3) * 64 + (s >> 7) * 32 + (s & 31);         // [g][wc][32 rows] -> wc*64 + g*32 + row
+      voff[j] = (unsigned)(r * p.ldw + 8 * lslot) * 2u;
+    }
+  }
+
+  f32x16 acc[TM][2];
+  const int sw = (l31 >> 1) & 7;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+  // one LDS-DMA piece: scalar base (64-bit, SGPRs) + per-thread 32-bit offset; m0 carries the wave-uniform LDS byte address
+#define PHP_DMA1(VOFF, SBASE, LDSB)                                                                           \
+  {                                                                                                           \
+    unsigned keep_;                                                                                           \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(VOFF), "s"(LDSB), "s"(SBASE) : "memory");                                \
+  }
+#define PHP_PIECE(J, SBASE, BUF) PHP_DMA1(voff[J], SBASE, lds_wave + (unsigned)((BUF) * STAGE + (J) * 8192))
+
+  uint4 fa[2][4], fb0[4], fb1[4];
+  auto read_a = [&](int buf, int h) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        fa[ii][ks] = *reinterpret_cast<const uint4*>(smem + buf * STAGE + (h * 128 + wr * 64 + ii * 32 + l31) * 128 + (((2 * ks + hi) ^ sw) * 16));
+  };
+  auto read_b = [&](uint4 (&fb)[4], int buf, int g) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      fb[ks] = *reinterpret_cast<const uint4*>(smem + buf * STAGE + ABYTES + (g * 128 + wc * 32 + l31) * 128 + (((2 * ks + hi) ^ sw) * 16));
+  };
+  // SWP (EPI_H_QKV_NORM, q and k column tiles): the swapped product C^T = W A^T, see the kernel above.  A compile-time property of the
+  // k-loop COPY that runs (chosen per output tile): as a run-time flag inside the phases it cost 2x (r03 call 10: the accumulators of
+  // the two alternatives are reconciled with register copies at every phase).
+#define PHP_MMA(SWP, H, G, FB)                                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                                          \
+  if constexpr (SWP) {                                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                        \
+      acc[2 * (H)][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[ks]), __builtin_bit_cast(T8, fa[0][ks]), acc[2 * (H)][G]);         \
+      acc[2 * (H) + 1][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[ks]), __builtin_bit_cast(T8, fa[1][ks]), acc[2 * (H) + 1][G]); \
+    }                                                                                                         \
+  } else {                                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                        \
+      acc[2 * (H)][G] = H16<DT>::mfma(__builtin_bit_cast(T8, fa[0][ks]), __builtin_bit_cast(T8, FB[ks]), acc[2 * (H)][G]);         \
+      acc[2 * (H) + 1][G] = H16<DT>::mfma(__builtin_bit_cast(T8, fa[1][ks]), __builtin_bit_cast(T8, FB[ks]), acc[2 * (H) + 1][G]); \
+    }                                                                                                         \
+  }                                                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // scalar source bases of an output tile (virtual block id v): A panel rows m0.., W panel rows n0.., at k = 0
+  auto tile_bases = [&](int v, const unsigned char*& ab, const unsigned char*& wb, int& m0, int& n0) {
+    const int logical = xcd_remap(v, total);
+    m0 = (logical / nt) * 256;
+    n0 = (logical % nt) * 256;
+    ab = reinterpret_cast<const unsigned char*>(p.A) + (size_t)m0 * p.lda * 2;
+    wb = reinterpret_cast<const unsigned char*>(p.W) + (size_t)n0 * p.ldw * 2;
+  };
+
+  int v = blockIdx.x;
+  const unsigned char *a_cur, *w_cur, *a_nxt = nullptr, *w_nxt = nullptr;
+  int m0, n0, m0n = 0, n0n = 0;
+  tile_bases(v, a_cur, w_cur, m0, n0);
+
+  // prologue of the block: the first k-tile completely, plus the A half h0 of the second (what phase q3 of "k-tile -1" would have issued)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) PHP_PIECE(j, a_cur, 0)
+#pragma unroll
+  for (int j = 4; j < 8; ++j) PHP_PIECE(j, w_cur, 0)
+  PHP_PIECE(0, a_cur + 128, 1) PHP_PIECE(1, a_cur + 128, 1)            // nk >= 2 (the launcher checks K >= 128)
+  PH_VM(2)
+  PH_BAR
+  int par = 0;                                   // stage that holds the current k-tile of the stream
+  bool first_tile = true;
+
+  for (;;) {
+    const int vn = v + (int)gridDim.x;
+    const bool has_next = vn < total;
+    if (has_next) tile_bases(vn, a_nxt, w_nxt, m0n, n0n);
+    const bool swp = EPI == EPI_H_QKV_NORM && (n0 + wc * 64) < 2 * p.heads * 64;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (wr == 1) { PH_BAR }                      // wave row 1 runs one barrier behind
+
+    auto k_tiles = [&](auto swp_c) __attribute__((always_inline)) {
+      constexpr bool SWP = decltype(swp_c)::value;
+      for (int t = 0; t < nk; ++t) {
+        const int buf = par;
+        // stream successors: k-tile t + 1 / t + 2 of this output tile, or k-tile 0 / 1 of the next one
+        const bool in1 = t + 1 < nk, in2 = t + 2 < nk;
+        const bool ok1 = in1 || has_next, ok2 = in2 || has_next;
+        const unsigned char* a1 = in1 ? a_cur + (size_t)(t + 1) * 128 : a_nxt;
+        const unsigned char* w1 = in1 ? w_cur + (size_t)(t + 1) * 128 : w_nxt;
+        const unsigned char* a2 = in2 ? a_cur + (size_t)(t + 2) * 128 : a_nxt + (size_t)(t + 2 - nk) * 128;
+        // the first k-tile after an epilogue: everything it reads was confirmed before the epilogue; a counted wait here would wait
+        // for the epilogue's stores (vmcnt is in-order over loads and stores)
+        const bool nowait = t == 0 && !first_tile;
+        // ---- q0: quadrant (h0, g0)
+        read_a(buf, 0); read_b(fb0, buf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ok1) { PHP_PIECE(4, w1, buf ^ 1) PHP_PIECE(5, w1, buf ^ 1) if (!nowait) { PH_VM(6) } } else { PH_VM(2) }
+        PH_BAR
+        PHP_MMA(SWP, 0, 0, fb0)
+        PH_BAR
+        // ---- q1: quadrant (h0, g1)
+        read_b(fb1, buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ok1) { PHP_PIECE(6, w1, buf ^ 1) PHP_PIECE(7, w1, buf ^ 1) if (!nowait) { PH_VM(6) } } else { PH_VM(0) }
+        PH_BAR
+        PHP_MMA(SWP, 0, 1, fb1)
+        PH_BAR
+        // ---- q2: quadrant (h1, g1)
+        read_a(buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ok1) { PHP_PIECE(2, a1, buf ^ 1) PHP_PIECE(3, a1, buf ^ 1) if (!nowait) { PH_VM(6) } }
+        PH_BAR
+        PHP_MMA(SWP, 1, 1, fb1)
+        PH_BAR
+        // ---- q3: quadrant (h1, g0)
+        read_b(fb0, buf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ok2) { PHP_PIECE(0, a2, buf) PHP_PIECE(1, a2, buf) PH_VM(6) } else if (ok1) { PH_VM(4) }
+        PH_BAR
+        PHP_MMA(SWP, 1, 0, fb0)
+        PH_BAR
+        par ^= 1;
+      }
+    };
+    if constexpr (EPI == EPI_H_QKV_NORM) {
+      if (swp) k_tiles(std::true_type{}); else k_tiles(std::false_type{});
+    } else {
+      k_tiles(std::false_type{});
+    }
+    if (wr == 0) { PH_BAR }                      // equal barrier counts for both wave rows
+    // Everything the next output tile's first k-tile reads has been requested during the last k-tile: confirm it NOW (all but the
+    // two pieces of the k-tile after next, issued in q3), then publish with the barrier that also says "every wave has read the last stage".
+    if (has_next) { PH_VM(2) } else { PH_VM(0) }
+    PH_BAR
+    {
+      const int last = par ^ 1;                  // the stage the last k-tile was read from: its bytes [16 KB, 64 KB) are idle
+      unsigned char* slab = wave < 5 ? smem + last * STAGE + 16384 + wave * H16_STG_BYTES : smem + 2 * STAGE + (wave - 5) * H16_STG_BYTES;
+      static_assert(5 * H16_STG_BYTES <= STAGE - 16384 && 3 * H16_STG_BYTES <= 32768, "epilogue slabs must fit the idle regions");
+      if constexpr (EPI == EPI_H_QKV_NORM) {
+        if (swp) gemm_h16_qknorm_epilogue<DT, TM>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+        else gemm_h16_epilogue<EPI_H_QKV, DT, TM>(p, acc, slab, m0 + wr * 128, n0 + wc * 64, lane);
+      } else {
+        gemm_h16_epilogue<EPI, DT, TM>(p, acc, slab, m0 + wr * 128, n0 + wc * 64, lane);
+      }
+    }
+    if (!has_next) break;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PH_BAR                                       // every wave has drained its slab: the next k-loop's DMA may overwrite the region
+    v = vn; a_cur = a_nxt; w_cur = w_nxt; m0 = m0n; n0 = n0n;
+    first_tile = false;
+  }
+}
+
+template <int EPI, int DT>
+static int launch_php(hipStream_t stream, const GemmParamsH& p) {
+  constexpr int LDS = 4 * 256 * 128 + 32768;
+  auto kern = gemm_h16_php_kernel<EPI, DT>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    rap_set_last_hip_error((int)hipGetLastError());
+    return RAP_ERR_HIP;
+  }
+  static std::atomic<int> n_cu_cache[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return RAP_ERR_HIP;
+  int n_cu = (dev >= 0 && dev < 16) ? n_cu_cache[dev].load() : 0;
+  if (n_cu == 0) {
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) return RAP_ERR_HIP;
+    n_cu = n_cu >= 8 ? (n_cu / 8) * 8 : n_cu;     // a multiple of the XCD count: a block's virtual ids stay on its XCD
+    if (dev >= 0 && dev < 16) n_cu_cache[dev] = n_cu;
+  }
+  const int total = (p.M / 256) * (p.N / 256);
+  hipLaunchKernelGGL(kern, dim3(total < n_cu ? total : n_cu), dim3(512), LDS, stream, p);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
 // Kernel choice (round 3: the fifteen other main loops of rounds 1-2 -- rings, pipelined rings, interleaved issue, persistent,
 // 128 x 512 -- all measured within +-4 % of this one and are gone from the tree; their source and numbers are in the history at
 // 72efb73 and in DESIGN.md section 4.3).  Default: the phase-split 256 x 256 kernel.  Fallback for shapes it cannot tile
 // (N % 256 != 0 or K < 128) and for few-row calls: the two-stage 128 x 128 kernel, two blocks per CU.
 // RAP_ABLATION_BUILD only: rap_set_tuning(2, 0) forces the 128 x 128 kernel, (2, 1) the two-stage 256 x 256 kernel.
 rap_tuning_t g_rap_gemm_h16_variant = 14;
+rap_tuning_t g_rap_gemm_h16_persistent = 1;     // tuning key 11: the persistent phase-split kernel for full-tile shapes (1, default) or one tile per block (0)
 
 template <int EPI, int DT, int WM, int WN, int TM, int TN>
 static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
@@ -565,6 +863,12 @@ static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
   return RAP_OK;
 }
 
+// rows of a 256-row tile are addressed by a 32-bit byte offset from the tile's scalar base
+static bool use_persistent(const GemmParamsH& p) {
+  return g_rap_gemm_h16_persistent && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 128 && (long)(p.M / 256) * (p.N / 256) >= 512 &&
+         p.lda <= (1 << 20) && p.ldw <= (1 << 20);
+}
+
 template <int EPI, int DT>
 static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
   const bool big = p.N % 256 == 0 && p.K >= 128;
@@ -572,6 +876,9 @@ static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
   if (g_rap_gemm_h16_variant == 0) return launch_cfg<EPI, DT, 2, 2, 2, 2>(stream, p);
   if (g_rap_gemm_h16_variant == 1 && big) return launch_cfg<EPI, DT, 2, 4, 4, 2>(stream, p);
 #endif
+  // persistent form when every row tile is full and there are at least two rounds of tiles for a 256-CU part; the one-tile-per-block
+  // form for ragged M (it clamps rows) and for few tiles
+  if (big && use_persistent(p)) return launch_php<EPI, DT>(stream, p);
   if (big && p.M > 128) return launch_ph<EPI, DT, 0, 1>(stream, p);
   return launch_cfg<EPI, DT, 2, 2, 2, 2>(stream, p);
 }
@@ -581,9 +888,13 @@ static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
   switch (epilogue) {
     case EPI_H_BIAS: return launch_variant<EPI_H_BIAS, DT>(stream, p);
     case EPI_H_BIAS_RESID_F32: return launch_variant<EPI_H_BIAS_RESID_F32, DT>(stream, p);
+    case EPI_H_BIAS_RESID_H16:
+      if (!p.resid_h || (p.ldc & 7) || (p.ldr & 7)) return RAP_ERR_INVALID;
+      return launch_variant<EPI_H_BIAS_RESID_H16, DT>(stream, p);
     case EPI_H_GEGLU: return launch_variant<EPI_H_GEGLU, DT>(stream, p);
     case EPI_H_QKV_NORM:
       if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256 || !p.gamma_q || !p.gamma_k || p.K < 128) return RAP_ERR_INVALID;
+      if (use_persistent(p)) return launch_php<EPI_H_QKV_NORM, DT>(stream, p);
       return launch_ph<EPI_H_QKV_NORM, DT, 0, 1>(stream, p);
     case EPI_H_QKV:
       if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256) return RAP_ERR_INVALID;
@@ -622,6 +933,27 @@ int launch_convert_h16(hipStream_t stream, int dtype, const float* src, u16* dst
   if (dtype == RAP_DT_BF16) hipLaunchKernelGGL(convert_h16_kernel<RAP_DT_BF16>, dim3(grid), dim3(256), 0, stream, src, dst, n4);
   else if (dtype == RAP_DT_F16) hipLaunchKernelGGL(convert_h16_kernel<RAP_DT_F16>, dim3(grid), dim3(256), 0, stream, src, dst, n4);
   else return RAP_ERR_INVALID;
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
+// fp16 -> fp32 (the 16-bit residual stream handed to the fp32 head / returned as transformer_features)
+__global__ __launch_bounds__(256) void convert_f16_to_f32_kernel(const u16* __restrict__ src, float* __restrict__ dst, size_t n8) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n8; i += stride) {
+    float v[8];
+    h16_unpack8<RAP_DT_F16>(reinterpret_cast<const uint4*>(src)[i], v);
+    reinterpret_cast<float4*>(dst)[2 * i] = float4{v[0], v[1], v[2], v[3]};
+    reinterpret_cast<float4*>(dst)[2 * i + 1] = float4{v[4], v[5], v[6], v[7]};
+  }
+}
+int launch_convert_f16_to_f32(hipStream_t stream, const u16* src, float* dst, size_t n) {
+  if (n == 0) return RAP_OK;
+  if (n % 8 != 0) return RAP_ERR_INVALID;
+  const size_t n8 = n / 8;
+  const unsigned grid = (unsigned)((n8 + 255) / 256 < 65536 ? (n8 + 255) / 256 : 65536);
+  hipLaunchKernelGGL(convert_f16_to_f32_kernel, dim3(grid), dim3(256), 0, stream, src, dst, n8);
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }

@@ -109,6 +109,8 @@ enum GemmEpilogueH {
   EPI_H_BIAS_RESID_F32 = 1,  // C fp32 (M,N) = (resid +) acc (+ bias[n])      (resid may alias C)
   EPI_H_GEGLU = 3,           // W rows pre-interleaved [32 value | 32 gate]: C half (M,N/2) = (h + bh) * gelu_erf(g + bg)
   EPI_H_QKV = 4,             // N = 3*H*64: q,k -> C half [2][H][M][64]; v -> vt half [H][vt_nblk][64 d][64 pos] (half.h vt_pos)
+  EPI_H_BIAS_RESID_H16 = 6,  // C fp16 (M,N) = fp16(resid_h (fp16) + acc + bias[n]), ONE rounding from the fp32 sum   (resid_h may alias C):
+                             // the residual GEMMs of the 16-bit residual stream (rap_model_set_residual_dtype), whatever the operand dtype
   EPI_H_QKV_NORM = 5,        // EPI_H_QKV with MultiHeadRMSNorm (norm.py:28-33) fused: q,k rows are normalised from the fp32 accumulators,
                              // multiplied by gamma and by q_mul / 8 before the single rounding to 16 bit (phase-split kernel only)
 };
@@ -121,6 +123,7 @@ struct GemmParamsH {
   const float* resid; int ldr;
   int heads;
   uint16_t* vt; int vt_nblk;
+  const uint16_t* resid_h = nullptr;                                                     // EPI_H_BIAS_RESID_H16 (row stride ldr)
   const float* gamma_q = nullptr; const float* gamma_k = nullptr; float q_mul = 8.0f;   // EPI_H_QKV_NORM
 };
 int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p);
@@ -135,10 +138,12 @@ int attention_h16_block_queries(int dtype);      // work-list granularity of the
 // per-head logit bounds of one attention branch after qk-norm: out[h] = 8 * max_j|gamma_q[h][j]| * max_j|gamma_k[h][j]|
 int launch_qk_logit_bound(hipStream_t stream, const float* gamma_q, const float* gamma_k, int heads, float* out);
 // LayerNorm with 16-bit output (fp32 statistics), same modulation forms as launch_layernorm_*
-int launch_layernorm_mod_h16(hipStream_t stream, int dtype, const float* x, uint16_t* out, int TP, int d, const float* mod,
+// x: the residual stream, fp32 (x_f16 = 0) or fp16 (x_f16 = 1: the 16-bit residual stream); statistics and modulation in fp32
+int launch_layernorm_mod_h16(hipStream_t stream, int dtype, const void* x, int x_f16, uint16_t* out, int TP, int d, const float* mod,
                              long mod_stride, const int32_t* token_row);
-int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const float* x, uint16_t* out, int TP, int d,
+int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const void* x, int x_f16, uint16_t* out, int TP, int d,
                                 const float* gain, const float* shift);
+int launch_convert_f16_to_f32(hipStream_t stream, const uint16_t* src, float* dst, size_t n);
 // q_mul: factor of the q plane (8 = the reference's sqrt(Dh); RAP_QMUL_PRESCALED = log2(e) for the pre-scaled attention path)
 #define RAP_QMUL_PRESCALED 1.44269504088896340736f
 int launch_qknorm_h16(hipStream_t stream, int dtype, uint16_t* qk, int TP, int heads, const float* gamma_q,

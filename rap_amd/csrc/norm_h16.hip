@@ -1,27 +1,42 @@
 // HBM-bound normalisation kernels of the reduced-precision path: same arithmetic as norm.hip (fp32 statistics,
 // fp32 modulation), 16-bit outputs for the bf16 / fp16 GEMM and attention operands.
 //  * layernorm_h16_kernel: fp32 residual stream in, LN (+ adaLN modulation or affine), 16-bit out:
-//    3 KiB of traffic per 512-wide token (2 KiB read + 1 KiB write).
+//    3 KiB of traffic per 512-wide token (2 KiB read + 1 KiB write); XH = true: the residual stream is fp16 (round 3,
+//    rap_model_set_residual_dtype): 2 KiB per token.
 //  * qknorm_h16_kernel: MultiHeadRMSNorm (flow_model/norm.py:28-33) in place on the 16-bit q and k planes.
 #include "half.h"
 #include "kernels.h"
 
-template <int NV, int DT>  // NV float4 per lane: d = 256 * NV
-__global__ __launch_bounds__(256) void layernorm_h16_kernel(const float* __restrict__ x, u16* __restrict__ out, int TP,
+template <int NV, int DT, bool XH>  // NV float4 per lane: d = 256 * NV
+__global__ __launch_bounds__(256) void layernorm_h16_kernel(const void* __restrict__ x_, u16* __restrict__ out, int TP,
                                                             const float* __restrict__ gain_base, const float* __restrict__ shift_base,
                                                             long row_stride, const int32_t* __restrict__ token_row, int add_one) {
   const int d = 256 * NV;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= TP) return;
-  const float* xr = x + (size_t)row * d;
   float4 v[NV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
-    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    if constexpr (XH && NV % 2 == 0) {
+      // 16 bytes per lane in, 16 bytes per lane out: v[i], v[i + 1] are 8 CONSECUTIVE columns (col_of below)
+      if (i % 2 == 0) {
+        float f8[8];
+        h16_unpack8<RAP_DT_F16>(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(x_) + (size_t)row * d + (i / 2) * 512 + lane * 8), f8);
+        v[i] = float4{f8[0], f8[1], f8[2], f8[3]};
+        v[i + 1] = float4{f8[4], f8[5], f8[6], f8[7]};
+      }
+    } else if constexpr (XH) {
+      const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(x_) + (size_t)row * d + (i * 64 + lane) * 4);
+      const typename H16<RAP_DT_F16>::T4 h4 = __builtin_bit_cast(typename H16<RAP_DT_F16>::T4, raw);
+      v[i] = float4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+    } else {
+      v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x_) + (size_t)row * d + (i * 64 + lane) * 4);
+    }
   }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
@@ -36,46 +51,60 @@ __global__ __launch_bounds__(256) void layernorm_h16_kernel(const float* __restr
   const float* b = shift_base + mrow * row_stride;
   const float one = add_one ? 1.0f : 0.0f;
   u16* orow = out + (size_t)row * d;
+  constexpr bool WIDE = XH && NV % 2 == 0;
+  uint2 keep = make_uint2(0, 0);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * 4;
+    const int c = WIDE ? (i / 2) * 512 + lane * 8 + (i % 2) * 4 : (i * 64 + lane) * 4;
     const float4 gg = *reinterpret_cast<const float4*>(g + c);
     const float4 bb = *reinterpret_cast<const float4*>(b + c);
     const float ox = (v[i].x - mean) * rstd * (one + gg.x) + bb.x;
     const float oy = (v[i].y - mean) * rstd * (one + gg.y) + bb.y;
     const float oz = (v[i].z - mean) * rstd * (one + gg.z) + bb.z;
     const float ow = (v[i].w - mean) * rstd * (one + gg.w) + bb.w;
-    *reinterpret_cast<uint2*>(orow + c) = h16_pack4<DT>(ox, oy, oz, ow);
+    const uint2 pk = h16_pack4<DT>(ox, oy, oz, ow);
+    if constexpr (WIDE) {
+      if (i % 2 == 0) keep = pk;
+      else *reinterpret_cast<uint4*>(orow + c - 4) = make_uint4(keep.x, keep.y, pk.x, pk.y);
+    } else {
+      *reinterpret_cast<uint2*>(orow + c) = pk;
+    }
   }
 }
 
-template <int DT>
-static int launch_ln_h16(hipStream_t stream, const float* x, u16* out, int TP, int d, const float* gain, const float* shift,
+template <int DT, bool XH>
+static int launch_ln_h16(hipStream_t stream, const void* x, u16* out, int TP, int d, const float* gain, const float* shift,
                          long row_stride, const int32_t* token_row, int add_one) {
   if (TP <= 0) return RAP_OK;
   if (d % 256 != 0 || d > 1024) return RAP_ERR_INVALID;
   dim3 grid((TP + 3) / 4), block(256);
   switch (d / 256) {
-    case 1: hipLaunchKernelGGL((layernorm_h16_kernel<1, DT>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
-    case 2: hipLaunchKernelGGL((layernorm_h16_kernel<2, DT>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
-    case 3: hipLaunchKernelGGL((layernorm_h16_kernel<3, DT>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
-    default: hipLaunchKernelGGL((layernorm_h16_kernel<4, DT>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
+    case 1: hipLaunchKernelGGL((layernorm_h16_kernel<1, DT, XH>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
+    case 2: hipLaunchKernelGGL((layernorm_h16_kernel<2, DT, XH>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
+    case 3: hipLaunchKernelGGL((layernorm_h16_kernel<3, DT, XH>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
+    default: hipLaunchKernelGGL((layernorm_h16_kernel<4, DT, XH>), grid, block, 0, stream, x, out, TP, gain, shift, row_stride, token_row, add_one); break;
   }
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }
-
-int launch_layernorm_mod_h16(hipStream_t stream, int dtype, const float* x, u16* out, int TP, int d, const float* mod,
-                             long mod_stride, const int32_t* token_row) {
-  if (dtype == RAP_DT_BF16) return launch_ln_h16<RAP_DT_BF16>(stream, x, out, TP, d, mod, mod + d, mod_stride, token_row, 1);
-  if (dtype == RAP_DT_F16) return launch_ln_h16<RAP_DT_F16>(stream, x, out, TP, d, mod, mod + d, mod_stride, token_row, 1);
+static int launch_ln_h16_any(hipStream_t stream, int dtype, const void* x, int x_f16, u16* out, int TP, int d, const float* gain,
+                             const float* shift, long row_stride, const int32_t* token_row, int add_one) {
+  if (dtype == RAP_DT_BF16)
+    return x_f16 ? launch_ln_h16<RAP_DT_BF16, true>(stream, x, out, TP, d, gain, shift, row_stride, token_row, add_one)
+                 : launch_ln_h16<RAP_DT_BF16, false>(stream, x, out, TP, d, gain, shift, row_stride, token_row, add_one);
+  if (dtype == RAP_DT_F16)
+    return x_f16 ? launch_ln_h16<RAP_DT_F16, true>(stream, x, out, TP, d, gain, shift, row_stride, token_row, add_one)
+                 : launch_ln_h16<RAP_DT_F16, false>(stream, x, out, TP, d, gain, shift, row_stride, token_row, add_one);
   return RAP_ERR_INVALID;
 }
-int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const float* x, u16* out, int TP, int d, const float* gain,
+
+int launch_layernorm_mod_h16(hipStream_t stream, int dtype, const void* x, int x_f16, u16* out, int TP, int d, const float* mod,
+                             long mod_stride, const int32_t* token_row) {
+  return launch_ln_h16_any(stream, dtype, x, x_f16, out, TP, d, mod, mod + d, mod_stride, token_row, 1);
+}
+int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const void* x, int x_f16, u16* out, int TP, int d, const float* gain,
                                 const float* shift) {
-  if (dtype == RAP_DT_BF16) return launch_ln_h16<RAP_DT_BF16>(stream, x, out, TP, d, gain, shift, 0, nullptr, 0);
-  if (dtype == RAP_DT_F16) return launch_ln_h16<RAP_DT_F16>(stream, x, out, TP, d, gain, shift, 0, nullptr, 0);
-  return RAP_ERR_INVALID;
+  return launch_ln_h16_any(stream, dtype, x, x_f16, out, TP, d, gain, shift, 0, nullptr, 0);
 }
 
 // 8 lanes per (plane, head, token) row of 64 values (16 bytes per lane); 32 rows per 256-thread block.

@@ -9,6 +9,7 @@ PyTorch is used for device memory and the current stream only.
 from __future__ import annotations
 
 import collections
+import os
 import ctypes
 
 import torch
@@ -38,6 +39,13 @@ def _require_cuda(t: torch.Tensor, name: str) -> None:
         raise _lib.RapError(f"{name} must live on the GPU: rap_amd has no CPU path (got device {t.device})")
 
 
+# "auto": fp16 residual stream under bf16 compute, fp32 under fp16 compute -- chosen by measurement against the reference's fp32
+# fixtures (r03 call 4, tests/test_headline_gpu.py): with bf16 operands the fp16 stream does not move the deviation (configs[1] final
+# cloud 4.8e-4 vs 5.4e-4, |dR|_F 8.9e-4 vs 1.2e-3; configs[3] 1.8e-3 vs 1.2e-3) and buys 2.4 % of a sampling call; with fp16 operands
+# it doubles to triples it (2.3e-4 vs 1.1e-4, 6.9e-4 vs 2.2e-4), so that mode keeps the fp32 stream.  DESIGN.md section 4.3.
+DEFAULT_RESIDUAL_DTYPE = "auto"
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.float32).contiguous()
 
@@ -52,7 +60,7 @@ class PointCloudDiT:
                  dropout_rate: float = 0.0, softcap: float = 0.0, qk_norm: bool = True, attn_dtype: str = "float16",
                  final_mlp_act=None, max_points_per_part: int = 500, max_points_per_batch: int = 40000,
                  scale_emb_on: bool = True, local_feat_concat_on: bool = True, local_feat_dim: int = 0,
-                 compute_dtype: str | None = "float32"):
+                 compute_dtype: str | None = "float32", residual_dtype: str | None = None):
         if in_dim != 0:
             raise NotImplementedError("in_dim != 0 (PTv3 encoder latent) is off in every shipped config (rap_12.yaml:17)")
         if out_dim != 3:
@@ -78,6 +86,17 @@ class PointCloudDiT:
         if compute_dtype is not None and compute_dtype not in _lib.DTYPES:
             raise ValueError(f"Unsupported compute_dtype: {compute_dtype}")
         self.compute_dtype = compute_dtype
+        # residual_dtype (an extension; 16-bit compute modes only): storage of the residual stream between the layer kernels.
+        # "float32" = every residual add, LayerNorm statistic and the head see an fp32 stream (stricter than the reference's
+        # autocast inference); "float16" = the stream is held in fp16 like the reference's own "16-mixed" inference holds it
+        # (nn.Linear outputs are 16-bit there and layer.py:155-164 adds them), each residual sum formed in fp32 from the fp32
+        # accumulators and rounded once -- half the HBM bytes of the two N = 512 GEMMs and the three LayerNorms of a layer.
+        # None = RAP_RESIDUAL_DTYPE from the environment, else "auto" = the default chosen by measurement (see DEFAULT_RESIDUAL_DTYPE).
+        if residual_dtype is None:
+            residual_dtype = os.environ.get("RAP_RESIDUAL_DTYPE") or DEFAULT_RESIDUAL_DTYPE
+        if residual_dtype not in ("auto", "float32", "float16"):
+            raise ValueError(f"Unsupported residual_dtype: {residual_dtype}")
+        self.residual_dtype = residual_dtype
         self.cfg = dict(embed_dim=embed_dim, num_layers=num_layers, num_heads=num_heads, local_feat_dim=local_feat_dim)
         self._spec = weight_spec(self.cfg)
         self._sd: dict[str, torch.Tensor] | None = None
@@ -176,6 +195,10 @@ class PointCloudDiT:
         self._ensure_model(device)
         lib = _lib.load()
         code = self._dtype_code()
+        resolved = self.residual_dtype if self.residual_dtype != "auto" else ("float16" if code == 1 else "float32")
+        rcode = _lib.DTYPES[resolved]
+        if lib.rap_model_residual_dtype(self._handle) != rcode:
+            _lib.check(lib.rap_model_set_residual_dtype(self._handle, rcode), "rap_model_set_residual_dtype")
         if lib.rap_model_compute_dtype(self._handle) != code:
             with torch.cuda.device(device):
                 _lib.check(lib.rap_model_set_compute_dtype(self._handle, code, _lib.current_stream(device)),

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Where a 256 x 256 tile of the phase-split 16-bit GEMM spends its time (ablation library: python -m rap_amd._build --ablation).
+s_memrealtime stamps (100 MHz) of thread 0 of every block: entry, prologue DMA issued, first k-tile landed, k-loop done, epilogue done
+(stores issued); blocks are grouped by the CU they ran on (XCC_ID, HW_ID) to get the gap between a block's last stamp and the entry
+of the next block on the same CU (store drain + dispatch).  JSON lines."""
+import ctypes, json, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from rap_amd import _build
+
+dev = torch.device("cuda:0")
+raw = ctypes.CDLL(_build.ABLATION_LIB)
+raw.rap_debug_gemm_ts.restype = ctypes.c_int
+raw.rap_debug_gemm_ts.argtypes = [ctypes.c_void_p]
+P = ctypes.c_void_p
+raw.rap_gemm_h16.restype = ctypes.c_int
+raw.rap_gemm_h16.argtypes = [ctypes.c_int32, ctypes.c_int32, P, ctypes.c_int32, P, ctypes.c_int32, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                             ctypes.c_int32, P, P, ctypes.c_int32, ctypes.c_int32, P, ctypes.c_int32, P]
+g = torch.Generator(device=dev).manual_seed(0)
+TP = 262144
+st = lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)  # noqa: E731
+ptr = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())          # noqa: E731
+cases = [("plain 16-bit out", 0, 512, 512), ("plain 16-bit out", 0, 512, 2048), ("plain 16-bit out", 0, 1536, 512), ("GEGLU", 3, 4096, 512),
+         ("fp16 residual", 6, 512, 512)]
+for name, epi, N, K in cases:
+    A = torch.randn(TP, K, device=dev, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev, generator=g)
+    Cw = N // 2 if epi == 3 else N
+    C = torch.zeros(TP, Cw, device=dev, dtype=torch.float16 if epi == 6 else torch.bfloat16)
+    resid = C if epi == 6 else None
+    nblocks = (TP // 256) * (N // 256)
+    ts = torch.zeros(nblocks * 8, dtype=torch.int64, device=dev)
+    assert raw.rap_debug_gemm_ts(ts.data_ptr()) == 0
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = raw.rap_gemm_h16(1, epi, ptr(A), K, ptr(W), K, ptr(C), Cw, TP, N, K, ptr(bias), ptr(resid), Cw if resid is not None else 0, 0,
+                              ptr(None), 0, st())
+        assert rc == 0, rc
+        e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    t = ts.cpu().numpy().reshape(nblocks, 8).astype(np.int64)
+    r0 = t[:, 0].min()
+    us = lambda a: a / 100.0   # noqa: E731
+    seg = {"entry->prologue DMA issued": us(t[:, 1] - t[:, 0]), "->first k-tile landed": us(t[:, 2] - t[:, 1]), "k-loop": us(t[:, 3] - t[:, 2]),
+           "epilogue (to stores issued)": us(t[:, 4] - t[:, 3]), "whole block (thread 0)": us(t[:, 4] - t[:, 0])}
+    # gap to the next block on the same CU
+    cu = t[:, 5]
+    gaps = []
+    for c in np.unique(cu):
+        idx = np.where(cu == c)[0]
+        o = idx[np.argsort(t[idx, 0])]
+        gaps.extend(us(t[o[1:], 0] - t[o[:-1], 4]))
+    gaps = np.array(gaps)
+    row = {"case": name, "N": N, "K": K, "blocks": nblocks, "cus": int(len(np.unique(cu))), "launch_ms_events": round(ms, 3),
+           "first_entry_to_last_stamp_us": round(float(us(t[:, 4].max() - r0)), 1), "rounds": round(nblocks / len(np.unique(cu)), 2)}
+    for k, v in seg.items():
+        row[k] = {"median": round(float(np.median(v)), 2), "p10": round(float(np.percentile(v, 10)), 2), "p90": round(float(np.percentile(v, 90)), 2)}
+    row["gap: stores issued -> next block's entry on that CU"] = {"median": round(float(np.median(gaps)), 2), "p10": round(float(np.percentile(gaps, 10)), 2),
+                                                                   "p90": round(float(np.percentile(gaps, 90)), 2)}
+    print(json.dumps(row), flush=True)
