@@ -624,6 +624,11 @@ static int launch_ph(hipStream_t stream, const GemmParamsH& p) {
 //  * vmcnt is in-order over loads AND stores, so a counted wait after an epilogue would also wait for its stores: everything
 //    the first k-tile of the next output tile reads is therefore confirmed BEFORE the epilogue (vmcnt(2): all but the two pieces of
 //    the k-tile after next), its phases q0-q2 wait for nothing, and q3's usual vmcnt(6) is the first point the stores must have drained.
+// Measured (r03 calls 12-14, TP = 262 144 rows, bf16): qkv + qk-norm 0.653 -> 0.566 ms, out-projection 0.215 -> 0.192, ff1 + GEGLU 1.353 ->
+// 1.204, ff2 0.550 -> 0.528; the layer GEMMs of a sampling call 829 -> 689 ms (796 -> 957 TF); results BIT-identical to the kernel above for
+// every epilogue (tests/test_h16_gpu.py).  Stamps of the persistent kernel: tile period 18-21 us = 13.5-15 us of k-loop + 3.6-4.4 us of
+// epilogue (7.4 with the residual's HBM latency; GEGLU is VALU-bound: the younger wave of each SIMD finishes 2.5 us after the older) +
+// 0.5-0.8 us of turn-around.  Starting every other block half a period late (so that the CUs do not store in lockstep) changes nothing (+-1 %).
 // ---------------------------------------------------------------------------------------------
 template <int EPI, int DT>
 __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
@@ -728,6 +733,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
   PH_BAR
   int par = 0;                                   // stage that holds the current k-tile of the stream
   bool first_tile = true;
+#ifdef RAP_ABLATION_BUILD
+  int ts_it = 0;                                 // [block][tile][4] stamps: 0 k-loop start, 1 k-loop end, 2 epilogue end (stores issued), 3 XCC/HW id
+#define PHP_TS(I) if (g_gemm_ts && threadIdx.x == 0 && ts_it < 32) { g_gemm_ts[((size_t)blockIdx.x * 32 + ts_it) * 4 + (I)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define PHP_TS(I)
+#endif
 
   for (;;) {
     const int vn = v + (int)gridDim.x;
@@ -740,6 +751,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    PHP_TS(0)
     if (wr == 1) { PH_BAR }                      // wave row 1 runs one barrier behind
 
     auto k_tiles = [&](auto swp_c) __attribute__((always_inline)) {
@@ -791,6 +803,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
     } else {
       k_tiles(std::false_type{});
     }
+    PHP_TS(1)
     if (wr == 0) { PH_BAR }                      // equal barrier counts for both wave rows
     // Everything the next output tile's first k-tile reads has been requested during the last k-tile: confirm it NOW (all but the
     // two pieces of the k-tile after next, issued in q3), then publish with the barrier that also says "every wave has read the last stage".
@@ -807,6 +820,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
         gemm_h16_epilogue<EPI, DT, TM>(p, acc, slab, m0 + wr * 128, n0 + wc * 64, lane);
       }
     }
+    PHP_TS(2)
+#ifdef RAP_ABLATION_BUILD
+    ++ts_it;
+#endif
     if (!has_next) break;
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

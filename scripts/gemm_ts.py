@@ -21,6 +21,9 @@ g = torch.Generator(device=dev).manual_seed(0)
 TP = 262144
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)  # noqa: E731
 ptr = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())          # noqa: E731
+PERSISTENT = "--persistent" in sys.argv
+raw.rap_set_tuning.restype = ctypes.c_int; raw.rap_set_tuning.argtypes = [ctypes.c_int32, ctypes.c_int32]
+assert raw.rap_set_tuning(11, 1 if PERSISTENT else 0) == 0
 cases = [("plain 16-bit out", 0, 512, 512), ("plain 16-bit out", 0, 512, 2048), ("plain 16-bit out", 0, 1536, 512), ("GEGLU", 3, 4096, 512),
          ("fp16 residual", 6, 512, 512)]
 for name, epi, N, K in cases:
@@ -31,7 +34,7 @@ for name, epi, N, K in cases:
     C = torch.zeros(TP, Cw, device=dev, dtype=torch.float16 if epi == 6 else torch.bfloat16)
     resid = C if epi == 6 else None
     nblocks = (TP // 256) * (N // 256)
-    ts = torch.zeros(nblocks * 8, dtype=torch.int64, device=dev)
+    ts = torch.zeros(max(nblocks * 8, 256 * 32 * 4), dtype=torch.int64, device=dev)
     assert raw.rap_debug_gemm_ts(ts.data_ptr()) == 0
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,13 +44,28 @@ for name, epi, N, K in cases:
         assert rc == 0, rc
         e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    t = ts.cpu().numpy().reshape(nblocks, 8).astype(np.int64)
+    if PERSISTENT:
+        # [block][tile][4]: k-loop start, k-loop end, epilogue end; consecutive tiles of one block give the tile-to-tile period
+        tt = ts.cpu().numpy()[: 256 * 32 * 4].reshape(256, 32, 4).astype(np.int64)
+        ntile = min(32, nblocks // 256)
+        tt = tt[:, :ntile]
+        us = lambda a: a / 100.0   # noqa: E731
+        row = {"case": name, "N": N, "K": K, "persistent": True, "tiles_per_block": nblocks / 256, "launch_ms_events": round(ms, 3)}
+        seg = {"k-loop": us(tt[:, :, 1] - tt[:, :, 0]).ravel(), "epilogue (to stores issued)": us(tt[:, :, 2] - tt[:, :, 1]).ravel(),
+               "tile period (k-loop start -> next k-loop start)": us(tt[:, 1:, 0] - tt[:, :-1, 0]).ravel(),
+               "epilogue end -> next k-loop start": us(tt[:, 1:, 0] - tt[:, :-1, 2]).ravel(),
+               "block entry (first k-loop start) spread": us(tt[:, 0, 0] - tt[:, 0, 0].min())}
+        for k, v in seg.items():
+            row[k] = {"median": round(float(np.median(v)), 2), "p10": round(float(np.percentile(v, 10)), 2), "p90": round(float(np.percentile(v, 90)), 2)}
+        print(json.dumps(row), flush=True)
+        continue
+    t = ts.cpu().numpy().reshape(-1, 8)[:nblocks].astype(np.int64)
     r0 = t[:, 0].min()
     us = lambda a: a / 100.0   # noqa: E731
     seg = {"entry->prologue DMA issued": us(t[:, 1] - t[:, 0]), "->first k-tile landed": us(t[:, 2] - t[:, 1]), "k-loop": us(t[:, 3] - t[:, 2]),
            "epilogue (to stores issued)": us(t[:, 4] - t[:, 3]), "whole block (thread 0)": us(t[:, 4] - t[:, 0])}
     # gap to the next block on the same CU
-    cu = t[:, 5]
+    cu = t[:, 5] & ~0xff & 0xffffffff | ((t[:, 5] >> 16) << 32)      # drop wave / SIMD / pipe ids: one key per CU (XCC, SE, SH, CU)
     gaps = []
     for c in np.unique(cu):
         idx = np.where(cu == c)[0]
