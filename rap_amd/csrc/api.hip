@@ -128,10 +128,11 @@ extern rap_tuning_t g_rap_attn_split;     // attn_f32.hip
 extern rap_tuning_t g_rap_gemm_h16_variant;   // gemm_h16.hip
 extern rap_tuning_t g_rap_attn_h16_variant;   // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_h16_persistent;   // gemm_h16.hip
+extern rap_tuning_t g_rap_gemm_f32_persistent;   // gemm_f32.hip
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 // Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
 // fp32 summation order -- 5 split-KV for few-token calls, 6 split-K for few-row calls, 7 fused qk-norm, 9 GEGLU's Phi by the
-// 1.5e-7 erfc polynomial (1) or erff (0), 11 persistent 16-bit GEMM.  Keys 0-4 (kernel-variant A/B of the round-1/2 experiments) exist
+// 1.5e-7 erfc polynomial (1) or erff (0), 11 / 12 persistent 16-bit / fp32 GEMM.  Keys 0-4 (kernel-variant A/B of the round-1/2 experiments) exist
 // only in a library built with -DRAP_ABLATION_BUILD; the shipped library refuses them.
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
 #ifdef RAP_ABLATION_BUILD
@@ -145,6 +146,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 7 && (value == 0 || value == 1)) { g_rap_fuse_qknorm = value; return RAP_OK; }
   if (key == 9 && (value == 0 || value == 1)) { g_rap_geglu_fast = value; return RAP_OK; }
   if (key == 11 && (value == 0 || value == 1)) { g_rap_gemm_h16_persistent = value; return RAP_OK; }
+  if (key == 12 && (value == 0 || value == 1)) { g_rap_gemm_f32_persistent = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 

@@ -341,6 +341,121 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
   if (mw + 64 <= p.M) store_tile(std::false_type{}); else store_tile(std::true_type{});
 }
 
+// Epilogue of one 128 x 64 wave tile (4 x 2 MFMA tiles) of the 256 x 256 kernels: as the 128x128 kernels' epilogues.
+template <int EPI>
+__device__ __forceinline__ void gemm_f32_epilogue_4x2(const GemmParams& p, f32x16 (&acc)[4][2], int mw, int nw, int hi, int l31) {
+  constexpr int TM = 4, TN = 2;
+  if (EPI == EPI_QKV_HEADMAJOR && p.gamma_q && nw < 2 * p.heads * 64) { qkv_store_normalised<TM>(p, acc, mw, nw, hi, l31); return; }
+  if (EPI == EPI_GEGLU) {
+    const int nout = (nw >> 1) + l31;
+    const float bh = p.bias ? p.bias[nw + l31] : 0.f;
+    const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+    if (p.geglu_fast) {                              // tuning key 9: packed-pair GEGLU (see half.h), stage-major over 8 pairs
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        f32x2 h2[8], g2[8], o2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          h2[j] = f32x2{acc[mi][0][2 * j], acc[mi][0][2 * j + 1]} + f32x2{bh, bh};
+          g2[j] = f32x2{acc[mi][1][2 * j], acc[mi][1][2 * j + 1]} + f32x2{bg, bg};
+        }
+        geglu_pairs<8>(h2, g2, o2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int m = mw + mi * 32 + mfma32_crow(2 * j, hi);
+          if (m < p.M) p.C[(size_t)m * p.ldc + nout] = o2[j].x;
+          if (m + 1 < p.M) p.C[(size_t)(m + 1) * p.ldc + nout] = o2[j].y;
+        }
+      }
+      return;
+    }
+    auto geglu = [&](auto G) {
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + mi * 32 + mfma32_crow(r, hi);
+          if (decltype(G)::value && m >= p.M) continue;
+          const float h = acc[mi][0][r] + bh;
+          const float g = acc[mi][1][r] + bg;
+          const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+          p.C[(size_t)m * p.ldc + nout] = h * ge;
+        }
+      }
+    };
+    if (mw + 32 * TM <= p.M) geglu(std::false_type{}); else geglu(std::true_type{});
+    return;
+  }
+  if (EPI == EPI_BIAS_RESID) {                     // see gemm_f32_dma_kernel: unconditional, batched residual loads
+    const bool full = mw + 32 * TM <= p.M;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      float rr[TN][16];
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = mw + mi * 32 + mfma32_crow(r, hi);
+          m = m < p.M ? m : p.M - 1;
+          rr[ni][r] = p.resid[(size_t)m * p.ldr + nw + ni * 32 + l31];
+        }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int n = nw + ni * 32 + l31;
+        const float bn = p.bias ? p.bias[n] : 0.f;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            p.C[(size_t)(mw + mi * 32 + mfma32_crow(r, hi)) * p.ldc + n] = rr[ni][r] + (acc[mi][ni][r] + bn);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mw + mi * 32 + mfma32_crow(r, hi);
+            if (m < p.M) p.C[(size_t)m * p.ldc + n] = rr[ni][r] + (acc[mi][ni][r] + bn);
+          }
+        }
+      }
+    }
+    return;
+  }
+  auto store_tile = [&](auto G) {
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int n = nw + ni * 32 + l31;
+      const float bn = p.bias ? p.bias[n] : 0.f;
+      size_t qkv_col = 0;                              // head-major plane and column of this lane's output column
+      if (EPI == EPI_QKV_HEADMAJOR) {
+        const int dmodel = p.heads * 64;
+        const int c = n / dmodel;
+        const int rem = n - c * dmodel;
+        qkv_col = ((size_t)c * p.heads + (rem >> 6)) * (size_t)p.M * 64 + (rem & 63);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + mi * 32 + mfma32_crow(r, hi);
+        if (decltype(G)::value && m >= p.M) continue;
+        const float v = acc[mi][ni][r] + bn;
+        if (EPI == EPI_BIAS) {
+          p.C[(size_t)m * p.ldc + n] = v;
+        } else if (EPI == EPI_BIAS_SILU) {
+          p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
+        } else if (EPI == EPI_BIAS_RELU) {
+          p.C[(size_t)m * p.ldc + n] = fmaxf(v, 0.f);
+        } else if (EPI == EPI_BIAS_ANCHOR) {
+          const int sel = p.anchor[m] ? 1 : 0;
+          p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
+        } else if (EPI == EPI_QKV_HEADMAJOR) {
+          p.C[qkv_col + (size_t)m * 64] = v;
+        }
+      }
+    }
+  }
+  };
+  if (mw + 32 * TM <= p.M) store_tile(std::false_type{}); else store_tile(std::true_type{});
+}
+
 // ---------------------------------------------------------------------------------------------
 // variant 32 (opt-in, rap_set_tuning(0, 32)): the same LDS-DMA loop on a 256x256 block tile, 8 waves (2 x 4), wave tile
 // 128 x 64 = 4 x 2 MFMA tiles -- the shape of the 16-bit GEMM (gemm_h16.hip).  Per 4 k-values a wave reads 6 fragments for 32
@@ -473,118 +588,140 @@ __global__ __launch_bounds__(512) void gemm_f32_dma256_kernel(GemmParams p) {
     BG_MMA(f1)
   }
 
-  // ---------------- epilogue: as the 128x128 kernels, over 4 x 2 MFMA tiles ----------------
-  const int mw = m0 + wm * TM * 32;
-  const int nw = n0 + wn * TN * 32;
-  if (EPI == EPI_QKV_HEADMAJOR && p.gamma_q && nw < 2 * p.heads * 64) { qkv_store_normalised<TM>(p, acc, mw, nw, hi, l31); return; }
-  if (EPI == EPI_GEGLU) {
-    const int nout = (nw >> 1) + l31;
-    const float bh = p.bias ? p.bias[nw + l31] : 0.f;
-    const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
-    if (p.geglu_fast) {                              // tuning key 9: packed-pair GEGLU (see half.h), stage-major over 8 pairs
+  gemm_f32_epilogue_4x2<EPI>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, hi, l31);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the 256 x 256 kernel (round 3; the same idea as gemm_h16_php_kernel, where scripts/gemm_ts.py itemised the per-tile
+// overhead of a one-tile-per-block launch: block start-up and tile decode, the wait for the first k-tile, the gap to the next block).
+// ONE block per CU walks the tiles of its XCD (virtual block id v = blockIdx.x + i * gridDim.x, gridDim.x a multiple of 8) and the
+// k-tiles of consecutive output tiles form one DMA stream: the last k-tile of an output tile requests the first k-tile of the NEXT one
+// into the spare stage exactly as it would request its own successor, so the next k-loop starts on landed data and the epilogue's
+// stores (straight from the accumulator registers: no LDS involved) drain under it.  Sources are a scalar base (tile origin + k offset)
+// plus one 32-bit per-thread byte offset per 16-byte chunk (the saddr form of global_load_lds): needs M % 256 == 0 (no row clamping).
+// Same MFMA order, same epilogue: results are bit-identical to gemm_f32_dma256_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_f32_dma256p_kernel(GemmParams p) {
+  constexpr int WN = 4, TM = 4, TN = 2, NT = 512, BM = 256, BN = 256;
+  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;          // 16-byte chunks per thread per k-tile
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];   // [A0 A1 B0 B1]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nt = p.N / BN;
+  const int total = (p.M / BM) * nt;
+  const int nk = p.K / GBK;
+
+  unsigned a_off[CA], w_off[CB];           // byte offsets inside the tile's A / W panel at k = 0
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-        f32x2 h2[8], g2[8], o2[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          h2[j] = f32x2{acc[mi][0][2 * j], acc[mi][0][2 * j + 1]} + f32x2{bh, bh};
-          g2[j] = f32x2{acc[mi][1][2 * j], acc[mi][1][2 * j + 1]} + f32x2{bg, bg};
-        }
-        geglu_pairs<8>(h2, g2, o2);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int m = mw + mi * 32 + mfma32_crow(2 * j, hi);
-          if (m < p.M) p.C[(size_t)m * p.ldc + nout] = o2[j].x;
-          if (m + 1 < p.M) p.C[(size_t)(m + 1) * p.ldc + nout] = o2[j].y;
-        }
-      }
-      return;
-    }
-    auto geglu = [&](auto G) {
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mw + mi * 32 + mfma32_crow(r, hi);
-          if (decltype(G)::value && m >= p.M) continue;
-          const float h = acc[mi][0][r] + bh;
-          const float g = acc[mi][1][r] + bg;
-          const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
-          p.C[(size_t)m * p.ldc + nout] = h * ge;
-        }
-      }
-    };
-    if (mw + 32 * TM <= p.M) geglu(std::false_type{}); else geglu(std::true_type{});
-    return;
+  for (int i = 0; i < CA; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 3;
+    const int lslot = (id & 7) ^ ((row >> 1) & 7);
+    a_off[i] = (unsigned)(row * p.lda + 4 * lslot) * 4u;
   }
-  if (EPI == EPI_BIAS_RESID) {                     // see gemm_f32_dma_kernel: unconditional, batched residual loads
-    const bool full = mw + 32 * TM <= p.M;
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-      float rr[TN][16];
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int m = mw + mi * 32 + mfma32_crow(r, hi);
-          m = m < p.M ? m : p.M - 1;
-          rr[ni][r] = p.resid[(size_t)m * p.ldr + nw + ni * 32 + l31];
-        }
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) {
-        const int n = nw + ni * 32 + l31;
-        const float bn = p.bias ? p.bias[n] : 0.f;
-        if (full) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            p.C[(size_t)(mw + mi * 32 + mfma32_crow(r, hi)) * p.ldc + n] = rr[ni][r] + (acc[mi][ni][r] + bn);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = mw + mi * 32 + mfma32_crow(r, hi);
-            if (m < p.M) p.C[(size_t)m * p.ldc + n] = rr[ni][r] + (acc[mi][ni][r] + bn);
-          }
-        }
-      }
-    }
-    return;
+  for (int i = 0; i < CB; ++i) {
+    const int id = i * NT + tid;
+    const int row = id >> 3;
+    const int lslot = (id & 7) ^ ((row >> 1) & 7);
+    w_off[i] = (unsigned)(row * p.ldw + 4 * lslot) * 4u;
   }
-  auto store_tile = [&](auto G) {
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      const int n = nw + ni * 32 + l31;
-      const float bn = p.bias ? p.bias[n] : 0.f;
-      size_t qkv_col = 0;                              // head-major plane and column of this lane's output column
-      if (EPI == EPI_QKV_HEADMAJOR) {
-        const int dmodel = p.heads * 64;
-        const int c = n / dmodel;
-        const int rem = n - c * dmodel;
-        qkv_col = ((size_t)c * p.heads + (rem >> 6)) * (size_t)p.M * 64 + (rem & 63);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mw + mi * 32 + mfma32_crow(r, hi);
-        if (decltype(G)::value && m >= p.M) continue;
-        const float v = acc[mi][ni][r] + bn;
-        if (EPI == EPI_BIAS) {
-          p.C[(size_t)m * p.ldc + n] = v;
-        } else if (EPI == EPI_BIAS_SILU) {
-          p.C[(size_t)m * p.ldc + n] = v / (1.0f + expf(-v));
-        } else if (EPI == EPI_BIAS_RELU) {
-          p.C[(size_t)m * p.ldc + n] = fmaxf(v, 0.f);
-        } else if (EPI == EPI_BIAS_ANCHOR) {
-          const int sel = p.anchor[m] ? 1 : 0;
-          p.C[(size_t)m * p.ldc + n] = v + p.anchor_emb[(size_t)sel * p.N + n];
-        } else if (EPI == EPI_QKV_HEADMAJOR) {
-          p.C[qkv_col + (size_t)m * 64] = v;
-        }
-      }
-    }
+
+  f32x16 acc[TM][TN];
+  const int sw = (l31 >> 1) & 7;
+  const int a_row = (wm * TM * 32 + l31) * 128;              // byte offsets inside one A / B buffer
+  const int b_row = (wn * TN * 32 + l31) * 128;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem256;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+#define BP_DMA1(VOFF, SBASE, LDSB)                                                                            \
+  {                                                                                                           \
+    unsigned keep_;                                                                                           \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(VOFF), "s"(LDSB), "s"(SBASE) : "memory");                                \
   }
+#define BP_DMA(ABASE, WBASE, BUF)                                                                             \
+  _Pragma("unroll") for (int i = 0; i < CA; ++i)                                                              \
+    BP_DMA1(a_off[i], ABASE, lds_wave + (unsigned)((BUF) * ABYTES + i * NT * 16))                             \
+  _Pragma("unroll") for (int i = 0; i < CB; ++i)                                                              \
+    BP_DMA1(w_off[i], WBASE, lds_wave + (unsigned)(2 * ABYTES + (BUF) * BBYTES + i * NT * 16))
+  // raw barrier: __syncthreads() would also fence (drain) the epilogue's global stores
+#define BP_SYNC asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+
+  struct Frag { float4 a[TM]; float4 b[TN]; };
+  Frag f0, f1;
+  auto read_frag = [&](Frag& f, int buf, int g) {
+    const int co = ((2 * g + hi) ^ sw) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      f.a[i] = *reinterpret_cast<const float4*>(smem256 + buf * ABYTES + a_row + i * 32 * 128 + co);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      f.b[j] = *reinterpret_cast<const float4*>(smem256 + 2 * ABYTES + buf * BBYTES + b_row + j * 32 * 128 + co);
   };
-  if (mw + 32 * TM <= p.M) store_tile(std::false_type{}); else store_tile(std::true_type{});
+
+  auto tile_bases = [&](int v, const unsigned char*& ab, const unsigned char*& wb, int& m0, int& n0) {
+    const int logical = xcd_remap(v, total);
+    m0 = (logical / nt) * BM;
+    n0 = (logical % nt) * BN;
+    ab = reinterpret_cast<const unsigned char*>(p.A) + (size_t)m0 * p.lda * 4;
+    wb = reinterpret_cast<const unsigned char*>(p.W) + (size_t)n0 * p.ldw * 4;
+  };
+
+  int v = blockIdx.x;
+  const unsigned char *a_cur, *w_cur, *a_nxt = nullptr, *w_nxt = nullptr;
+  int m0, n0, m0n = 0, n0n = 0;
+  tile_bases(v, a_cur, w_cur, m0, n0);
+  BP_DMA(a_cur, w_cur, 0)
+  BP_SYNC
+  int par = 0;                              // stage of the current k-tile of the stream
+
+  for (;;) {
+    const int vn = v + (int)gridDim.x;
+    const bool has_next = vn < total;
+    if (has_next) tile_bases(vn, a_nxt, w_nxt, m0n, n0n);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    read_frag(f0, par, 0);
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = par;
+      const bool in1 = kt + 1 < nk;
+      if (in1) { BP_DMA(a_cur + (size_t)(kt + 1) * (GBK * 4), w_cur + (size_t)(kt + 1) * (GBK * 4), cur ^ 1) }
+      else if (has_next) { BP_DMA(a_nxt, w_nxt, cur ^ 1) }       // the stream continues into the next output tile
+      read_frag(f1, cur, 1);
+      BG_FENCE
+      BG_MMA(f0)
+      BG_FENCE
+      read_frag(f0, cur, 2);
+      BG_FENCE
+      BG_MMA(f1)
+      BG_FENCE
+      read_frag(f1, cur, 3);
+      BG_FENCE
+      BG_MMA(f0)
+      BG_FENCE
+      BP_SYNC                              // successor k-tile landed (vmcnt(0): also this block's earlier stores) and visible; reads of `cur` complete
+      if (in1) read_frag(f0, cur ^ 1, 0);
+      BG_FENCE
+      BG_MMA(f1)
+      BG_FENCE
+      par ^= 1;
+    }
+    gemm_f32_epilogue_4x2<EPI>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, hi, l31);
+    if (!has_next) break;
+    v = vn; a_cur = a_nxt; w_cur = w_nxt; m0 = m0n; n0 = n0n;
+  }
 }
 
 // C[m][n] = resid[m][n] + bias[n] + sum_s part[s][m][n]   (the split-K path of EPI_BIAS_RESID; one thread per 4 columns)
@@ -612,10 +749,31 @@ __global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(GemmParams p, 
 // RAP_ABLATION_BUILD only: rap_set_tuning(0, 16 | 32) forces one of the two.
 rap_tuning_t g_rap_gemm_variant = 48;
 
+rap_tuning_t g_rap_gemm_f32_persistent = 1;     // tuning key 12: the persistent 256 x 256 kernel for full-tile shapes (1, default) or one tile per block (0)
+
 template <int EPI>
 static int launch_gemm_variant(hipStream_t stream, const GemmParams& p, int variant) {
   const int mt = (p.M + GBM - 1) / GBM;
-  if (variant == 32 && p.N % 256 == 0) {
+  if (variant == 32 && p.N % 256 == 0 && g_rap_gemm_f32_persistent && p.M % 256 == 0 &&
+      (long)(p.M / 256) * (p.N / 256) >= 512 && p.lda <= (1 << 20) && p.ldw <= (1 << 20)) {
+    constexpr int LDS = 2 * (256 + 256) * 128;
+    auto kern = gemm_f32_dma256p_kernel<EPI>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      rap_set_last_hip_error((int)hipGetLastError());
+      return RAP_ERR_HIP;
+    }
+    static std::atomic<int> n_cu_cache[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RAP_ERR_HIP;
+    int n_cu = (dev >= 0 && dev < 16) ? n_cu_cache[dev].load() : 0;
+    if (n_cu == 0) {
+      if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) return RAP_ERR_HIP;
+      n_cu = n_cu >= 8 ? (n_cu / 8) * 8 : n_cu;
+      if (dev >= 0 && dev < 16) n_cu_cache[dev] = n_cu;
+    }
+    const int total = (p.M / 256) * (p.N / 256);
+    hipLaunchKernelGGL(kern, dim3(total < n_cu ? total : n_cu), dim3(512), LDS, stream, p);
+  } else if (variant == 32 && p.N % 256 == 0) {
     constexpr int LDS = 2 * (256 + 256) * 128;
     auto kern = gemm_f32_dma256_kernel<EPI>;
     // per device and cheap: set unconditionally (a process may drive several GPUs)

@@ -117,6 +117,40 @@ def test_gemm_qkv_headmajor_scatter(lib, dev):
     assert (C.cpu().double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("epi,M,N,K", [(0, 16384, 2048, 512), (1, 65536, 512, 2048), (1, 65536, 512, 512), (2, 65536, 512, 512), (3, 16384, 2048, 512),
+                                       (4, 32768, 1536, 512)])
+def test_persistent_fp32_gemm_is_bit_identical_to_the_one_tile_per_block_kernel(lib, dev, epi, M, N, K):
+    """Round 3: full-tile shapes (M % 256 == 0, at least 512 tiles of 256 x 256, K >= 256) run on the PERSISTENT 256 x 256 kernel;
+    rap_set_tuning(12, 0) restores one tile per block.  Same MFMA order, same epilogue: bit-identical for every epilogue (0 bias,
+    1 bias + residual in place, 2 bias + SiLU, 3 GEGLU, 4 head-major QKV with the fused qk-norm left to the model tests)."""
+    g = torch.Generator(device=dev).manual_seed(200 + epi)
+    A = torch.randn(M, K, device=dev, generator=g); W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    bias = torch.randn(N, device=dev, generator=g)
+    outs = []
+    try:
+        for persistent in (1, 0):
+            assert lib.rap_set_tuning(12, persistent) == 0
+            if epi == 1:
+                C = torch.randn(M, N, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+                gemm(lib, dev, 1, A, W, C, M, N, K, bias=bias, resid=C)
+            elif epi == 3:
+                C = torch.zeros(M, N // 2, device=dev); gemm(lib, dev, 3, A, W, C, M, N, K, bias=bias, ldc=N // 2)
+            elif epi == 4:
+                C = torch.zeros(3, 8, M, 64, device=dev); gemm(lib, dev, 4, A, W, C, M, N, K, bias=bias, heads=8)
+            else:
+                C = torch.zeros(M, N, device=dev); gemm(lib, dev, epi, A, W, C, M, N, K, bias=bias)
+            outs.append(C.clone())
+    finally:
+        assert lib.rap_set_tuning(12, 1) == 0
+    assert torch.equal(outs[0], outs[1])
+    if epi in (0, 1):
+        rows = torch.randint(0, M, (64,), generator=torch.Generator().manual_seed(3)).to(dev)
+        ref = A[rows].double() @ W.double().T + bias.double()
+        if epi == 1:
+            ref = ref + torch.randn(M, N, device=dev, generator=torch.Generator(device=dev).manual_seed(5))[rows].double()
+        assert (outs[0][rows].double() - ref).abs().max().item() < 2e-5 * max(1.0, K / 512)
+
+
 def test_gemm_full_size_linearity_property(lib, dev):
     """BASELINE geometry (TP = 32*8192 rows, d = 512): GEMM(a1 + a2) == GEMM(a1) + GEMM(a2) to round-off,
     and a spot check of 64 random rows against fp64."""
