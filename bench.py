@@ -62,15 +62,16 @@ SHIPPED_ATTENTION_SYMBOL = {
 
 def pmc_traffic(dtype, symbol):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside this
-    process; the passes are separate runs of scripts/kernel_bench.py, summarised in profiles/).  Returned only when the passes
-    measured the instantiation this run timed (`kernel_symbol` in the JSON); otherwise (None, reason)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if dtype == "float32" else "pmc_traffic_h16.json")
+    process; the passes are separate runs, scripts/pmc_passes.sh, summarised in profiles/pmc_traffic.json per kernel SYMBOL).
+    Returned only when the passes measured the instantiation this run timed; otherwise (None, reason)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             j = json.load(f)
-        if j.get("kernel_symbol") != symbol:
-            return None, f"no PMC pass for {symbol} (profiles/ holds {j.get('kernel_symbol')})"
-        return j["hbm_bytes_per_launch"], j["source"]
+        for sym, k in j["kernels"].items():
+            if sym == symbol:
+                return k["hbm_bytes_per_launch"], f"{j['source']}; measured on: {k['measured_on']}"
+        return None, f"no PMC pass for {symbol} in profiles/pmc_traffic.json"
     except (OSError, KeyError, ValueError):
         return None, "no PMC summary under profiles/"
 
@@ -96,8 +97,8 @@ def parse_args():
     ap.add_argument("--residual-dtype", default=None, choices=["auto", "float32", "float16"],
                     help="storage of the residual stream in the 16-bit modes (default: rap_amd's default, see PointCloudDiT)")
     ap.add_argument("--gamma-scale", type=float, default=3.0,
-                    help="multiplier on the seeded q/k-norm gains for the extra 'roofline_online_softmax' leg (1 warm-up + 2 timed sample "
-                         "calls per precision; 0 = skip the leg)")
+                    help="multiplier on the seeded q/k-norm gains for the extra 'roofline_online_softmax' leg (1 warm-up + 1 timed sample "
+                         "call per precision; 0 = skip the leg)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra bf16 measurement of the same workload that a float32 run appends as 'reduced_precision'")
     return ap.parse_args()
@@ -406,10 +407,13 @@ def main():
     secondary = None
     if args.dtype == "float32" and not args.no_secondary:
         # the same workload with bf16 MFMA blocks (BASELINE configs[2]'s per-GPU shard), reported beside the fp32 headline
-        e2, p2, l2 = run_mode("bfloat16", args.steps, args.warmup)
+        # (at most 10 timed + 2 warm-up calls: the leg is a secondary measurement and the default run has to stay within minutes)
+        sec_steps, sec_warm = min(args.steps, 10), min(args.warmup, 2)
+        e2, p2, l2 = run_mode("bfloat16", sec_steps, sec_warm)
         a, b = l2["end_point_trajectory"][-1], last["end_point_trajectory"][-1]
         secondary = {
-            "dtype": "bf16", "value": pts_per_rank * world * args.steps / e2, "unit": "points/s", "ms_per_step": 1e3 * e2 / args.steps,
+            "dtype": "bf16", "value": pts_per_rank * world * sec_steps / e2, "unit": "points/s", "ms_per_step": 1e3 * e2 / sec_steps,
+            "steps": sec_steps, "warmup": sec_warm,
             "host_call_ms_per_step": run_mode.host_enqueue_ms,
             "workload": f"same batch, bf16 MFMA transformer blocks (fp32 accumulate / LN statistics / softmax / head; residual stream held in {run_mode.residual_dtype})",
             "residual_stream": run_mode.residual_dtype,
@@ -429,15 +433,15 @@ def main():
         online = {"gamma_scale": args.gamma_scale,
                   "what": "same batch, MultiHeadRMSNorm gains of the seeded weights multiplied by gamma_scale: every logit bound "
                           "8 max|gamma_q| max|gamma_k| exceeds 40, so every attention launch takes the online-softmax kernel "
-                          "(what a trained checkpoint with large gains runs); 1 warm-up + 2 timed sample calls"}
+                          "(what a trained checkpoint with large gains runs); 1 warm-up + 1 timed sample call"}
         for dt_name in ([args.dtype] if (args.dtype != "float32" or args.no_secondary) else ["float32", "bfloat16"]):
-            eo, po, lo = run_mode(dt_name, 2, 1, gamma_scale=args.gamma_scale)
+            eo, po, lo = run_mode(dt_name, 1, 1, gamma_scale=args.gamma_scale)
             ro = roofline_of(dt_name, po, run_mode.prof_region_s, bounded=False)
             if run_mode.bounded_launches != 0:
                 raise SystemExit(f"gamma scale {args.gamma_scale}: {run_mode.bounded_launches} launches still bounded")
             if ro:
-                ro["points_per_s"] = pts_per_rank * 2 / eo
-                ro["ms_per_step"] = 1e3 * eo / 2
+                ro["points_per_s"] = pts_per_rank / eo
+                ro["ms_per_step"] = 1e3 * eo
             online[DTYPE_TAG[dt_name]] = ro
             if dt_name == args.dtype and rank == 0 and not args.no_cpu_baseline:
                 # parity of the online path: pair 0, first flow step, vs the CPU oracle run with the same scaled gains

@@ -187,15 +187,18 @@ int64_t rap_spinnet_weight_count(void);
 int rap_spinnet_create(const float* d_weights, int64_t n_floats, void* stream, rap_spinnet** out);
 void rap_spinnet_destroy(rap_spinnet* m);
 size_t rap_spinnet_workspace_bytes(int32_t keypoints_per_chunk);
-/* Patch alignment of MiniSpinNet.forward (patch_embedder.py:141-166): 1 (default) = is_aligned_to_global_z, the shipped demo setting
- * (R = I); 0 = every patch is rotated so that its own normal -- the singular vector of the smallest singular value of the patch
- * covariance, oriented towards the origin (cal_Z_axis, utils/common.py:539-557) -- becomes +z (RodsRotatFormula, :472-496). */
-int rap_spinnet_set_alignment(rap_spinnet* m, int32_t aligned_to_global_z);
-/* A/B knob: 1 (default) = the seven 3x3 cylindrical convolutions as implicit GEMMs (spin_conv3x3_kernel: the im2col gather happens in the
- * LDS-DMA source addresses, 32- / 64- / 128-column tiles); 0 = the round-1 path (materialised im2col + the fp32 GEMM at 128 padded columns). */
-int rap_spinnet_set_conv_path(rap_spinnet* m, int32_t implicit_gemm);
+/* flags of rap_spinnet_describe (per call: the handle is immutable after rap_spinnet_create, two callers may share it):
+ *   RAP_SPINNET_PATCH_LRF   patch alignment of MiniSpinNet.forward (patch_embedder.py:141-166): unset (default) = is_aligned_to_global_z,
+ *                           the shipped demo setting (R = I); set = every patch is rotated so that its own normal -- the singular vector of
+ *                           the smallest singular value of the patch covariance, oriented towards the origin (cal_Z_axis,
+ *                           utils/common.py:539-557) -- becomes +z (RodsRotatFormula, :472-496);
+ *   RAP_SPINNET_IM2COL_PATH A/B: unset (default) = the seven 3x3 cylindrical convolutions as implicit GEMMs (spin_conv3x3_kernel: the
+ *                           im2col gather happens in the LDS-DMA source addresses); set = the round-1 path (materialised im2col + the
+ *                           fp32 GEMM at 128 padded columns). */
+#define RAP_SPINNET_PATCH_LRF 1
+#define RAP_SPINNET_IM2COL_PATH 2
 int rap_spinnet_describe(const rap_spinnet* m, const float* pts, const int32_t* perm, int64_t N, const float* kpts, int32_t K,
-                         float des_r, float* desc_out, int32_t keypoints_per_chunk, void* ws, size_t ws_bytes, void* stream);
+                         float des_r, int32_t flags, float* desc_out, int32_t keypoints_per_chunk, void* ws, size_t ws_bytes, void* stream);
 
 /* Farthest point sampling, the keypoint selection in front of MiniSpinNet (reference dataset_process/utils/
  * point_sampling_utils.py:263-305 -> pytorch3d.ops.sample_farthest_points with lengths, per-cloud K and a random start):

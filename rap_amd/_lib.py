@@ -72,9 +72,7 @@ SIGNATURES = {
     "rap_spinnet_create": (c_int32, [_P, c_int64, _P, ctypes.POINTER(_P)]),
     "rap_spinnet_destroy": (None, [_P]),
     "rap_spinnet_workspace_bytes": (c_size_t, [c_int32]),
-    "rap_spinnet_set_alignment": (c_int32, [_P, c_int32]),
-    "rap_spinnet_set_conv_path": (c_int32, [_P, c_int32]),
-    "rap_spinnet_describe": (c_int32, [_P, _P, _P, c_int64, _P, c_int32, c_float, _P, c_int32, _P, c_size_t, _P]),
+    "rap_spinnet_describe": (c_int32, [_P, _P, _P, c_int64, _P, c_int32, c_float, c_int32, _P, c_int32, _P, c_size_t, _P]),
     "rap_outlier_workspace_bytes": (c_size_t, [c_int64]),
     "rap_statistical_outliers": (c_int32, [_P, c_int64, c_int32, ctypes.c_double, _P, _P, _P, _P, c_size_t, _P]),
     "rap_check_batch": (c_int32, [_P, _P, c_int32, c_int32, c_int64, _P, _P]),

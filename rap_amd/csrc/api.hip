@@ -932,8 +932,6 @@ struct rap_spinnet {
   const void* pool_w;         // SpinPoolW on the device
   SpinLayer layers[8];
   const float* zeros = nullptr;   // 256 bytes of zeros: the elevation pad of the implicit-GEMM convolutions
-  int implicit = 1;           // 1 (default): layers 1-7 as implicit GEMMs (spin_conv3x3_kernel); 0: the r01 im2col + GEMM path
-  int lrf = 0;                // 1: patches are aligned to their own normal (is_aligned_to_global_z = False)
 };
 static const int kSpinCin[8] = {16, 64, 64, 128, 128, 64, 64, 32};
 static const int kSpinCout[8] = {64, 64, 128, 128, 64, 64, 32, 32};
@@ -1056,22 +1054,14 @@ extern "C" size_t rap_spinnet_workspace_bytes(int32_t keypoints_per_chunk) {
   return keypoints_per_chunk <= 0 ? 0 : carve_spin(keypoints_per_chunk, nullptr).total;
 }
 
-extern "C" int rap_spinnet_set_conv_path(rap_spinnet* m, int32_t implicit_gemm) {
-  if (!m) return RAP_ERR_INVALID;
-  m->implicit = implicit_gemm ? 1 : 0;
-  return RAP_OK;
-}
-
-extern "C" int rap_spinnet_set_alignment(rap_spinnet* m, int32_t aligned_to_global_z) {
-  if (!m) return RAP_ERR_INVALID;
-  m->lrf = aligned_to_global_z ? 0 : 1;
-  return RAP_OK;
-}
-
 extern "C" int rap_spinnet_describe(const rap_spinnet* m, const float* pts, const int32_t* perm, int64_t N, const float* kpts,
-                                    int32_t K, float des_r, float* desc_out, int32_t keypoints_per_chunk, void* ws, size_t ws_bytes,
-                                    void* stream_) {
+                                    int32_t K, float des_r, int32_t flags, float* desc_out, int32_t keypoints_per_chunk, void* ws,
+                                    size_t ws_bytes, void* stream_) {
   if (!m || !pts || !kpts || !desc_out || N <= 0 || K < 0 || !(des_r > 0.f) || keypoints_per_chunk <= 0) return RAP_ERR_INVALID;
+  if (flags & ~(RAP_SPINNET_PATCH_LRF | RAP_SPINNET_IM2COL_PATH)) return RAP_ERR_INVALID;
+  // per-call options (round 3, ADVICE r02: they used to be mutable state of the handle, a race between two callers of one model)
+  const int lrf = (flags & RAP_SPINNET_PATCH_LRF) ? 1 : 0;
+  const bool implicit = !(flags & RAP_SPINNET_IM2COL_PATH);
   if (K == 0) return RAP_OK;
   if (!ws) return RAP_ERR_WORKSPACE;
   SpinWs w = carve_spin(keypoints_per_chunk, (char*)ws);
@@ -1081,13 +1071,13 @@ extern "C" int rap_spinnet_describe(const rap_spinnet* m, const float* pts, cons
   for (int k0 = 0; k0 < K; k0 += keypoints_per_chunk) {
     const int Kc = K - k0 < keypoints_per_chunk ? K - k0 : keypoints_per_chunk;
     const int M = Kc * 140;
-    if ((rc = launch_spin_patch(stream, pts, perm, (long)N, kpts + (size_t)k0 * 3, Kc, des_r, m->vox, m->h_w1, m->h_b1, w.x0, m->lrf))) return rc;
+    if ((rc = launch_spin_patch(stream, pts, perm, (long)N, kpts + (size_t)k0 * 3, Kc, des_r, m->vox, m->h_w1, m->h_b1, w.x0, lrf))) return rc;
     float* yin = nullptr;
     float* yout = w.Y0;
     int ld_in = 128;
     for (int i = 0; i < 8; ++i) {
       const SpinLayer& L = m->layers[i];
-      if (m->implicit) {
+      if (implicit) {
         // implicit GEMM: the gather of the 3x3(x3) cylindrical neighbourhood happens in the DMA source addresses, output is dense (M, Cout)
         if (i == 0) rc = launch_spin_conv3d(stream, w.x0, L.Wt, L.bt, m->zeros, yout, M);
         else rc = launch_spin_conv3x3(stream, yin, ld_in, L.Cin, L.Wt, L.bt, m->zeros, yout, L.Cout, M, L.bn_relu);

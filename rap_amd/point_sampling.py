@@ -132,7 +132,14 @@ def remove_statistical_outlier(points: torch.Tensor, nb_neighbors: int = 20, std
 def calculate_voxel_coverage(points: torch.Tensor, voxel_size: float, path: str | None = None) -> int:
     """point_sampling_utils.py:11-31: number of distinct voxels floor(p / voxel_size) the cloud occupies (exact key: the
     down-sampling table reproduces the reference's colliding cubic key and cannot be used to count).  A byte table over the grid's
-    bounding box, or a radix sort of the per-point voxel ids when that box is large against the number of points."""
+    bounding box, or a radix sort of the per-point voxel ids when that box is large against the number of points.
+
+    Precision: the cloud is taken as float32 and the voxel index is floor(fp32(p) / fp32(voxel_size)).  The reference computes
+    np.floor(points / voxel_size) in the array's OWN dtype, so for float64 input a point within one fp32 rounding of a voxel face
+    (|p / voxel_size - round(p / voxel_size)| < ~6e-8 |p / voxel_size|) can be counted in the neighbouring voxel; identical counts are
+    guaranteed (and tested against the reference's own function) for float32 clouds, which is what the reference's pipeline feeds it
+    (extract_sample_features.py loads .ply vertices as float32).  The same holds for voxel_down_sample_torch and
+    remove_statistical_outlier below."""
     if points.shape[0] == 0:
         return 0
     _require_cuda(points, "points")

@@ -154,9 +154,9 @@ class MiniSpinNet:
         lib = _lib.load()
         chunk = max(1, min(self.keypoints_per_chunk, K))
         ws = workspace(device, lib.rap_spinnet_workspace_bytes(chunk))
-        _lib.check(lib.rap_spinnet_set_alignment(self._handle, 1 if is_aligned_to_global_z else 0), "rap_spinnet_set_alignment")
+        flags = (0 if is_aligned_to_global_z else 1) | (2 if getattr(self, "im2col_path", False) else 0)     # rapflow.h: RAP_SPINNET_*
         with torch.cuda.device(device):
-            rc = lib.rap_spinnet_describe(self._handle, _lib.ptr(p), _lib.ptr(perm_d), N, _lib.ptr(kp), K, float(des_r), _lib.ptr(desc),
+            rc = lib.rap_spinnet_describe(self._handle, _lib.ptr(p), _lib.ptr(perm_d), N, _lib.ptr(kp), K, float(des_r), flags, _lib.ptr(desc),
                                           chunk, _lib.ptr(ws), ws.numel(), _lib.current_stream(device))
         _lib.check(rc, "rap_spinnet_describe")
         return {"desc": desc}

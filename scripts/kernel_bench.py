@@ -37,10 +37,6 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
     tdt = {1: torch.bfloat16, 2: torch.float16}[dt]
     PEAK = 2500.0
     rows = []
-    if args.h16_gemm_variant >= 0:
-        assert lib.rap_set_tuning(2, args.h16_gemm_variant) == 0
-    if args.h16_attn_variant >= 0:
-        assert lib.rap_set_tuning(3, args.h16_attn_variant) == 0
     nblk = (TP + 255) // 256 * 256 // 64
 
     def gemm_case(name, epi, N, K, out_half, Cw=None, heads=0):
@@ -58,7 +54,7 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
             assert rc == 0, rc
         t = timeit(fn)
         fl = 2.0 * TP * N * K
-        rows.append({"kernel": f"gemm_h16[{name}]", "dtype": args.dtype, "variant": args.h16_gemm_variant, "pad_lda": args.pad_lda, "M": TP, "N": N, "K": K,
+        rows.append({"kernel": f"gemm_h16[{name}]", "dtype": args.dtype, "pad_lda": args.pad_lda, "M": TP, "N": N, "K": K,
                      "ms": t * 1e3, "tflops": fl / t / 1e12, "frac_of_2500TF": fl / t / 1e12 / PEAK})
 
     if args.only in ("", "gemm"):
@@ -68,13 +64,12 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
         gemm_case("ff2 +bias +resid (fp32 out)", 1, d, 4 * d, False)
     if args.only in ("", "attention"):
         qk = torch.nn.functional.normalize(torch.randn(2, H, TP, 64, device=dev, generator=g), dim=-1) * 8
-        if args.h16_attn_variant == 10:
-            qk[0] *= 0.125 * 1.4426950408889634      # what the model path's qk-norm writes for the pre-scaled kernel
         qk = qk.to(tdt)
         vt = torch.randn(H, nblk, 64, 64, device=dev, generator=g).to(tdt)
         out = torch.empty(TP, d, device=dev, dtype=tdt)
-        bound = torch.full((H,), 8.01, device=dev) if args.bounded else None     # |q| = |k| = 8  ->  q.k/8 <= 8
-        for name, L in (("per part", args.points), ("per sample", args.points * args.views)):
+        for bounded, (name, L) in [(b, c) for b in ((1, 0) if args.bounded == 2 else (args.bounded,))
+                                   for c in (("per part", args.points), ("per sample", args.points * args.views))]:
+            bound = torch.full((H,), 8.01, device=dev) if bounded else None     # |q| = |k| = 8  ->  q.k/8 <= 8
             cu = torch.arange(0, TP + 1, L, dtype=torch.int32, device=dev)
             nseg = cu.numel() - 1
             ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, nseg))
@@ -84,7 +79,7 @@ def bench_h16(args, lib, dev, st, TP, d, H, g):
                 assert rc == 0, rc
             t = timeit(fn, iters=1 if args.pmc else 5, warm=0 if args.pmc else 2)
             fl = 4.0 * H * 64 * L * TP
-            rows.append({"kernel": f"attention_h16[{name} L={L}]", "dtype": args.dtype, "variant": args.h16_attn_variant, "bounded": bool(args.bounded), "ms": t * 1e3, "tflops": fl / t / 1e12,
+            rows.append({"kernel": f"attention_h16[{name} L={L}]", "dtype": args.dtype, "bounded": bool(bounded), "ms": t * 1e3, "tflops": fl / t / 1e12,
                          "frac_of_2500TF": fl / t / 1e12 / PEAK})
     if args.only == "":
         x = torch.randn(TP, d, device=dev, generator=g); y = torch.empty(TP, d, device=dev, dtype=tdt)
@@ -108,29 +103,19 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--views", type=int, default=2)
-    ap.add_argument("--gemm-stagger", type=int, default=-1, help="fp32 GEMM tuning key 4")
     ap.add_argument("--only", default="", help="'attention' or 'gemm': restrict to one kernel family (PMC passes)")
     ap.add_argument("--pmc", action="store_true", help="one launch per kernel, no warm-up (for rocprofv3 --pmc passes)")
-    ap.add_argument("--gemm-variant", type=int, default=-1)
-    ap.add_argument("--attn-variant", type=int, default=-1)
     ap.add_argument("--dtype", default="float32", help="float32 | bfloat16 | float16 (16-bit: GEMM / attention / LN / qknorm twins)")
-    ap.add_argument("--h16-gemm-variant", type=int, default=-1)
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE", help="rap_set_tuning(KEY, VALUE) before the run")
     ap.add_argument("--pad-lda", type=int, default=0, help="16-bit GEMM: extra elements per row of A and W (row stride K + pad)")
-    ap.add_argument("--h16-attn-variant", type=int, default=-1, help="timing-only ablations of the 16-bit attention kernel")
-    ap.add_argument("--bounded", type=int, default=1, help="pass per-head logit bounds to the 16-bit attention (bounded-softmax v2, bf16)")
+    ap.add_argument("--bounded", type=int, default=1, help="attention: 1 = pass per-head logit bounds (bounded softmax kernel), 0 = none (online "
+                                                            "softmax kernel), 2 = time both")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
     for kv in args.tuning:
         k_, v_ = (int(x) for x in kv.split('='))
         assert lib.rap_set_tuning(k_, v_) == 0, kv
-    if args.gemm_variant >= 0:
-        assert lib.rap_set_tuning(0, args.gemm_variant) == 0
-    if args.gemm_stagger >= 0:
-        assert lib.rap_set_tuning(4, args.gemm_stagger) == 0
-    if args.attn_variant >= 0:
-        assert lib.rap_set_tuning(1, args.attn_variant) == 0
     st = lambda: _lib.current_stream(dev)
     TP = args.batch * args.views * args.points
     d, H = 512, 8
@@ -152,7 +137,7 @@ def main():
             assert rc == 0, rc
         t = timeit(fn)
         fl = 2.0 * TP * N * K
-        rows.append({"kernel": f"gemm_f32[{name}]", "variant": args.gemm_variant, "stagger": args.gemm_stagger, "M": TP, "N": N, "K": K, "ms": t * 1e3, "tflops": fl / t / 1e12,
+        rows.append({"kernel": f"gemm_f32[{name}]", "M": TP, "N": N, "K": K, "ms": t * 1e3, "tflops": fl / t / 1e12,
                      "frac_of_157.3TF": fl / t / 1e12 / 157.3})
 
     if args.only in ("", "gemm"):
@@ -171,18 +156,19 @@ def main():
     qkv = torch.randn(3, H, TP, 64, device=dev, generator=g)
     qkv[:2] = torch.nn.functional.normalize(qkv[:2], dim=-1) * 8
     out = torch.empty(TP, d, device=dev)
-    bound32 = torch.full((H,), 8.01, device=dev) if args.bounded else None     # |q| = |k| = 8  ->  q.k/8 <= 8
-    for name, L in (("per part", args.points), ("per sample", args.points * args.views)):
-        cu = torch.arange(0, TP + 1, L, dtype=torch.int32, device=dev)
-        nseg = cu.numel() - 1
-        ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, nseg))
-        def fn():
-            rc = lib.rap_attention_f32(_lib.ptr(qkv), _lib.ptr(cu), nseg, _lib.ptr(out), TP, H, _lib.ptr(bound32), _lib.ptr(ws), ws.numel(), st())
-            assert rc == 0, rc
-        t = timeit(fn, iters=1 if args.pmc else 3, warm=0 if args.pmc else 1)
-        fl = 4.0 * H * 64 * L * TP
-        rows.append({"kernel": f"attention_f32[{name} L={L}]", "variant": args.attn_variant, "bounded": bool(args.bounded), "ms": t * 1e3, "tflops": fl / t / 1e12,
-                     "frac_of_157.3TF": fl / t / 1e12 / 157.3})
+    for bounded in ((1, 0) if args.bounded == 2 else (args.bounded,)):
+        bound32 = torch.full((H,), 8.01, device=dev) if bounded else None     # |q| = |k| = 8  ->  q.k/8 <= 8
+        for name, L in (("per part", args.points), ("per sample", args.points * args.views)):
+            cu = torch.arange(0, TP + 1, L, dtype=torch.int32, device=dev)
+            nseg = cu.numel() - 1
+            ws = workspace(dev, lib.rap_attention_workspace_bytes(TP, nseg))
+            def fn():
+                rc = lib.rap_attention_f32(_lib.ptr(qkv), _lib.ptr(cu), nseg, _lib.ptr(out), TP, H, _lib.ptr(bound32), _lib.ptr(ws), ws.numel(), st())
+                assert rc == 0, rc
+            t = timeit(fn, iters=1 if args.pmc else 3, warm=0 if args.pmc else 1)
+            fl = 4.0 * H * 64 * L * TP
+            rows.append({"kernel": f"attention_f32[{name} L={L}]", "bounded": bool(bounded), "ms": t * 1e3, "tflops": fl / t / 1e12,
+                         "frac_of_157.3TF": fl / t / 1e12 / 157.3})
 
     if args.only == "attention":
         for r in rows:

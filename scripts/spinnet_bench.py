@@ -16,7 +16,7 @@ def run(): return net(cloud[None], kp[None], 0.2, True, perm=perm)["desc"]
 outs = {}
 for rep in range(3):
     for mode in (1, 0):
-        _lib.check(lib.rap_spinnet_set_conv_path(net._handle, mode), "set_conv_path")
+        net.im2col_path = not mode                     # per-call flag RAP_SPINNET_IM2COL_PATH (rapflow.h)
         run(); torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -26,5 +26,5 @@ for rep in range(3):
         outs[mode] = d
         print(json.dumps({"conv_path": "implicit GEMM" if mode else "im2col + GEMM (r01)", "keypoints": 4096, "ms": round(ms, 3), "keypoints_per_s": round(4096 / ms * 1e3),
                           "algorithmic_TFLOPs": round(4096 * 119e6 / (ms * 1e-3) / 1e12, 1), "frac_of_157.3TF": round(4096 * 119e6 / (ms * 1e-3) / 157.3e12, 3)}), flush=True)
-_lib.check(lib.rap_spinnet_set_conv_path(net._handle, 1), "set_conv_path")
+net.im2col_path = False
 print(json.dumps({"max_abs_descriptor_difference_between_paths": float((outs[1] - outs[0]).abs().max())}))

@@ -94,7 +94,7 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
     assert lib.rap_relative_transforms(N, N, N, N, N, N, 1, 1, N, N, N, N) == -1
     assert lib.rap_chamfer_rmse(N, N, N, 1, 10, N, N, 0, N) == -1
     assert lib.rap_correspondence_rmse(N, N, N, N, 1, 1, 0.1, N, N, 0, N) == -1
-    assert lib.rap_spinnet_describe(N, N, N, 10, N, 1, 0.5, N, 16, N, 0, N) == -1
+    assert lib.rap_spinnet_describe(N, N, N, 10, N, 1, 0.5, 0, N, 16, N, 0, N) == -1
     assert lib.rap_spinnet_create(N, 0, N, ctypes.byref(ctypes.c_void_p(0))) == -1
     assert lib.rap_model_set_compute_dtype(N, 1, N) == -1
     assert lib.rap_spinnet_weight_count() == 426341
