@@ -68,15 +68,24 @@ extern "C" int rap_debug_attn_ts(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(
 // W16 (r02, built at the end of the round, UNMEASURED; rap_set_tuning(3, 24)): 16 waves x 32 queries = 512 queries per block on a work
 // list of 512-query items: the K / V^T stream, its staging instructions and the barrier are shared by twice the matrix work (threads
 // 0-511 stage K, 512-1023 stage V^T: one 16-byte chunk per thread and tile).  Same 4 waves per SIMD, one block per CU.
-template <int DT, int ABL, int OPT, bool PERSIST = false, bool ROT = false, bool LST = false, bool W16 = false>
+// DMA (round 3, the default): K / V^T tiles go global -> LDS directly (global_load_lds_dwordx4, two 1 KB pieces per wave and tile: no
+// staging registers, no ds_write_b128, no s_waitcnt in front of them -- round 2's instruction-mix microbenchmark priced the
+// register-staged stream at 16-20 % of this loop).  The DMA writes LDS lane-linearly, so rows are 128 bytes without padding and
+// bank conflicts are removed as in the GEMMs: 16-byte slot' = slot ^ ((row >> 1) & 7), applied to the per-lane global source
+// address and to the ds_read_b128 address.
+template <int DT, int ABL, int OPT, bool PERSIST = false, bool ROT = false, bool LST = false, bool W16 = false, bool DMA = false>
 __global__ __launch_bounds__(W16 ? 1024 : 512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt,
                                                                int vt_nblk, u16* __restrict__ out, int TP, int heads,
                                                                const AttnWorkItem* __restrict__ items,
                                                                const float* __restrict__ bound, int total_blocks) {
   typedef typename H16<DT>::T8 T8;
-  __shared__ __attribute__((aligned(16))) u16 smem[4 * HKV * HLD];
-  u16* Ks = smem;                    // [2][64 keys][72]
-  u16* Vs = smem + 2 * HKV * HLD;    // [2][64 d][72]   (columns = vt_pos of the key)
+  static_assert(!(DMA && (W16 || ROT)), "the LDS-DMA stream is built for the 8-wave, in-order key walk");
+  constexpr int LDR = DMA ? 64 : HLD;   // LDS row stride in 16-bit elements: 128 B swizzled (DMA) or 144 B padded
+  // (a ring of THREE stages with tiles requested two ahead and a counted vmcnt(2) was measured too, r03 call 21: 1 132 vs 1 141 TF in the
+  // bench -- the DMA latency is not exposed with two.)
+  __shared__ __attribute__((aligned(16))) u16 smem[4 * HKV * HLD];   // 36 KB: two stages of K and V^T (32 KB with DMA) / the 8 output slabs
+  u16* Ks = smem;                    // [2][64 keys][LDR]
+  u16* Vs = smem + 2 * HKV * LDR;    // [2][64 d][LDR]   (columns = vt_pos of the key)
 
   const int tid = threadIdx.x;
   int vb = blockIdx.x;
@@ -131,6 +140,25 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, 2) void attention_h16_kernel(cons
   const int ntile = ((seg1 - 1) >> 6) - b_first + 1;
   const int soff = srow * HLD + sch;
   uint4 rk = make_uint4(0, 0, 0, 0), rv = rk;
+  // DMA: wave w stages rows 8w .. 8w+7 of the K tile and of the V^T tile; lane -> (row 8w + lane/8, physical slot lane%8)
+  const int drow = (tid >> 6) * 8 + ((tid & 63) >> 3);
+  const int dls = ((tid & 7) ^ ((drow >> 1) & 7)) * 8;              // logical slot (in elements) this lane fetches
+  const unsigned lds_k = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) u16*)Ks + (unsigned)(tid >> 6) * 1024u);
+  const unsigned lds_v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) u16*)Vs + (unsigned)(tid >> 6) * 1024u);
+#define HATT_DMA1(GSRC, LDSB)                                                                                 \
+  {                                                                                                           \
+    unsigned keep_;                                                                                           \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_) : "v"(GSRC), "s"(LDSB) : "memory");                                           \
+  }
+#define HATT_DMA(T, BUF)                                                                             \
+  {                                                                                                  \
+    const int blk_ = b_first + (T);                                                                  \
+    int tok_ = blk_ * 64 + drow;                                                                     \
+    tok_ = tok_ < TP ? tok_ : TP - 1;                                                                \
+    HATT_DMA1(Kg + (size_t)tok_ * 64 + dls, lds_k + (unsigned)(BUF) * (HKV * 64 * 2))                \
+    HATT_DMA1(Vg + ((size_t)blk_ * 64 + drow) * 64 + dls, lds_v + (unsigned)(BUF) * (HKV * 64 * 2))  \
+  }
 #define HATT_LOAD(T)                                                                                 \
   {                                                                                                  \
     const int blk_ = b_first + (T);                                                                  \
@@ -145,8 +173,17 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, 2) void attention_h16_kernel(cons
 
   int rt = ROT ? (int)(((unsigned)it.q0 >> 6) % (unsigned)ntile) : 0;     // rotated tile index of iteration t
   ATT_TS(1)
-  HATT_LOAD(rt)
-  HATT_STORE(0)
+  if (DMA) {
+    HATT_DMA(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the Q fragments have landed too -- tell the compiler (a use of every fragment), or it waits for them with vmcnt(3..0) inside
+    // the key loop, where those waits would drain the DMA pieces of the NEXT tile it does not know about
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { uint4 q_ = __builtin_bit_cast(uint4, qf[s]); asm volatile("" : "+v"(q_.x), "+v"(q_.y), "+v"(q_.z), "+v"(q_.w)); qf[s] = __builtin_bit_cast(T8, q_); }
+  } else {
+    HATT_LOAD(rt)
+    HATT_STORE(0)
+  }
   __syncthreads();
   ATT_TS(2)
   if (ABL & 256) { const uint4 q0_ = __builtin_bit_cast(uint4, qf[0]); const uint4 q3_ = __builtin_bit_cast(uint4, qf[3]); if ((q0_.x ^ q3_.w) == 0x9e3779b9u && tid == 9999) return; }   // the Q loads complete before stamp 3
@@ -157,19 +194,21 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, 2) void attention_h16_kernel(cons
     const bool more = (ABL & 2) ? false : (t + 1) < ntile;
     const int rt_cur = rt;
     if (ROT) { rt = rt + 1; rt = rt == ntile ? 0 : rt; }
-    if (more) { HATT_LOAD(ROT ? rt : t + 1) }
+    if (more) { if (DMA) { HATT_DMA(t + 1, cur ^ 1) } else { HATT_LOAD(ROT ? rt : t + 1) } }   // DMA: every wave left buffer cur^1 at the last barrier
 
     if (wave_active) {
       // ---- S^T = K Q^T : two 32-key sub-tiles x 32 queries
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-      const u16* kp = Ks + cur * (HKV * HLD) + l31 * HLD + 8 * hi;
+      const int swz = (l31 >> 1) & 7;                 // DMA layout: slot ^ ((row >> 1) & 7), the same for rows l31 and 32 + l31
+      const u16* kp = Ks + cur * (HKV * LDR) + l31 * LDR + (DMA ? 0 : 8 * hi);
       if (OPT & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const T8 k0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 16 * s));
-        const T8 k1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 32 * HLD + 16 * s));
+        const int ko = DMA ? ((2 * s + hi) ^ swz) * 8 : 16 * s;
+        const T8 k0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + ko));
+        const T8 k1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 32 * LDR + ko));
         s0 = H16<DT>::mfma(k0, qf[s], s0);
         s1 = H16<DT>::mfma(k1, qf[s], s1);
       }
@@ -254,7 +293,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, 2) void attention_h16_kernel(cons
         lsum += ps2.x + ps2.y;
       } else { lsum += s0[0]; }
       // ---- O^T += V^T P^T : key step ks contracts the keys held in registers 8(ks&1)..+7 of sub-tile ks>>1
-      const u16* vp = Vs + cur * (HKV * HLD) + l31 * HLD + 8 * hi;
+      const u16* vp = Vs + cur * (HKV * LDR) + l31 * LDR + (DMA ? 0 : 8 * hi);
       if (OPT & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -264,15 +303,17 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, 2) void attention_h16_kernel(cons
           pb = h16_pack8<DT>(s0[rb + 0], s0[rb + 1], s0[rb + 2], s0[rb + 3], s0[rb + 4], s0[rb + 5], s0[rb + 6], s0[rb + 7]);
         else
           pb = h16_pack8<DT>(s1[rb + 0], s1[rb + 1], s1[rb + 2], s1[rb + 3], s1[rb + 4], s1[rb + 5], s1[rb + 6], s1[rb + 7]);
-        const T8 v0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 16 * ks));
-        const T8 v1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 32 * HLD + 16 * ks));
+        const int vo = DMA ? ((2 * ks + hi) ^ swz) * 8 : 16 * ks;
+        const T8 v0 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + vo));
+        const T8 v1 = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 32 * LDR + vo));
         o0 = H16<DT>::mfma(v0, pb, o0);
         o1 = H16<DT>::mfma(v1, pb, o1);
       }
       if (OPT & 4) __builtin_amdgcn_s_setprio(0);
     }
 
-    if (more) { HATT_STORE(cur ^ 1) }
+    if (more && !DMA) { HATT_STORE(cur ^ 1) }
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's two pieces of tile t + 1 have landed
     if (!(ABL & 2)) __syncthreads();
   }
 
@@ -325,6 +366,7 @@ __global__ __launch_bounds__(W16 ? 1024 : 512, 2) void attention_h16_kernel(cons
 // persistent blocks, rotated key walk, 512-query blocks -- all measured equal or slower) are in the history at 72efb73.
 // RAP_ABLATION_BUILD only: rap_set_tuning(3, 5) forces the online softmax even with bounds (A/B of the bounded kernel).
 rap_tuning_t g_rap_attn_h16_variant = 0;
+rap_tuning_t g_rap_attn_h16_dma = 1;      // tuning key 13: K / V^T tiles by LDS-DMA (1, default) or staged through registers (0)
 
 int attention_h16_block_queries(int) { return 256; }
 
@@ -345,13 +387,14 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
   if (g_rap_attn_h16_variant == 5) bound = nullptr;
 #endif
 #define HATT_LAUNCH_D(DTV, OPTV) \
-  hipLaunchKernelGGL((attention_h16_kernel<DTV, 0, OPTV, false, false, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, max_items * heads)
+  if (g_rap_attn_h16_dma) hipLaunchKernelGGL((attention_h16_kernel<DTV, 0, OPTV, false, false, true, false, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, max_items * heads); \
+  else hipLaunchKernelGGL((attention_h16_kernel<DTV, 0, OPTV, false, false, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, max_items * heads)
   if (dtype == RAP_DT_BF16) {
-    if (bound && q_prescaled) HATT_LAUNCH_D(RAP_DT_BF16, 24);
-    else if (bound) HATT_LAUNCH_D(RAP_DT_BF16, 8);
-    else HATT_LAUNCH_D(RAP_DT_BF16, 3);
+    if (bound && q_prescaled) { HATT_LAUNCH_D(RAP_DT_BF16, 24); }
+    else if (bound) { HATT_LAUNCH_D(RAP_DT_BF16, 8); }
+    else { HATT_LAUNCH_D(RAP_DT_BF16, 3); }
   } else if (dtype == RAP_DT_F16) {
-    HATT_LAUNCH_D(RAP_DT_F16, 3);
+    { HATT_LAUNCH_D(RAP_DT_F16, 3); }
   } else {
     return RAP_ERR_INVALID;
   }

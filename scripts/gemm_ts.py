@@ -25,7 +25,17 @@ PERSISTENT = "--persistent" in sys.argv
 raw.rap_set_tuning.restype = ctypes.c_int; raw.rap_set_tuning.argtypes = [ctypes.c_int32, ctypes.c_int32]
 assert raw.rap_set_tuning(11, 1 if PERSISTENT else 0) == 0
 cases = [("plain 16-bit out", 0, 512, 512), ("plain 16-bit out", 0, 512, 2048), ("plain 16-bit out", 0, 1536, 512), ("GEGLU", 3, 4096, 512),
-         ("fp16 residual", 6, 512, 512)]
+         ("fp16 residual", 6, 512, 512), ("qkv + qk-norm", 5, 1536, 512)]
+raw.rap_gemm_h16_qkvnorm.restype = ctypes.c_int
+raw.rap_gemm_h16_qkvnorm.argtypes = [ctypes.c_int32, P, ctypes.c_int32, P, ctypes.c_int32, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, P, P, ctypes.c_float, P,
+                                     ctypes.c_int32, P]
+
+
+def xcd_remap(bid, nblk):
+    q, r = nblk >> 3, nblk & 7
+    xcd, idx = bid & 7, bid >> 3
+    base = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+    return base + idx
 for name, epi, N, K in cases:
     A = torch.randn(TP, K, device=dev, generator=g).to(torch.bfloat16)
     W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
@@ -33,14 +43,19 @@ for name, epi, N, K in cases:
     Cw = N // 2 if epi == 3 else N
     C = torch.zeros(TP, Cw, device=dev, dtype=torch.float16 if epi == 6 else torch.bfloat16)
     resid = C if epi == 6 else None
+    vt = torch.zeros(8 * (TP // 64) * 64 * 64, device=dev, dtype=torch.bfloat16) if epi == 5 else None
+    gq = torch.ones(8, 64, device=dev)
     nblocks = (TP // 256) * (N // 256)
     ts = torch.zeros(max(nblocks * 8, 256 * 32 * 4), dtype=torch.int64, device=dev)
     assert raw.rap_debug_gemm_ts(ts.data_ptr()) == 0
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = raw.rap_gemm_h16(1, epi, ptr(A), K, ptr(W), K, ptr(C), Cw, TP, N, K, ptr(bias), ptr(resid), Cw if resid is not None else 0, 0,
-                              ptr(None), 0, st())
+        if epi == 5:
+            rc = raw.rap_gemm_h16_qkvnorm(1, ptr(A), K, ptr(W), K, ptr(C), TP, K, 8, ptr(gq), ptr(gq), 8.0, ptr(vt), TP // 64, st())
+        else:
+            rc = raw.rap_gemm_h16(1, epi, ptr(A), K, ptr(W), K, ptr(C), Cw, TP, N, K, ptr(bias), ptr(resid), Cw if resid is not None else 0, 0,
+                                  ptr(None), 0, st())
         assert rc == 0, rc
         e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
@@ -57,6 +72,13 @@ for name, epi, N, K in cases:
                "block entry (first k-loop start) spread": us(tt[:, 0, 0] - tt[:, 0, 0].min())}
         for k, v in seg.items():
             row[k] = {"median": round(float(np.median(v)), 2), "p10": round(float(np.percentile(v, 10)), 2), "p90": round(float(np.percentile(v, 90)), 2)}
+        if epi == 5:       # q / k column tiles (swapped product, direct 16-byte row stores) vs V tiles (V^T image through the LDS slab)
+            nt_ = N // 256
+            ncol = np.array([[xcd_remap(b + 256 * i, nblocks) % nt_ for i in range(ntile)] for b in range(256)])
+            ep = us(tt[:, :, 2] - tt[:, :, 1])
+            for lab, mask in (("epilogue, q / k tiles (swapped, direct stores)", ncol < 4), ("epilogue, V tiles (V^T through LDS)", ncol >= 4)):
+                v = ep[mask]
+                row[lab] = {"median": round(float(np.median(v)), 2), "p10": round(float(np.percentile(v, 10)), 2), "p90": round(float(np.percentile(v, 90)), 2)}
         print(json.dumps(row), flush=True)
         continue
     t = ts.cpu().numpy().reshape(-1, 8)[:nblocks].astype(np.int64)

@@ -110,8 +110,8 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
     del one
     # the shipped library carries no kernel-variant switch: keys 0-4 / 8 of the round-1/2 experiments are refused, the five
     # production switches accept {0, 1} only
-    for key in (0, 1, 2, 3, 4, 8, 10, 13, -1):
+    for key in (0, 1, 2, 3, 4, 8, 10, 14, -1):
         assert lib.rap_set_tuning(key, 1) == -1 and lib.rap_set_tuning(key, 0) == -1, key
-    for key in (5, 6, 7, 9, 11, 12):
+    for key in (5, 6, 7, 9, 11, 12, 13):
         assert lib.rap_set_tuning(key, 2) == -1 and lib.rap_set_tuning(key, 1) == 0, key
     assert lib.rap_model_bounded_attention_launches(N) < 0
