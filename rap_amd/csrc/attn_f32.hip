@@ -27,6 +27,10 @@
 //    L2 then serves the K/V of one head).
 #include "kernels.h"
 
+// Measured and NOT kept (round 3, call 22): K / V tiles by LDS-DMA (global_load_lds_dwordx4, 256-byte K rows with a slot ^ (row & 15) swizzle)
+// instead of through staging registers -- bit-identical output, 196 instead of 228-242 VGPRs, and exactly the same speed (141.7 vs
+// 141.8 TF per sample, 140.8 vs 141.2 per part): at 64 cycles per MFMA the 8 loads + 8 ds_write_b128 of a tile are noise.  The same
+// change is worth +3.5 % in the 16-bit kernel (attn_h16.hip), where a tile is 16x shorter.
 #define AQ_WAVE 64
 #define AKV 64
 #define KLD 68  // K LDS row stride (floats): 272 B = 17 slots -> conflict-free ds_read_b128

@@ -584,6 +584,28 @@ def test_baseline_geometries_h16_agrees_with_fp32_path(label, batch, views, poin
 
 
 @pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("bounded", [False, True], ids=["online", "bounded"])
+def test_attention_h16_lds_dma_stream_is_bit_identical_to_register_staging(lib, dev, dt, bounded):
+    """Round 3: the K / V^T tiles reach the LDS by global_load_lds (128-byte rows, slot ^ ((row >> 1) & 7) swizzle) instead of through
+    staging registers (rap_set_tuning(13, 0) restores those).  Data movement only: outputs BIT-identical on ragged segments."""
+    g = torch.Generator().manual_seed(78)
+    H = 4
+    cu = torch.tensor([0] + [1, 63, 64, 65, 128, 129, 192, 300, 0, 257, 384, 31, 449, 700]).cumsum(0)
+    TP = int(cu[-1])
+    q = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8
+    k = F.normalize(torch.randn(H, TP, 64, generator=g), dim=-1) * 8
+    v = torch.randn(H, TP, 64, generator=g)
+    outs = []
+    try:
+        for dma in (1, 0):
+            assert lib.rap_set_tuning(13, dma) == 0
+            outs.append(run_attention_h(lib, dev, dt, q, k, v, cu, bound=logit_bound(q, k) if bounded else None))
+    finally:
+        assert lib.rap_set_tuning(13, 1) == 0
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("dt", [1, 2])
 def test_attention_h16_bounded_and_online_softmax_agree(lib, dev, dt):
     """The two shipped softmax evaluations of the 16-bit attention (bounded / offset-free when logit bounds are supplied, online with
     running maxima otherwise; fp16 always takes the online one): same function, results within rounding of each other, on segment
