@@ -880,9 +880,12 @@ static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
   return RAP_OK;
 }
 
-// rows of a 256-row tile are addressed by a 32-bit byte offset from the tile's scalar base
+// The persistent kernel pays where the per-tile overhead is a large share of a tile: K <= 2048 (<= 32 k-tiles per output tile) and at least
+// two tiles per CU.  With long tiles a STATIC tile walk loses more to imbalance than it saves: 8192^3 (128 k-tiles, 4 tiles per block) runs at
+// 1 129 TF persistent vs 1 221 one tile per block, while K = 512 gains 21-23 % and K = 2048 8.5 % (scripts/gemm_square.py, r03 call 23).
+// Rows of a 256-row tile are addressed by a 32-bit byte offset from the tile's scalar base.
 static bool use_persistent(const GemmParamsH& p) {
-  return g_rap_gemm_h16_persistent && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 128 && (long)(p.M / 256) * (p.N / 256) >= 512 &&
+  return g_rap_gemm_h16_persistent && p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 128 && p.K <= 2048 && (long)(p.M / 256) * (p.N / 256) >= 512 &&
          p.lda <= (1 << 20) && p.ldw <= (1 << 20);
 }
 

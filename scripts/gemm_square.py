@@ -8,11 +8,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from rap_amd import _lib
 dev = torch.device("cuda:0")
 lib = _lib.load()
-variants = [int(v) for v in sys.argv[1:]] or [14]
+variants = [int(v) for v in sys.argv[1:]] or [1, 0]      # rap_set_tuning(11, .): 1 = persistent kernel where the shape allows (>= 512 full tiles), 0 = one tile per block
 g = torch.Generator(device=dev).manual_seed(0)
 st = torch.cuda.current_stream(dev).cuda_stream
 for var in variants:
-    assert lib.rap_set_tuning(2, var) == 0
+    assert lib.rap_set_tuning(11, var) == 0
     for (M, N, K) in ((4096, 4096, 4096), (8192, 8192, 8192), (16384, 4096, 512), (262144, 4096, 512), (262144, 512, 2048), (32768, 512, 8192), (262144, 512, 512)):
         A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
         W = (torch.rand(N, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
@@ -27,5 +27,6 @@ for var in variants:
         for _ in range(iters): fn()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
-        print(json.dumps({"variant": var, "M": M, "N": N, "K": K, "ms": round(ms, 4), "tflops": round(2.0 * M * N * K / ms / 1e9, 1)}), flush=True)
+        print(json.dumps({"persistent": bool(var) and M % 256 == 0 and (M // 256) * (N // 256) >= 512, "M": M, "N": N, "K": K, "ms": round(ms, 4), "tflops": round(2.0 * M * N * K / ms / 1e9, 1)}), flush=True)
         del A, W, C
+assert lib.rap_set_tuning(11, 1) == 0

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: parity tests, per-kernel variant sweep, the bench line, and a rocprofv3 kernel trace of the
 # same bench command.  Usage (from the repo root, through gpurun):  bash scripts/gpu_run.sh <tag> [stages...]
-# stages: tests sweep h16 bench prof pmc   (default: tests sweep bench prof); PYTEST_ARGS overrides "-x -q"
+# stages: tests sweep bench prof pmc   (default: tests sweep bench prof); PYTEST_ARGS overrides "-x -q"
 set -u
 TAG=${1:-run}; shift || true
 STAGES=${*:-"tests sweep bench prof"}
@@ -15,25 +15,12 @@ if has tests; then
   echo "pytest exit $?" >> "$OUT/pytest_gpu.log"
   grep -E "^(FAILED|ERROR)|passed|failed" "$OUT/pytest_gpu.log" | tail -40
 fi
-if has h16; then
-  : > "$OUT/kernel_bench_h16.jsonl"
-  for v in 0 1 2 3 5; do
-    timeout 300 python scripts/kernel_bench.py --dtype bfloat16 --only gemm --h16-gemm-variant $v >> "$OUT/kernel_bench_h16.jsonl" 2>> "$OUT/kernel_bench.err"
-  done
-  timeout 300 python scripts/kernel_bench.py --dtype bfloat16 --only attention >> "$OUT/kernel_bench_h16.jsonl" 2>> "$OUT/kernel_bench.err"
-  timeout 300 python scripts/kernel_bench.py --dtype float16 >> "$OUT/kernel_bench_h16.jsonl" 2>> "$OUT/kernel_bench.err"
-  cat "$OUT/kernel_bench_h16.jsonl"; tail -5 "$OUT/kernel_bench.err"
-fi
 if has sweep; then
-  : > "$OUT/kernel_bench.jsonl"
-  for v in 2 4 8 16; do
-    timeout 300 python scripts/kernel_bench.py --only gemm --gemm-variant $v >> "$OUT/kernel_bench.jsonl" 2>> "$OUT/kernel_bench.err"
-  done
-  for v in 1 3 5; do
-    timeout 300 python scripts/kernel_bench.py --only attention --attn-variant $v >> "$OUT/kernel_bench.jsonl" 2>> "$OUT/kernel_bench.err"
-  done
-  timeout 300 python scripts/kernel_bench.py > "$OUT/kernel_bench_default.jsonl" 2>> "$OUT/kernel_bench.err"
-  cat "$OUT/kernel_bench.jsonl"
+  timeout 300 python scripts/kernel_bench.py > "$OUT/kernel_bench_f32.jsonl" 2>> "$OUT/kernel_bench.err"
+  timeout 300 python scripts/kernel_bench.py --dtype bfloat16 --bounded 2 > "$OUT/kernel_bench_bf16.jsonl" 2>> "$OUT/kernel_bench.err"
+  timeout 300 python scripts/kernel_bench.py --dtype float16 > "$OUT/kernel_bench_f16.jsonl" 2>> "$OUT/kernel_bench.err"
+  ( cd scripts && timeout 200 python gemm_epi_bench.py > "../$OUT/gemm_epi_bench.jsonl" 2>> "../$OUT/kernel_bench.err" )
+  cat "$OUT/kernel_bench_f32.jsonl" "$OUT/kernel_bench_bf16.jsonl"
 fi
 if has bench; then
   timeout 900 python bench.py ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err"
@@ -49,15 +36,6 @@ if has prof; then
   done
 fi
 if has pmc; then
-  for DT in float32 bfloat16; do
-    for c in FETCH_SIZE WRITE_SIZE; do
-      ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d "$GRAFT_REPO_ROOT/$OUT/pmc_${DT}_$c" -o pmc -- \
-          python "$GRAFT_REPO_ROOT/scripts/kernel_bench.py" --dtype $DT --only attention --pmc > "$GRAFT_REPO_ROOT/$OUT/pmc_${DT}_$c.log" 2>&1 )
-      DB=$(find "$OUT/pmc_${DT}_$c" -name '*.db' | head -1)
-      if [ -n "$DB" ]; then python scripts/rocpd_summary.py "$DB" --pmc | grep -E "PMC.*attention" | sed "s/^/$DT /" >> "$OUT/pmc_traffic.txt"; fi
-      find "$OUT/pmc_${DT}_$c" -name '*.db' -delete
-    done
-  done
-  cat "$OUT/pmc_traffic.txt"
+  bash scripts/pmc_passes.sh "$OUT/pmc"
 fi
 echo "gpu_run $TAG done"
