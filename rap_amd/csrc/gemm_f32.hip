@@ -651,8 +651,9 @@ __global__ __launch_bounds__(512) void gemm_f32_dma256p_kernel(GemmParams p) {
     BP_DMA1(a_off[i], ABASE, lds_wave + (unsigned)((BUF) * ABYTES + i * NT * 16))                             \
   _Pragma("unroll") for (int i = 0; i < CB; ++i)                                                              \
     BP_DMA1(w_off[i], WBASE, lds_wave + (unsigned)(2 * ABYTES + (BUF) * BBYTES + i * NT * 16))
-  // raw barrier: __syncthreads() would also fence (drain) the epilogue's global stores
-#define BP_SYNC asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+  // raw barrier (no memory fence needed: LDS-DMA arrival is confirmed by this wave's vmcnt, fragment reads of the stage that the next
+  // DMA overwrites by lgkmcnt -- they were issued one MFMA group earlier, so the wait is free)
+#define BP_SYNC asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
 
   struct Frag { float4 a[TM]; float4 b[TN]; };
   Frag f0, f1;
