@@ -298,25 +298,39 @@ def make_headline_goldens(which=("c1_rigid", "c1_free", "c3", "c4")):
             # forcing (attention at L = 65 536), and the first pair of RANK 1 of the configs[2] job (bench.py: rank r owns
             # samples [32 r, 32 r + 32), sample b is seeded 1234 + b)
             "c4_steps": ("headline_c4_steps", 2, 32768, 2, True, 64, 1234),
-            "c2_rank1": ("headline_c2_rank1", 2, 4096, 20, True, 32, 1234 + 32)}
+            "c2_rank1": ("headline_c2_rank1", 2, 4096, 20, True, 32, 1234 + 32),
+            # round 3, full-size cases beyond the uniform BASELINE geometries: a RAGGED 4-part sample (three views of unequal size and a
+            # trailing empty part) through rap_12, and the configs[1] pair through the reference's largest model (rap_16)
+            "c1_ragged": ("headline_c1_ragged", None, None, 20, True, 32, 4321, [[4096, 2500, 1000, 0]], 12),
+            "c1_rap16": ("headline_c1_rap16", 2, 4096, 20, True, 32, 1234, None, 16)}
     for key in which:
         if key not in jobs:
             continue
         name, views, points, steps, rigid, stride = jobs[key][:6]
         iseed = jobs[key][6] if len(jobs[key]) > 6 else 1234
-        inp = S.make_uniform_inputs(1, views, points, seed=iseed)
+        parts = jobs[key][7] if len(jobs[key]) > 7 else None
+        layers = jobs[key][8] if len(jobs[key]) > 8 else 12
+        cfg_j, sd_j = cfg, sd
+        if layers != 12:
+            cfg_j = dict(S.RAP_12); cfg_j["num_layers"] = layers
+            sd_j = S.make_weights(cfg_j, 0)
+        inp = S.make_inputs(parts, seed=iseed) if parts else S.make_uniform_inputs(1, views, points, seed=iseed)
         t0 = time.perf_counter()
-        ref = ref_loader.reference_sample(cfg, sd, inp, steps, rigid)
+        ref = ref_loader.reference_sample(cfg_j, sd_j, inp, steps, rigid)
         dt = time.perf_counter() - t0
-        out = {"num_layers": np.int64(12), "weight_seed": np.int64(0), "input_seed": np.int64(iseed), "views": np.int64(views),
-               "points": np.int64(points), "num_steps": np.int64(steps), "rigidity": np.int64(int(rigid)),
-               "weights_checksum": np.float64(weights_checksum(sd)), "reference_seconds": np.float64(dt),
+        out = {"num_layers": np.int64(layers), "weight_seed": np.int64(0), "input_seed": np.int64(iseed),
+               "views": np.int64(views if views else len(parts[0])), "points": np.int64(points if points else 0),
+               "num_steps": np.int64(steps), "rigidity": np.int64(int(rigid)),
+               "weights_checksum": np.float64(weights_checksum(sd_j)), "reference_seconds": np.float64(dt),
                "reference_threads": np.int64(torch.get_num_threads())}
+        if parts:
+            out["parts"] = np.array(parts, dtype=np.int64)
         out.update(_traj_summary(ref, stride))
         path = os.path.join(GOLDEN_DIR, name + ".npz")
         np.savez_compressed(path, **out)
-        timings[name] = {"seconds": dt, "threads": torch.get_num_threads(), "points": views * points, "flow_steps": steps,
-                         "points_per_s": views * points / dt, "rigidity_forcing": rigid,
+        npts = int(inp["pointclouds"].shape[0])
+        timings[name] = {"seconds": dt, "threads": torch.get_num_threads(), "points": npts, "flow_steps": steps, "num_layers": layers,
+                         "points_per_s": npts / dt, "rigidity_forcing": rigid,
                          "what": "unmodified reference modules (oracle/ref_loader.reference_sample), fp32, CPU of the build container, "
                                  "all flow steps + final fit_transformations"}
         print(name, os.path.getsize(path) // 1024, "KiB", f"{dt:.1f} s", flush=True)
@@ -353,7 +367,7 @@ def make_headline_goldens(which=("c1_rigid", "c1_free", "c3", "c4")):
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.endswith("-only")]     # e.g. --overlap-only regenerates one fixture
     if "--headline-only" in only:                               # ~1.5 h of CPU: never part of the default regeneration
-        make_headline_goldens(tuple(a[2:] for a in sys.argv[1:] if a[2:] in ("c1_rigid", "c1_free", "c3", "c4", "c4_steps", "c2_rank1")) or ("c1_rigid", "c1_free", "c3", "c4"))
+        make_headline_goldens(tuple(a[2:] for a in sys.argv[1:] if a[2:] in ("c1_rigid", "c1_free", "c3", "c4", "c4_steps", "c2_rank1", "c1_ragged", "c1_rap16")) or ("c1_rigid", "c1_free", "c3", "c4"))
         sys.exit(0)
     if any(a.startswith("--case=") for a in sys.argv[1:]):      # only the named sampler fixtures (main() filters)
         main()

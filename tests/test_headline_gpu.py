@@ -10,6 +10,8 @@ EVERY flow step -- so error growth over the re-noised steps at L = 8192 / 16384 
   headline_c4_forward       : configs[4] geometry: 2 x 32768, one forward of a 2-layer model at t = 0.5
   headline_c4_steps         : configs[4] geometry: 2 x 32768, ALL 12 layers, two re-noised flow steps with rigidity forcing (round 3)
   headline_c2_rank1         : configs[2]: the first pair of RANK 1 of the 8-GPU job (input seed 1234 + 32), all 20 steps (round 3)
+  headline_c1_ragged        : one RAGGED sample, parts of 4096 / 2500 / 1000 points + a trailing empty part, rap_12, 20 steps (round 3)
+  headline_c1_rap16         : the configs[1] pair through rap_16, the reference's largest model, 20 steps (round 3)
 
 Stated fp32 tolerances: end points / x_t 5e-4, |R - R_ref|_F 1e-3, |t - t_ref| 1e-3, velocity per
 forward 1e-4 max|v|.  The 16-bit modes are compared with the SAME reference fixtures (not with the fp32 GPU path); their
@@ -73,11 +75,14 @@ def dev():
 
 
 def _run_sample(g, dtype, dev, residual_dtype="float32", features=False):
-    views, points, steps = int(g["views"]), int(g["points"]), int(g["num_steps"])
-    cfg, sd = _weights(12)
+    views, points, steps, layers = int(g["views"]), int(g["points"]), int(g["num_steps"]), int(g["num_layers"])
+    cfg, sd = _weights(layers)
     assert abs(sum(v.double().sum().item() for v in sd.values()) - float(g["weights_checksum"])) < 1e-6
-    inp = S.make_uniform_inputs(1, views, points, seed=int(g["input_seed"]))
-    flow = rap_amd.RectifiedPointFlow(flow_model=_model(12, dtype, dev, residual_dtype), inference_sampling_steps=steps,
+    if "parts" in g:                                            # ragged fixture: explicit part sizes (empty parts included)
+        inp = S.make_inputs([[int(n) for n in row] for row in g["parts"]], seed=int(g["input_seed"]))
+    else:
+        inp = S.make_uniform_inputs(1, views, points, seed=int(g["input_seed"]))
+    flow = rap_amd.RectifiedPointFlow(flow_model=_model(layers, dtype, dev, residual_dtype), inference_sampling_steps=steps,
                                       rigidity_forcing=bool(g["rigidity"]))
     d = {k: v.to(dev) for k, v in inp.items()}
     out = flow.sample_and_register(d, x_1=d["x_1"], return_transformer_features=features)
@@ -103,7 +108,8 @@ def _errors(out, g):
     return e
 
 
-@pytest.mark.parametrize("name", ["headline_c1_rigid", "headline_c1_free", "headline_c3_rigid", "headline_c2_rank1"])
+@pytest.mark.parametrize("name", ["headline_c1_rigid", "headline_c1_free", "headline_c3_rigid", "headline_c2_rank1", "headline_c1_ragged",
+                                  "headline_c1_rap16"])
 def test_fp32_all_steps_match_the_reference(name, dev):
     g = _golden(name)
     e = _errors(_run_sample(g, "float32", dev), g)
@@ -123,7 +129,7 @@ def test_fp32_all_steps_match_the_reference(name, dev):
 
 
 @pytest.mark.parametrize("dtype,cloud_tol,R_tol", [("bfloat16", 5e-2, 1e-1), ("float16", 1e-2, 2e-2)])
-@pytest.mark.parametrize("name", ["headline_c1_rigid", "headline_c3_rigid", "headline_c2_rank1"])
+@pytest.mark.parametrize("name", ["headline_c1_rigid", "headline_c3_rigid", "headline_c2_rank1", "headline_c1_ragged", "headline_c1_rap16"])
 def test_16bit_all_steps_deviation_from_the_reference(name, dtype, cloud_tol, R_tol, dev):
     """north_star: report the measured deviation of the reduced-precision modes -- against the reference's fp32 result."""
     g = _golden(name)
