@@ -53,10 +53,10 @@ CPU_BASELINE_THREADS = 16
 # were measured on.
 SHIPPED_ATTENTION_SYMBOL = {
     ("float32", True): "attention_f32_kernel<4, true, false>", ("float32", False): "attention_f32_kernel<4, false, false>",
-    ("bfloat16", True): "attention_h16_kernel<1, 0, 24, false, false, true, false>",
-    ("bfloat16", False): "attention_h16_kernel<1, 0, 3, false, false, true, false>",
-    ("float16", True): "attention_h16_kernel<2, 0, 3, false, false, true, false>",
-    ("float16", False): "attention_h16_kernel<2, 0, 3, false, false, true, false>",
+    ("bfloat16", True): "attention_h16_kernel<1, 24, true>",
+    ("bfloat16", False): "attention_h16_kernel<1, 3, true>",
+    ("float16", True): "attention_h16_kernel<2, 3, true>",
+    ("float16", False): "attention_h16_kernel<2, 3, true>",
 }
 
 

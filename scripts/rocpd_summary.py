@@ -25,7 +25,8 @@ def main():
             q = ("select k.name, p.counter_name, count(*), sum(p.counter_value) from pmc_events p join kernels k on p.dispatch_id = k.dispatch_id "
                  "group by k.name, p.counter_name order by k.name")
             for name, cname, n, v in cur.execute(q):
-                print(f"PMC {name.split("(")[0][:120]:60s} {cname:16s} dispatches={n} sum={v:.6g} per_dispatch={v / n:.6g}")
+                short = name.split("(")[0][:120]          # the whole template argument list (rocprofv3 prints it before the parameters)
+                print(f"PMC {short:60s} {cname:16s} dispatches={n} sum={v:.6g} per_dispatch={v / n:.6g}")
         except sqlite3.Error as e:
             cols = [r[1] for r in cur.execute("pragma table_info('pmc_events')")]
             print("pmc_events columns:", cols, "error:", e)
