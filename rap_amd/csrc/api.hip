@@ -459,7 +459,11 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         g.vt = w.vth; g.vt_nblk = w.vt_nblk;
         const bool bnd = m->bounded[j] != 0;                              // this launch's softmax kernel (per layer and branch)
         const bool prescale = attention_h16_wants_prescaled_q(dt, bnd);
-        if (g_rap_fuse_qknorm) {
+        // few-token calls (fewer 256 x 256 tiles than CUs): the 128 x 128 kernel fills the chip better than the fused epilogue's 256 x 256
+        // tiles save (it exists only in the phase-split kernels), so the projection and qk-norm run as two kernels there
+        // (r03 call 32: one pair of 2 x 1024 points, 10 steps, bf16: 21.3 -> 18.5 ms; at 2 x 4096 -- 192 tiles -- the fused form is still ahead)
+        const bool few_tiles = (long)((TP + 255) / 256) * (3 * d / 256) < 128;
+        if (g_rap_fuse_qknorm && !few_tiles) {
           // qk-norm in the QKV epilogue: one kernel, q / k normalised from the fp32 accumulators (no 16-bit round trip through HBM)
           g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; g.q_mul = prescale ? RAP_QMUL_PRESCALED : 8.0f;
           { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV_NORM, g); }

@@ -858,8 +858,9 @@ static int launch_php(hipStream_t stream, const GemmParamsH& p) {
 
 // Kernel choice (round 3: the fifteen other main loops of rounds 1-2 -- rings, pipelined rings, interleaved issue, persistent,
 // 128 x 512 -- all measured within +-4 % of this one and are gone from the tree; their source and numbers are in the history at
-// 72efb73 and in DESIGN.md section 4.3).  Default: the phase-split 256 x 256 kernel.  Fallback for shapes it cannot tile
-// (N % 256 != 0 or K < 128) and for few-row calls: the two-stage 128 x 128 kernel, two blocks per CU.
+// 72efb73 and in docs/DESIGN_r01_r02.md section 4.3).  Default: the phase-split 256 x 256 kernel, persistent where the shape allows.
+// Fallback for shapes it cannot tile (N % 256 != 0 or K < 128) and for calls with fewer 256 x 256 tiles than CUs: the two-stage
+// 128 x 128 kernel, two blocks per CU.
 // RAP_ABLATION_BUILD only: rap_set_tuning(2, 0) forces the 128 x 128 kernel, (2, 1) the two-stage 256 x 256 kernel.
 rap_tuning_t g_rap_gemm_h16_variant = 14;
 rap_tuning_t g_rap_gemm_h16_persistent = 1;     // tuning key 11: the persistent phase-split kernel for full-tile shapes (1, default) or one tile per block (0)
@@ -899,7 +900,9 @@ static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
   // persistent form when every row tile is full and there are at least two rounds of tiles for a 256-CU part; the one-tile-per-block
   // form for ragged M (it clamps rows) and for few tiles
   if (big && use_persistent(p)) return launch_php<EPI, DT>(stream, p);
-  if (big && p.M > 128) return launch_ph<EPI, DT, 0, 1>(stream, p);
+  // fewer 256 x 256 tiles than CUs (few-token calls): 128 x 128 tiles, two blocks per CU, fill the chip better -- one pair of
+  // 2 x 1024 points x 10 steps 26.6 -> 21.6 ms in bf16, 2 x 4096 x 20 steps 102.5 -> 94.0 ms, unchanged from 4 pairs up (r03 call 31)
+  if (big && (long)((p.M + 255) / 256) * (p.N / 256) >= 256) return launch_ph<EPI, DT, 0, 1>(stream, p);
   return launch_cfg<EPI, DT, 2, 2, 2, 2>(stream, p);
 }
 

@@ -59,8 +59,9 @@ def gemm_h(lib, dev, dt, epi, A, W, C, M, N, K, bias=None, resid=None, heads=0, 
     torch.cuda.synchronize()
 
 
-# Two GEMM kernels ship (gemm_h16.hip: launch_variant): the phase-split 256 x 256 kernel for M > 128, N % 256 == 0, K >= 128 and
-# the two-stage 128 x 128 kernel for everything else -- the shapes below reach both.
+# Kernels that ship (gemm_h16.hip: launch_variant): the phase-split 256 x 256 kernel (persistent for full-tile shapes with >= 512 tiles and
+# K <= 2048; one tile per block from 256 tiles on) and the two-stage 128 x 128 kernel for everything else -- the shapes of this file reach
+# all three (the small parity shapes the 128 x 128 kernel; the full-size / persistent tests the other two).
 # ---------------------------------------------------------------------------------------------
 # conversion, GEMM
 # ---------------------------------------------------------------------------------------------
@@ -148,7 +149,7 @@ def test_gemm_h16_qkv_split_and_transposed_v(lib, dev, dt, M):
     want = ref[2].permute(1, 0, 2)                     # (M, H, 64)
     errv = (got - want).abs() / (want.abs() + 1e-2)
     assert errv.max().item() < 1.01 * ULP[dt], errv.max().item()
-    m_tiles = 256 if M > 128 else 128      # which kernel ran (launch_variant): rows up to its M tile are written
+    m_tiles = 256 if ((M + 255) // 256) * (1536 // 256) >= 256 else 128      # which kernel ran (launch_variant): rows up to its M tile are written
     tp = torch.arange(M, (M + m_tiles - 1) // m_tiles * m_tiles)
     if tp.numel():
         pad = vtc[:, tp >> 6, :, vt_pos(tp & 63)]
