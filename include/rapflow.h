@@ -280,6 +280,15 @@ int rap_convert_h16(int32_t dtype, const float* src, uint16_t* dst, int64_t n, v
 int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, void* C,
                  int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const float* resid, int32_t ldr,
                  int32_t heads, uint16_t* vt, int32_t vt_nblk, void* stream);
+/* Epilogues 1 and 6 of rap_gemm_h16 with the split-K form rap_sample uses for the K = 4d feed-forward GEMM of few-token calls (tuning
+ * key 6): when rap_gemm_h16_splitk_workspace_bytes(M, N, K) > 0 (K >= 1024 and at most 128 tiles of 128 x 128), K is split over 2 or 4
+ * blocks per tile that write fp32 partial tiles to ws, and a combine pass forms resid + (bias + sum of partials) in a fixed order
+ * (deterministic; equals the unsplit result up to the fp32 association of the k-sum).  resid: fp32 (epilogue 1, may be NULL) or fp16
+ * (epilogue 6, required) (M,N) matrix with row stride ldr, may alias C.  With a workspace size of 0 the call is rap_gemm_h16. */
+size_t rap_gemm_h16_splitk_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int rap_gemm_h16_splitk(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, void* C,
+                        int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const void* resid, int32_t ldr, void* ws,
+                        size_t ws_bytes, void* stream);
 /* flash_attn_varlen_qkvpacked_func equivalent on 16-bit operands (fp32 softmax): qk [2][H][TP][64], vt as above,
  * out half (TP, H*64).  ws >= rap_attention_workspace_bytes(TP, nseg).
  * logit_bound: NULL, or H device floats B[h] with q.k/8 <= B[h] <= 40 for every query/key pair of head h GUARANTEED by
@@ -351,7 +360,7 @@ int rap_check_batch(const int64_t* points_per_part, const int32_t* cu_batch, int
 int rap_profile_enable(int on);
 /* Production switches between two SHIPPED code paths that compute the same function (process-global, atomic; not per model):
  *   key 5  split-KV attention for few-token calls        {0 off, 1 on (default)}       fp32 path
- *   key 6  split-K of the bias + residual GEMM, few rows  {0 off, 1 on (default)}       fp32 path
+ *   key 6  split-K of the bias + residual GEMM, few rows  {0 off, 1 on (default)}       both precisions (16-bit: K >= 1024, i.e. ff2)
  *   key 7  qk-norm fused into the QKV GEMM epilogue       {1 (default), 0 = own kernel} both precisions
  *   key 9  GEGLU's Phi                                    {1 (default): erfc polynomial, |error| <= 1.5e-7; 0: erff}   fp32 path
  *   key 11 persistent 16-bit GEMM (one block per CU walks {1 (default), 0 = one 256 x 256 tile per block}   16-bit path

@@ -94,6 +94,9 @@ SIGNATURES = {
     "rap_convert_h16": (c_int32, [c_int32, _P, _P, c_int64, _P]),
     "rap_gemm_h16": (c_int32, [c_int32, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P,
                                c_int32, c_int32, _P, c_int32, _P]),
+    "rap_gemm_h16_splitk_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "rap_gemm_h16_splitk": (c_int32, [c_int32, c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32,
+                                      _P, c_size_t, _P]),
     "rap_gemm_h16_qkvnorm": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, c_float, _P, c_int32, _P]),
     "rap_attention_h16": (c_int32, [c_int32, _P, _P, c_int32, _P, c_int32, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "rap_layernorm_mod_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P]),

@@ -132,7 +132,8 @@ extern rap_tuning_t g_rap_attn_h16_dma;          // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_f32_persistent;   // gemm_f32.hip
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 // Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
-// fp32 summation order -- 5 split-KV for few-token calls, 6 split-K for few-row calls, 7 fused qk-norm, 9 GEGLU's Phi by the
+// fp32 summation order -- 5 split-KV for few-token calls (fp32 attention), 6 split-K for few-row calls (fp32 GEMMs and the 16-bit
+// residual GEMMs), 7 fused qk-norm, 9 GEGLU's Phi by the
 // 1.5e-7 erfc polynomial (1) or erff (0), 11 / 12 persistent 16-bit / fp32 GEMM.  Keys 0-4 (kernel-variant A/B of the round-1/2 experiments) exist
 // only in a library built with -DRAP_ABLATION_BUILD; the shipped library refuses them.
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
@@ -344,6 +345,7 @@ struct Workspace {
   u16* h16;                            // the residual stream when it is held in fp16 (16-bit modes with resid_dtype = fp16; h is then null)
   float *hid1, *hid2, *astatic;        // head hidden layers (T,d), (T,d/2) and the static feature matrix (T,128): aliases
   u16 *xnh, *qkh, *vth, *atth, *ffmidh; // reduced-precision mode: 16-bit activations (xn/qkv/att/ffmid are then unused)
+  float* splitk_h;                      // reduced-precision mode, few-token calls only: fp32 partial planes of the split-K ff2 GEMM (else null)
   int vt_nblk;
   double* proc_partials;
   int32_t *token_sample, *part_offsets;
@@ -364,6 +366,7 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   w.h16 = h16 ? (u16*)take(T * d * 2) : nullptr;
   w.xn = w.qkv = w.att = w.ffmid = nullptr;
   w.xnh = w.qkh = w.vth = w.atth = w.ffmidh = nullptr;
+  w.splitk_h = nullptr;
   w.vt_nblk = 0;
   if (m->dtype == RAP_DT_F32) {
     w.xn = (float*)take(T * d * 4);            // also head hidden 1 (TP,d)
@@ -381,6 +384,8 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
     w.hid1 = (float*)w.ffmidh;                 // (T,d) fp32   = 4*T*d bytes
     w.hid2 = w.hid1 + T * d;                   // (T,d/2) fp32 = 2*T*d bytes
     w.astatic = (float*)w.ffmidh;
+    const int splits = gemm_h16_splits((int)TP, (int)d, (int)(4 * d));      // ff2: the one layer GEMM with K >= 1024
+    if (splits > 1) w.splitk_h = (float*)take((size_t)splits * T * d * 4);
   }
   w.ax = (float*)take(T * 64 * 4);
   w.v = (float*)take(T * 3 * 4);
@@ -496,6 +501,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       GemmParamsH f2{};
       f2.A = w.ffmidh; f2.lda = 4 * d; f2.W = lh.Wff2; f2.ldw = 4 * d; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 4 * d;
       f2.bias = lw.bff2; f2.ldr = d;
+      f2.splitk_ws = w.splitk_h;               // few-token calls: K = 4d split over 2 / 4 blocks per tile (null otherwise)
       if (w.h16) { f2.C = w.h16; f2.resid_h = w.h16; } else { f2.C = w.h; f2.resid = w.h; }
       { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, epi_resid, f2); }
       if (rc) return rc;
@@ -792,6 +798,23 @@ extern "C" int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, 
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias;
   g.resid = resid; g.ldr = ldr; g.heads = heads; g.vt = vt; g.vt_nblk = vt_nblk;
   if (epilogue == EPI_H_BIAS_RESID_H16) { g.resid_h = reinterpret_cast<const uint16_t*>(resid); g.resid = nullptr; }   // fp16 residual
+  return launch_gemm_h16((hipStream_t)stream, dtype, epilogue, g);
+}
+// the residual epilogues (1, 6) with an optional split-K workspace (what rap_sample hands ff2 on few-token calls)
+extern "C" size_t rap_gemm_h16_splitk_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+  const int s = gemm_h16_splits(M, N, K);
+  return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+extern "C" int rap_gemm_h16_splitk(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, void* C,
+                                   int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const void* resid, int32_t ldr,
+                                   void* ws, size_t ws_bytes, void* stream) {
+  if (!A || !W || !C || (epilogue != EPI_H_BIAS_RESID_F32 && epilogue != EPI_H_BIAS_RESID_H16)) return RAP_ERR_INVALID;
+  const size_t need = rap_gemm_h16_splitk_workspace_bytes(M, N, K);
+  if (need && (!ws || ws_bytes < need)) return RAP_ERR_WORKSPACE;
+  GemmParamsH g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.ldr = ldr;
+  if (epilogue == EPI_H_BIAS_RESID_H16) g.resid_h = reinterpret_cast<const uint16_t*>(resid); else g.resid = reinterpret_cast<const float*>(resid);
+  g.splitk_ws = need ? reinterpret_cast<float*>(ws) : nullptr;
   return launch_gemm_h16((hipStream_t)stream, dtype, epilogue, g);
 }
 extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk,

@@ -287,6 +287,11 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
 // leaves as whole rows through an LDS slab.  The other schedules of rounds 1-2 (ping-pong, two software-pipelined kernels,
 // persistent blocks, rotated key walk, 512-query blocks -- all measured equal or slower) are in the history at 72efb73.
 // RAP_ABLATION_BUILD only: rap_set_tuning(3, 5) forces the online softmax even with bounds (A/B of the bounded kernel).
+// Few-token calls (one pair of 2 x 1024 points: 64 blocks for 256 CUs) -- two ways of filling the chip were measured in round 3 and NOT
+// kept: (a) 4 / 2 blocks of 64 / 128 queries per work item (bit-identical results): 18.4 vs 17.6 ms per bf16 call, 53.5 vs 50.8 at
+// 2 x 2048 (call 34) -- a wave then issues 4 / 2 times the LDS-DMA pieces per tile, and their issue cost is the wave's chain; (b) the fp32
+// kernel's split over key ranges with fp32 partial planes and a combine pass: 17.5 vs 17.7 ms and 54.6 vs 51.4 (call 35) -- the kernel
+// drops from 23.8 to 19.2 us per launch, the combine pass adds 5.3.  At that size every kernel of the layer sits at the 5-13 us launch floor.
 rap_tuning_t g_rap_attn_h16_variant = 0;
 rap_tuning_t g_rap_attn_h16_dma = 1;      // tuning key 13: K / V^T tiles by LDS-DMA (1, default) or staged through registers (0)
 

@@ -331,7 +331,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / 64;
+  // split-K (launch_splitk below: EPI_H_BIAS_RESID_F32 without bias / residual, gridDim.y = splits): block y multiplies k-tiles
+  // [y nk, (y + 1) nk) and writes plane y of the fp32 partial buffer
+  const int nk = p.K / 64 / (EPI == EPI_H_BIAS_RESID_F32 ? (int)gridDim.y : 1);
+  if constexpr (EPI == EPI_H_BIAS_RESID_F32) {
+    const size_t koff = (size_t)blockIdx.y * nk * 64;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) a_src[i] += koff;
+#pragma unroll
+    for (int i = 0; i < CB; ++i) w_src[i] += koff;
+  }
   const int sw = (l31 >> 1) & 7;
   const int a_row = (wm * TM * 32 + l31) * 128;                       // byte offsets inside one A / B buffer
   const int b_row = (wn * TN * 32 + l31) * 128;
@@ -420,6 +429,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
   static_assert(TN == 2, "wave tiles are 64 columns wide: one head / one GEGLU value+gate group");
   static_assert(WM * WN * H16_STG_BYTES + 1024 <= 2 * (BM + BN) * 128, "staging slabs (+ the LN statistics) must fit the operand buffers");
   __syncthreads();
+  if constexpr (EPI == EPI_H_BIAS_RESID_F32) {
+    if (gridDim.y > 1) {
+      GemmParamsH q = p;
+      q.C = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.y * p.M * p.ldc;
+      gemm_h16_epilogue<EPI, DT, TM>(q, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
+      return;
+    }
+  }
   gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
 }
 
@@ -881,6 +898,80 @@ static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
   return RAP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-K for the residual GEMMs of few-token calls (round 3).  ff2 of one pair of 2 x 1024 points is M = 2048, N = 512, K = 2048:
+// 64 tiles of 128 x 128 on 256 CUs, each a serial chain of 32 k-tiles with one tile of prefetch -- 33 us, latency-bound (r03 call 33: the
+// K = 512 out-projection of the same call takes 8.8 us).  Four blocks per tile take a quarter of the k-tiles each and write fp32 partial
+// tiles; the combine pass adds them in a fixed order, then bias, then the residual, and rounds once (fp16 stream) -- the unsplit
+// epilogue's order of operations with the k-sum re-associated.
+// ---------------------------------------------------------------------------------------------
+template <bool H16OUT>
+__global__ __launch_bounds__(256) void gemm_h16_splitk_combine_kernel(const float* __restrict__ part, int splits, int M, int N,
+                                                                      const float* __restrict__ bias, const void* __restrict__ resid, int ldr,
+                                                                      void* __restrict__ C, int ldc) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;      // one thread per 8 consecutive columns
+  const int n8 = N / 8;
+  if (i >= (long)M * n8) return;
+  const int m = (int)(i / n8), c = (int)(i % n8) * 8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < splits; ++s) {
+    const float4 a0 = *reinterpret_cast<const float4*>(part + ((size_t)s * M + m) * N + c);
+    const float4 a1 = *reinterpret_cast<const float4*>(part + ((size_t)s * M + m) * N + c + 4);
+    v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+  }
+  if (bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bias[c + e];
+  }
+  if constexpr (H16OUT) {
+    float rv[8];
+    h16_unpack8<RAP_DT_F16>(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(resid) + (size_t)m * ldr + c), rv);
+    const typename H16<RAP_DT_F16>::T8 o8 = h16_pack8<RAP_DT_F16>(v[0] + rv[0], v[1] + rv[1], v[2] + rv[2], v[3] + rv[3], v[4] + rv[4],
+                                                                 v[5] + rv[5], v[6] + rv[6], v[7] + rv[7]);
+    *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(C) + (size_t)m * ldc + c) = __builtin_bit_cast(uint4, o8);
+  } else {
+    float* out = reinterpret_cast<float*>(C) + (size_t)m * ldc + c;
+    if (resid) {
+      const float* r = reinterpret_cast<const float*>(resid) + (size_t)m * ldr + c;
+      const float4 r0 = *reinterpret_cast<const float4*>(r), r1 = *reinterpret_cast<const float4*>(r + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    *reinterpret_cast<float4*>(out) = float4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<float4*>(out + 4) = float4{v[4], v[5], v[6], v[7]};
+  }
+}
+
+extern rap_tuning_t g_rap_gemm_splitk;      // gemm_f32.hip, tuning key 6: split K for few-row calls (fp32 GEMMs and these)
+int gemm_h16_splits(int M, int N, int K) {
+  if (!g_rap_gemm_splitk || M <= 0 || N % 128 != 0 || K < 1024 || (K / 64) % 4 != 0) return 1;
+  const long tiles = (long)((M + 127) / 128) * (N / 128);
+  return tiles <= 64 ? 4 : tiles <= 128 ? 2 : 1;
+}
+
+template <int DT>
+static int launch_splitk(hipStream_t stream, int epilogue, const GemmParamsH& p, int splits) {
+  constexpr int LDS = 2 * (128 + 128) * 128;
+  auto kern = gemm_h16_kernel<EPI_H_BIAS_RESID_F32, DT, 2, 2, 2, 2>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    rap_set_last_hip_error((int)hipGetLastError());
+    return RAP_ERR_HIP;
+  }
+  GemmParamsH q = p;
+  q.C = p.splitk_ws; q.ldc = p.N; q.bias = nullptr; q.resid = nullptr; q.resid_h = nullptr; q.splitk_ws = nullptr;
+  hipLaunchKernelGGL(kern, dim3(((p.M + 127) / 128) * (p.N / 128), splits), dim3(256), LDS, stream, q);
+  RAP_LAUNCH_CHECK();
+  const long n8 = (long)p.M * (p.N / 8);
+  const dim3 grid((unsigned)((n8 + 255) / 256));
+  if (epilogue == EPI_H_BIAS_RESID_H16)
+    hipLaunchKernelGGL(gemm_h16_splitk_combine_kernel<true>, grid, dim3(256), 0, stream, p.splitk_ws, splits, p.M, p.N, p.bias,
+                       (const void*)p.resid_h, p.ldr, p.C, p.ldc);
+  else
+    hipLaunchKernelGGL(gemm_h16_splitk_combine_kernel<false>, grid, dim3(256), 0, stream, p.splitk_ws, splits, p.M, p.N, p.bias,
+                       (const void*)p.resid, p.ldr, p.C, p.ldc);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
 // The persistent kernel pays where the per-tile overhead is a large share of a tile: K <= 2048 (<= 32 k-tiles per output tile) and at least
 // two tiles per CU.  With long tiles a STATIC tile walk loses more to imbalance than it saves: 8192^3 (128 k-tiles, 4 tiles per block) runs at
 // 1 129 TF persistent vs 1 221 one tile per block, while K = 512 gains 21-23 % and K = 2048 8.5 % (scripts/gemm_square.py, r03 call 23).
@@ -908,6 +999,13 @@ static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
 
 template <int DT>
 static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
+  if ((epilogue == EPI_H_BIAS_RESID_F32 || epilogue == EPI_H_BIAS_RESID_H16) && p.splitk_ws) {
+    const int splits = gemm_h16_splits(p.M, p.N, p.K);
+    if (splits > 1) {
+      if ((p.ldc & 7) || (p.ldr & 7) || (epilogue == EPI_H_BIAS_RESID_H16 && !p.resid_h)) return RAP_ERR_INVALID;
+      return launch_splitk<DT>(stream, epilogue, p, splits);
+    }
+  }
   switch (epilogue) {
     case EPI_H_BIAS: return launch_variant<EPI_H_BIAS, DT>(stream, p);
     case EPI_H_BIAS_RESID_F32: return launch_variant<EPI_H_BIAS_RESID_F32, DT>(stream, p);

@@ -125,7 +125,13 @@ struct GemmParamsH {
   uint16_t* vt; int vt_nblk;
   const uint16_t* resid_h = nullptr;                                                     // EPI_H_BIAS_RESID_H16 (row stride ldr)
   const float* gamma_q = nullptr; const float* gamma_k = nullptr; float q_mul = 8.0f;   // EPI_H_QKV_NORM
+  // EPI_H_BIAS_RESID_F32 / _H16 on few-row calls (round 3): when splitk_ws (>= gemm_h16_splits(M, N, K) * M * N floats) is given and
+  // gemm_h16_splits() > 1, K is split over that many blocks per 128 x 128 tile (gridDim.y) writing fp32 partial tiles to splitk_ws, and a
+  // combine pass forms residual + (bias + partials) in a fixed order (deterministic; differs from the unsplit sum in fp32 rounding only)
+  float* splitk_ws = nullptr;
 };
+// 1 = no split; 2 or 4 for GEMMs with K >= 1024 whose 128 x 128 tile grid covers at most a quarter / half of the CUs (tuning key 6)
+int gemm_h16_splits(int M, int N, int K);
 int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p);
 int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t* dst, size_t n);
 // attention on q,k half [2][H][TP][64] + transposed-blocked v (vt); out half (TP, H*64)

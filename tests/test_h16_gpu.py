@@ -22,6 +22,7 @@ from rap_amd import _lib, synthetic as S
 from rap_amd.flow_model import workspace
 
 pytestmark = pytest.mark.gpu
+RAP_ERR_WORKSPACE = -2
 
 TORCH_DT = {1: torch.bfloat16, 2: torch.float16}
 ULP = {1: 2.0 ** -8, 2: 2.0 ** -11}     # largest relative error of one round-to-nearest into the type
@@ -294,6 +295,59 @@ def test_gemm_h16_full_size_linearity_property(lib, dev, dt):
                                 _lib.ptr(None), _lib.ptr(None), 0, stream(dev)), "gemm_f32")
     torch.cuda.synchronize()
     assert (C - Cf).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("epi", [1, 6], ids=["fp32-stream", "fp16-stream"])
+@pytest.mark.parametrize("M,splits", [(100, 4), (2048, 4), (3000, 2), (9000, 1)])
+def test_gemm_h16_splitk_of_the_residual_gemm(lib, dev, dt, epi, M, splits):
+    """Few-token calls (round 3): ff2 (N = 512, K = 2048) has at most 128 tiles of 128 x 128 and a chain of 32 k-tiles per tile, so K is
+    split over 4 (<= 64 tiles) or 2 blocks per tile and a combine pass forms resid + (bias + partials) in a fixed order.  Checked: the
+    split count the workspace query implies, the result within one rounding of the fp64 evaluation, agreement with the unsplit kernel
+    (tuning key 6 = 0) to fp32-association level, run-to-run determinism, and that a short workspace is refused."""
+    g = torch.Generator().manual_seed(43)
+    N, K = 512, 2048
+    need = lib.rap_gemm_h16_splitk_workspace_bytes(M, N, K)
+    assert need == (splits * M * N * 4 if splits > 1 else 0)
+    A = to_h(torch.randn(M, K, generator=g), dt); W = to_h(torch.randn(N, K, generator=g) / K ** 0.5, dt)
+    bias = torch.randn(N, generator=g)
+    h0 = (torch.randn(M, N, generator=g) * 3)
+    h0 = h0.to(torch.float16) if epi == 6 else h0
+    ref = h0.double() + A.double() @ W.double().T + bias.double()
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    ws = workspace(dev, max(need, 256))
+    bits = torch.int16 if epi == 6 else torch.int32
+
+    def run(ws_bytes=None):
+        hd = h0.to(dev).clone()
+        rc = lib.rap_gemm_h16_splitk(dt, epi, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(hd), N, M, N, K, _lib.ptr(bd), _lib.ptr(hd), N,
+                                     _lib.ptr(ws), ws.numel() if ws_bytes is None else ws_bytes, stream(dev))
+        torch.cuda.synchronize()
+        return rc, hd.cpu()
+
+    rc, out = run()
+    assert rc == 0
+    if epi == 6:
+        err = (out.double() - ref).abs() / (ref.abs() + 1e-2)
+        assert err.max().item() < 1.01 * ULP[2] + 1e-4, err.max().item()     # one fp16 rounding (+ fp32 accumulation noise)
+    else:
+        assert (out.double() - ref).abs().max().item() < 2e-5               # fp32 accumulation of K exact products
+    rc2, out2 = run()
+    assert rc2 == 0 and torch.equal(out.view(bits), out2.view(bits))
+    try:
+        assert lib.rap_set_tuning(6, 0) == 0
+        assert lib.rap_gemm_h16_splitk_workspace_bytes(M, N, K) == 0
+        rc3, unsplit = run()
+    finally:
+        assert lib.rap_set_tuning(6, 1) == 0
+    assert rc3 == 0
+    if epi == 6:
+        d = (out.double() - unsplit.double()).abs() / (ref.abs() + 1e-2)
+        assert d.max().item() < 2.01 * ULP[2], d.max().item()                # at most the neighbouring fp16 value
+    else:
+        assert (out.double() - unsplit.double()).abs().max().item() < 1e-5   # the k-sum re-associated
+    if splits > 1:
+        assert run(ws_bytes=need - 4)[0] == RAP_ERR_WORKSPACE
 
 
 # ---------------------------------------------------------------------------------------------
@@ -650,3 +704,34 @@ def test_fused_qknorm_model_path_agrees_with_the_unfused_one(dev):
     print(f"bf16 forward vs fp32 golden: fused {e_fused:.2e}, unfused {e_unfused:.2e}")
     assert e_fused < FWD_REL_BOUND["bfloat16"] and e_unfused < FWD_REL_BOUND["bfloat16"]
     assert (outs[1] - outs[0]).abs().max().item() / vmax < FWD_REL_BOUND["bfloat16"]
+
+
+@pytest.mark.parametrize("name", ["l12_small_rigid", "l2_ragged_rigid"])
+def test_few_token_split_k_model_path_agrees_with_the_unsplit_one(name, dev):
+    """Few-token calls in the 16-bit modes (round 3): ff2 splits K over up to 4 blocks per 128 x 128 tile (tuning key 6; fp32 partial
+    planes in the call's workspace, one combine pass).  Same function, the k-sum re-associated: the velocity field of the whole network
+    agrees with the unsplit path far inside the bf16 deviation bound, and both stay inside it against the fp32 golden."""
+    lib = _lib.load()
+    g, inp = load_golden(name)
+    outs = {}
+    try:
+        for on in (1, 0):
+            assert lib.rap_set_tuning(6, on) == 0
+            cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev, "bfloat16")
+            cu_b, cu_p = O.prepare_cu_seqlens(inp)
+            d = {k: v.to(dev) for k, v in inp.items()}
+            TP = int(d["x_1"].shape[0])
+            assert (lib.rap_gemm_h16_splitk_workspace_bytes(TP, 512, 2048) > 0) == bool(on)      # the fixture IS a few-token call
+            outs[on] = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
+                             local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                             cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev)).cpu()
+    finally:
+        assert lib.rap_set_tuning(6, 1) == 0
+    v_ref = torch.from_numpy(g["fwd_velocity"])
+    vmax = v_ref.abs().max().item()
+    e_on, e_off = (outs[1] - v_ref).abs().max().item() / vmax, (outs[0] - v_ref).abs().max().item() / vmax
+    between = (outs[1] - outs[0]).abs().max().item() / vmax
+    print(f"bf16 forward vs fp32 golden: split-K ff2 {e_on:.2e}, unsplit {e_off:.2e}, between them {between:.2e}")
+    assert not torch.isnan(outs[1]).any()
+    assert e_on < FWD_REL_BOUND["bfloat16"] and e_off < FWD_REL_BOUND["bfloat16"]
+    assert between < FWD_REL_BOUND["bfloat16"]
