@@ -392,7 +392,20 @@ int launch_attention_f32(hipStream_t stream, const float* qkv, float* out, int T
   if (heads <= 0) return RAP_ERR_INVALID;
   if (splits > 1) {
     if (!bound || !part_o || !part_l) return RAP_ERR_INVALID;
-    hipLaunchKernelGGL((attention_f32_kernel<4, true, true>), dim3(max_items * heads, splits), dim3(256), 0, stream, qkv, out, TP,
+    // At most ~one block per CU in the grid (one pair of 2 x 1024 points: 8 work items x 8 heads x 4 key ranges = 256 blocks): ask for
+    // 16 KB of (unused) dynamic LDS on top of the 68 KB of tiles, so that only ONE block fits a CU.  Left to itself the dispatcher
+    // doubles blocks up on some CUs while others stay empty, and two 4-wave blocks on one CU share its four matrix pipes: 102 -> 72 us
+    // per launch, 62.5 -> 55.3 ms per fp32 call at that size (r03 call 36; the same trick changes nothing for the 16-bit attention
+    // and GEMM launches of such a call).
+    unsigned dyn = 0;
+    if ((long)max_items * heads * splits <= 384) {
+      dyn = 16384;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f32_kernel<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) {
+        rap_set_last_hip_error((int)hipGetLastError());
+        return RAP_ERR_HIP;
+      }
+    }
+    hipLaunchKernelGGL((attention_f32_kernel<4, true, true>), dim3(max_items * heads, splits), dim3(256), dyn, stream, qkv, out, TP,
                        heads, items, bound, part_o, part_l);
     RAP_LAUNCH_CHECK();
     const long n4 = (long)TP * heads * 16;
