@@ -531,6 +531,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       GemmParams o{};
       o.A = w.att; o.lda = d; o.W = lw.Wout[a]; o.ldw = d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = d;
       o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d;
+      o.splitk_ws = w.ffmid;     // idle between the FFNs (the split attention's partial planes are consumed by now): 4 partial (T,d) planes
       { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_BIAS_RESID, o); }
       if (rc) return rc;
     }

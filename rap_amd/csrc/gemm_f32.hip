@@ -810,8 +810,11 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
   v = g_rap_gemm_variant;
 #endif
   if (v != 16 && v != 32) v = (p.N % 256 == 0 && p.K >= 256 && (long)((p.M + 255) / 256) * (p.N / 256) >= 512) ? 32 : 16;
-  if (epilogue == EPI_BIAS_RESID && (v == 16 || v == 32) && p.splitk_ws && g_rap_gemm_splitk && p.K >= 1024 && (p.ldr & 3) == 0 && (p.ldc & 3) == 0 &&
-      (long)((p.M + GBM - 1) / GBM) * (p.N / GBN) <= 128) {
+  // few-row calls: K >= 1024 (ff2) when the tile grid covers at most half of the CUs, K >= 512 (the out-projection) when it covers at
+  // most a quarter (r03: one pair of 2 x 1024 points -- 64 tiles, a chain of 16 k-tiles each)
+  const long tiles128 = (long)((p.M + GBM - 1) / GBM) * (p.N / GBN);
+  if (epilogue == EPI_BIAS_RESID && (v == 16 || v == 32) && p.splitk_ws && g_rap_gemm_splitk && (p.ldr & 3) == 0 && (p.ldc & 3) == 0 &&
+      ((p.K >= 1024 && tiles128 <= 128) || (p.K >= 512 && tiles128 <= 64))) {
     const int splits = 4;
     hipLaunchKernelGGL(gemm_f32_dma_kernel<EPI_SPLITK_PART>, dim3(((p.M + GBM - 1) / GBM) * (p.N / GBN), splits), dim3(256), 0, stream, p);
     RAP_LAUNCH_CHECK();

@@ -28,7 +28,7 @@ struct GemmParams {
   const uint8_t* anchor; const float* anchor_emb;
   int heads;
   // few-row calls of the bias + residual epilogue with a long K (the FFN down-projection at a few thousand tokens): when
-  // splitk_ws (>= 4 * M * N floats) is given and the tile grid would cover under a quarter of the block slots, K is split over 4
+  // splitk_ws (>= 4 * M * N floats) is given and the tile grid covers at most half (K >= 1024) / a quarter (K >= 512) of the CUs, K is split over 4
   // blocks per tile writing partial tiles to splitk_ws, and a combine pass adds residual + bias + partials (deterministic order)
   float* splitk_ws;
   // EPI_QKV_HEADMAJOR with gamma_q / gamma_k set: MultiHeadRMSNorm (norm.py:28-33) fused -- q and k leave the GEMM normalised
