@@ -77,7 +77,9 @@ int rap_model_residual_dtype(const rap_model* m);
 
 /* Bytes of caller-provided workspace for one call on a batch of TP points, B samples, `nseg_part`
  * part segments (B*P for rap_sample, VP for rap_dit_forward) and `rows` adaLN rows
- * (num_steps for rap_sample, B for rap_dit_forward). */
+ * (num_steps for rap_sample, B for rap_dit_forward).  Depends on the model's compute / residual dtype and, for few-token calls in
+ * the 16-bit modes, on tuning key 6 (the split-K planes of the feed-forward GEMM): query it in the state the call will run in -- a
+ * call whose workspace is too small for the current state returns -2, it never overruns. */
 size_t rap_workspace_bytes(const rap_model* m, int64_t TP, int32_t B, int32_t nseg_part, int32_t rows);
 
 /* Replaces PointCloudDiT.forward (reference flow_model/point_cloud_dit.py:141-191), called from
