@@ -115,3 +115,33 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
     for key in (5, 6, 7, 9, 11, 12, 13):
         assert lib.rap_set_tuning(key, 2) == -1 and lib.rap_set_tuning(key, 1) == 0, key
     assert lib.rap_model_bounded_attention_launches(N) < 0
+
+
+def test_splitk_rule_of_the_16bit_residual_gemm_is_host_arithmetic():
+    """rap_gemm_h16_splitk_workspace_bytes states the few-token split-K rule of the 16-bit residual GEMMs (gemm_h16.hip:
+    gemm_h16_splits): K >= 1024 with K / 64 a multiple of 4, at most 64 tiles of 128 x 128 -> 4 partial planes, at most 128 -> 2,
+    otherwise none; tuning key 6 switches it off.  Pure host arithmetic -- and the entry point refuses a short workspace, other
+    epilogues and NULL operands before it touches the device."""
+    import ctypes
+    from rap_amd import _lib
+    lib = _lib.load()
+    q = lib.rap_gemm_h16_splitk_workspace_bytes
+    plane = lambda m, n: m * n * 4
+    assert q(2048, 512, 2048) == 4 * plane(2048, 512)          # ff2 of one pair of 2 x 1024 points: 16 x 4 = 64 tiles
+    assert q(2049, 512, 2048) == 2 * plane(2049, 512)          # 17 x 4 = 68 tiles
+    assert q(4096, 512, 2048) == 2 * plane(4096, 512)          # 128 tiles
+    assert q(4097, 512, 2048) == 0                             # 132 tiles: the grid covers more than half of the CUs
+    assert q(2048, 512, 512) == 0 and q(2048, 512, 960) == 0   # short K (the out-projection); K / 64 not a multiple of 4 is also out
+    assert q(100, 1024, 4096) == 4 * plane(100, 1024)          # d = 1024 models
+    assert q(100, 576, 2048) == 0                              # N not a multiple of 128
+    assert q(0, 512, 2048) == 0 and q(-5, 512, 2048) == 0
+    try:
+        assert lib.rap_set_tuning(6, 0) == 0
+        assert q(2048, 512, 2048) == 0
+    finally:
+        assert lib.rap_set_tuning(6, 1) == 0
+    N, one = ctypes.c_void_p(0), ctypes.c_void_p(256)
+    assert lib.rap_gemm_h16_splitk(1, 6, N, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 1 << 30, N) == -1      # NULL A
+    assert lib.rap_gemm_h16_splitk(1, 3, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 1 << 30, N) == -1    # not a residual epilogue
+    assert lib.rap_gemm_h16_splitk(1, 6, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 4 * plane(2048, 512) - 1, N) == -2   # short workspace
+    assert lib.rap_gemm_h16_splitk(1, 6, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, N, 0, N) == -2             # no workspace
