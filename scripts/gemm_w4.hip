@@ -1,0 +1,282 @@
+// Prototype (round 3, NOT part of librapflow): bf16 GEMM C (M,N) = A (M,K) W (N,K)^T with FOUR waves per 256 x 256 block tile, i.e. a
+// 128 x 128 tile per wave and ONE wave per SIMD (512 registers: 256 accumulators + fragments), against the shipped kernel's eight waves of
+// 128 x 64 (two waves per SIMD, phase-split, 8 barriers per k-tile).  Question it answers: does register blocking (one third fewer LDS
+// bytes per MFMA: 32 ds_read_b128 per 64 MFMAs instead of 28 per 32) and one barrier per k-tile beat the two-waves-per-SIMD hand-off
+// at the layer shapes (K = 512 / 2048) and on the guide's square shape?  MI355X_MICROARCH.md prices a one-wave-per-SIMD stream at 32.4
+// (hand-placed) to 35.8 (compiler-scheduled) cycles per MFMA with <= 5 fillers per gap.
+//   * tiles by LDS-DMA (global_load_lds_dwordx4, scalar base + 32-bit per-thread offset), two 64 KB stages, 128-byte rows with the
+//     slot ^ ((row >> 1) & 7) swizzle; 16 pieces per wave per k-tile, four per k-step, issued between the MFMAs of that step;
+//   * swapped product (W fragment as the A operand): a lane owns a row of C, results leave as 8-byte pieces (MODE 0) or not at all
+//     (MODE 1: main loop only; the store is guarded by a condition that is never true);
+//   * one block per CU walks its XCD's tiles (persistent, as the shipped kernel) -- MODE bit 1 clear: one tile per block.
+// extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_err)  -> TFLOP/s (max_err vs a naive kernel on a sample of C)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <type_traits>
+#include <vector>
+
+typedef unsigned short u16;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// m0 is declared clobbered instead of saved and restored around every piece (two SALU fewer per MFMA gap)
+#define W4_DMA1(VOFF, SBASE, LDSB)                                                                            \
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(VOFF), "s"(LDSB), "s"(SBASE) : "memory", "m0");
+#define W4_FENCE __builtin_amdgcn_sched_barrier(0);
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const u16* __restrict__ A, int lda, const u16* __restrict__ W, int ldw,
+                                                         u16* __restrict__ C, int ldc, int M, int N, int K) {
+  constexpr int STAGE = 65536, WOFF = 32768;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nt = N / 256;
+  const int total = (M / 256) * nt;
+  const int nk = K / 64;
+
+  // DMA: piece i (0..7) of an operand = LDS rows 32 i + 8 wave + lane / 8 (1 KB, lane-linear), physical slot lane % 8
+  const int r0 = wave * 8 + (lane >> 3);
+  const int lslot = (lane & 7) ^ ((r0 >> 1) & 7);            // (row >> 1) & 7 is the same for rows r0 + 32 i
+  const unsigned voffA = (unsigned)(r0 * lda + 8 * lslot) * 2u;
+  const unsigned voffW = (unsigned)(r0 * ldw + 8 * lslot) * 2u;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+  const size_t a_step = (size_t)32 * lda * 2, w_step = (size_t)32 * ldw * 2;     // bytes between the rows of consecutive pieces
+
+  const int sw = (l31 >> 1) & 7;
+  const unsigned char* a_rd = smem + (wr * 128 + l31) * 128;
+  const unsigned char* w_rd = smem + WOFF + (wc * 128 + l31) * 128;
+
+  f32x16 acc[4][4];
+  uint4 fa[2][4], fw[2][4];
+  auto read_frags = [&](int set, int stage, int ks) {
+    const int co = ((2 * ks + hi) ^ sw) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const uint4*>(a_rd + stage * STAGE + i * 4096 + co);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fw[set][j] = *reinterpret_cast<const uint4*>(w_rd + stage * STAGE + j * 4096 + co);
+  };
+  // swapped product: D[n][m] -- W fragment is the A operand, A fragment the B operand: the lane owns row m = 32 i + l31 of the wave tile
+  auto mma = [&](int set) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[set][j]), __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
+  };
+
+  // The k-tiles of consecutive output tiles form ONE stream (as in the shipped persistent kernel): the last k-tile of an output tile
+  // requests the FIRST k-tile of the block's next output tile (or, for the very last one, its own first k-tile again: valid memory,
+  // never read), so there is one prologue per block and one copy of the k-loop body without a branch.  The epilogue uses no LDS.
+  const int stride = (MODE & 2) ? (int)gridDim.x : total;    // persistent: a block walks v = blockIdx.x + i gridDim.x
+  auto tile_bases = [&](int v, const unsigned char*& ab, const unsigned char*& wb, int& m0, int& n0) {
+    const int logical = xcd_remap(v, total);
+    m0 = (logical / nt) * 256; n0 = (logical % nt) * 256;
+    ab = reinterpret_cast<const unsigned char*>(A) + (size_t)m0 * lda * 2;
+    wb = reinterpret_cast<const unsigned char*>(W) + (size_t)n0 * ldw * 2;
+  };
+  int v = blockIdx.x;
+  if (v >= total) return;
+  const unsigned char *a_base, *w_base, *a_next, *w_next;
+  int m0, n0, m0n, n0n;
+  tile_bases(v, a_base, w_base, m0, n0);
+  // prologue (once per block): k-tile 0 -> stage 0
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    W4_DMA1(voffA, a_base + i * a_step, lds_wave + (unsigned)(i * 4096))
+    W4_DMA1(voffW, w_base + i * w_step, lds_wave + (unsigned)(WOFF + i * 4096))
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  read_frags(0, 0, 0);
+  int par = 0;                                   // stage that holds the current k-tile of the stream
+
+  for (;;) {
+    const int vn = v + stride;
+    const bool has_next = vn < total;
+    if (has_next) tile_bases(vn, a_next, w_next, m0n, n0n); else { a_next = a_base; w_next = w_base; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = par;
+      const bool own = kt + 1 < nk;
+      const unsigned char* a_n = own ? a_base + (size_t)(kt + 1) * 128 : a_next;
+      const unsigned char* w_n = own ? w_base + (size_t)(kt + 1) * 128 : w_next;
+      const unsigned lds_n = lds_wave + (unsigned)((cur ^ 1) * STAGE);
+      // One filler per MFMA gap (the guide: <= 5 single-issue instructions hide under a 32-cycle MFMA of a lone wave):
+      //   k-steps 0-2: gaps 0-7 the eight fragment reads of the next k-step, gaps 8.. the LDS-DMA pieces of the next k-tile (6 + 5 + 5);
+      //   k-step 3:    gaps 0-7 nothing, then vmcnt(0) + barrier (the next stage is published, this one is free), gaps 8-15 the fragment
+      //                reads of k-step 0 of the next k-tile.
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int set = ks & 1, nset = set ^ 1;
+        const int p0 = ks == 0 ? 0 : ks == 1 ? 6 : 11, np = ks == 0 ? 6 : 5;      // pieces of this k-step (ks < 3)
+#pragma unroll
+        for (int idx = 0; idx < 16; ++idx) {
+          const int i = idx & 3, j = idx >> 2;
+          if (ks == 3 && idx == 8) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            W4_FENCE
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[set][j]), __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
+          W4_FENCE
+          // ---- the filler of this gap
+          const int rd = ks < 3 ? idx : idx - 8;                 // fragment read 0..7: 0-3 = A rows i, 4-7 = W rows j
+          if (ks < 3 ? idx < 8 : idx >= 8) {
+            const int stage_r = ks < 3 ? cur : (cur ^ 1);
+            const int ks_r = ks < 3 ? ks + 1 : 0;
+            const int co = ((2 * ks_r + hi) ^ sw) * 16;
+            if (rd < 4) fa[nset][rd] = *reinterpret_cast<const uint4*>(a_rd + stage_r * STAGE + rd * 4096 + co);
+            else fw[nset][rd - 4] = *reinterpret_cast<const uint4*>(w_rd + stage_r * STAGE + (rd - 4) * 4096 + co);
+          }
+          if (ks < 3 && idx >= 8 && idx - 8 < np) {
+            const int pc = p0 + idx - 8, pi = pc >> 1;
+            if (pc & 1) { W4_DMA1(voffW, w_n + pi * w_step, lds_n + (unsigned)(WOFF + pi * 4096)) }
+            else { W4_DMA1(voffA, a_n + pi * a_step, lds_n + (unsigned)(pi * 4096)) }
+          }
+          W4_FENCE
+        }
+      }
+      par ^= 1;
+    }
+    // keep the accumulators in their AGPRs until the k-loop is over
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+    W4_FENCE
+
+    // ---- epilogue (no LDS): acc[i][j][r] = C[m0 + wr 128 + 32 i + l31][n0 + wc 128 + 32 j + 8 (r / 4) + 4 hi + (r % 4)]
+    const bool store = (MODE & 1) ? (acc[0][0][0] == 123456.789f) : true;     // MODE bit 0: main loop only
+    if (store) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u16* crow = C + (size_t)(m0 + wr * 128 + 32 * i + l31) * ldc + n0 + wc * 128 + 4 * hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            *reinterpret_cast<uint2*>(crow + 32 * j + 8 * g) = __builtin_bit_cast(uint2, __builtin_convertvector(v4, bf16x4));
+          }
+      }
+    }
+    if (!has_next) break;
+    v = vn; a_base = a_next; w_base = w_next; m0 = m0n; n0 = n0n;
+  }
+}
+
+// pseudo-random bf16 values in [-scale/2, scale/2)
+__global__ void init_kernel(u16* p, size_t n, unsigned seed, float scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ (unsigned)(i >> 32) * 40503u ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    const float f = ((h >> 8) & 0xffff) / 65536.0f - 0.5f;
+    p[i] = (u16)(__float_as_uint(f * scale) >> 16);       // truncation is fine for test data
+  }
+}
+
+// naive reference on a sample of rows
+__global__ void ref_kernel(const u16* A, int lda, const u16* W, int ldw, float* out, const int* rows, int nrows, int N, int K) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ri = blockIdx.y;
+  if (n >= N || ri >= nrows) return;
+  const int m = rows[ri];
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float a = __uint_as_float((unsigned)A[(size_t)m * lda + k] << 16), w = __uint_as_float((unsigned)W[(size_t)n * ldw + k] << 16);
+    s += a * w;
+  }
+  out[(size_t)ri * N + n] = s;
+}
+
+static float bf2f(u16 h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_err) {
+  if (M % 256 || N % 256 || K % 64 || K < 128) return -1.0;
+  u16 *A, *W, *C;
+  const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N;
+  if (hipMalloc((void**)&A, na * 2) != hipSuccess || hipMalloc((void**)&W, nw * 2) != hipSuccess || hipMalloc((void**)&C, nc * 2) != hipSuccess) return -2.0;
+  hipLaunchKernelGGL(init_kernel, dim3(4096), dim3(256), 0, 0, A, na, 12345u, 2.0f);
+  hipLaunchKernelGGL(init_kernel, dim3(4096), dim3(256), 0, 0, W, nw, 777u, 0.1f);
+  (void)hipMemset(C, 0, nc * 2);
+  constexpr int LDS = 2 * 65536;
+  int ncu = 256;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
+  ncu = (ncu / 8) * 8;
+  const int total = (M / 256) * (N / 256);
+  const int grid = (mode & 2) ? (total < ncu ? total : ncu) : total;
+  auto launch = [&]() {
+    switch (mode & 3) {
+      case 0: hipLaunchKernelGGL(gemm_w4_kernel<0>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K); break;
+      case 1: hipLaunchKernelGGL(gemm_w4_kernel<1>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K); break;
+      case 2: hipLaunchKernelGGL(gemm_w4_kernel<2>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K); break;
+      default: hipLaunchKernelGGL(gemm_w4_kernel<3>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K); break;
+    }
+  };
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  launch();
+  if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "gemm_w4: launch failed: %s\n", hipGetErrorString(hipGetLastError())); return -3.0; }
+  if (max_err) {
+    *max_err = -1.0;
+    if (!(mode & 1)) {
+      const int nrows = 24;
+      std::vector<int> rows(nrows);
+      for (int i = 0; i < nrows; ++i) rows[i] = (int)(((long)i * 2654435761u) % (unsigned)M);
+      rows[0] = 0; rows[1] = M - 1; rows[2] = 255; rows[3] = 256;
+      int* drows; float* dref;
+      (void)hipMalloc((void**)&drows, nrows * 4); (void)hipMalloc((void**)&dref, (size_t)nrows * N * 4);
+      (void)hipMemcpy(drows, rows.data(), nrows * 4, hipMemcpyHostToDevice);
+      hipLaunchKernelGGL(ref_kernel, dim3((N + 255) / 256, nrows), dim3(256), 0, 0, A, K, W, K, dref, drows, nrows, N, K);
+      std::vector<float> href((size_t)nrows * N);
+      std::vector<u16> hc(N);
+      (void)hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost);
+      double worst = 0.0;
+      for (int i = 0; i < nrows; ++i) {
+        (void)hipMemcpy(hc.data(), C + (size_t)rows[i] * N, (size_t)N * 2, hipMemcpyDeviceToHost);
+        for (int n = 0; n < N; ++n) {
+          const double ref = href[(size_t)i * N + n], got = bf2f(hc[n]);
+          const double e = fabs(got - ref) / (fabs(ref) + 0.05);
+          if (e > worst) worst = e;
+        }
+      }
+      *max_err = worst;
+      (void)hipFree(drows); (void)hipFree(dref);
+    }
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, 0);
+  for (int it = 0; it < iters; ++it) launch();
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipFree(A); (void)hipFree(W); (void)hipFree(C);
+  return 2.0 * M * N * K * iters / (ms * 1e-3) / 1e12;
+}
