@@ -8,7 +8,9 @@
 //     slot ^ ((row >> 1) & 7) swizzle; 16 pieces per wave per k-tile, four per k-step, issued between the MFMAs of that step;
 //   * swapped product (W fragment as the A operand): a lane owns a row of C, results leave as 8-byte pieces (MODE 0) or not at all
 //     (MODE 1: main loop only; the store is guarded by a condition that is never true);
-//   * one block per CU walks its XCD's tiles (persistent, as the shipped kernel) -- MODE bit 1 clear: one tile per block.
+//   * one block per CU walks its XCD's tiles (persistent, as the shipped kernel) -- MODE bit 1 clear: one tile per block;
+//   * ablation of the main loop (with MODE bits 0 and 1 set): bit 2 = no LDS-DMA after the prologue, bit 3 = no fragment reads after the
+//     first (the MFMAs run on stale registers): 3 = full loop, 7 = MFMA + reads, 11 = MFMA + DMA, 15 = MFMA + barrier only.
 // extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_err)  -> TFLOP/s (max_err vs a naive kernel on a sample of C)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -102,9 +104,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const u16* __restrict__
     W4_DMA1(voffA, a_base + i * a_step, lds_wave + (unsigned)(i * 4096))
     W4_DMA1(voffW, w_base + i * w_step, lds_wave + (unsigned)(WOFF + i * 4096))
   }
+  if (MODE & 4) {                                // ablation without DMA: both stages hold real operands
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      W4_DMA1(voffA, a_base + i * a_step + 128, lds_wave + (unsigned)(STAGE + i * 4096))
+      W4_DMA1(voffW, w_base + i * w_step + 128, lds_wave + (unsigned)(STAGE + WOFF + i * 4096))
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   read_frags(0, 0, 0);
+  if (MODE & 8) read_frags(1, 0, 1);             // ablation without fragment reads: both register sets hold real operands
   int par = 0;                                   // stage that holds the current k-tile of the stream
 
   for (;;) {
@@ -144,14 +154,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const u16* __restrict__
           W4_FENCE
           // ---- the filler of this gap
           const int rd = ks < 3 ? idx : idx - 8;                 // fragment read 0..7: 0-3 = A rows i, 4-7 = W rows j
-          if (ks < 3 ? idx < 8 : idx >= 8) {
+          if (!(MODE & 8) && (ks < 3 ? idx < 8 : idx >= 8)) {
             const int stage_r = ks < 3 ? cur : (cur ^ 1);
             const int ks_r = ks < 3 ? ks + 1 : 0;
             const int co = ((2 * ks_r + hi) ^ sw) * 16;
             if (rd < 4) fa[nset][rd] = *reinterpret_cast<const uint4*>(a_rd + stage_r * STAGE + rd * 4096 + co);
             else fw[nset][rd - 4] = *reinterpret_cast<const uint4*>(w_rd + stage_r * STAGE + (rd - 4) * 4096 + co);
           }
-          if (ks < 3 && idx >= 8 && idx - 8 < np) {
+          if (!(MODE & 4) && ks < 3 && idx >= 8 && idx - 8 < np) {
             const int pc = p0 + idx - 8, pi = pc >> 1;
             if (pc & 1) { W4_DMA1(voffW, w_n + pi * w_step, lds_n + (unsigned)(WOFF + pi * 4096)) }
             else { W4_DMA1(voffA, a_n + pi * a_step, lds_n + (unsigned)(pi * 4096)) }
@@ -228,18 +238,17 @@ extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_
   ncu = (ncu / 8) * 8;
   const int total = (M / 256) * (N / 256);
   const int grid = (mode & 2) ? (total < ncu ? total : ncu) : total;
+#define W4_CASE(MD)                                                                                                          \
+  case MD:                                                                                                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<MD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+    hipLaunchKernelGGL(gemm_w4_kernel<MD>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K);                        \
+    break;
   auto launch = [&]() {
-    switch (mode & 3) {
-      case 0: hipLaunchKernelGGL(gemm_w4_kernel<0>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K); break;
-      case 1: hipLaunchKernelGGL(gemm_w4_kernel<1>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K); break;
-      case 2: hipLaunchKernelGGL(gemm_w4_kernel<2>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K); break;
-      default: hipLaunchKernelGGL(gemm_w4_kernel<3>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K); break;
+    switch (mode & 15) {
+      W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(7) W4_CASE(11) W4_CASE(15)
+      default: break;
     }
   };
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   launch();
   if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "gemm_w4: launch failed: %s\n", hipGetErrorString(hipGetLastError())); return -3.0; }
   if (max_err) {

@@ -14,7 +14,11 @@ lib.gemm_w4.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)]
 SHAPES = [("guide square", 8192, 8192, 8192), ("ff2", 262144, 512, 2048), ("out-projection", 262144, 512, 512), ("ff1 (no GEGLU)", 262144, 4096, 512),
           ("qkv (plain store)", 262144, 1536, 512)]
 for name, M, N, K in SHAPES:
-    for mode, what in ((0, "one tile per block"), (2, "persistent"), (1, "one tile per block, main loop only"), (3, "persistent, main loop only")):
+    modes = ((0, "one tile per block"), (2, "persistent"), (1, "one tile per block, main loop only"), (3, "persistent, main loop only"))
+    if "--ablation" in sys.argv:
+        modes = ((3, "persistent, main loop only"), (7, "main loop without LDS-DMA (MFMA + fragment reads + barrier)"),
+                 (11, "main loop without fragment reads (MFMA + LDS-DMA + barrier)"), (15, "MFMA + barrier only"))
+    for mode, what in modes:
         err = ctypes.c_double(-1.0)
         iters = 5 if M * N * K > 2 ** 38 else 20
         tf = lib.gemm_w4(M, N, K, mode, iters, ctypes.byref(err))
