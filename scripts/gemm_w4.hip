@@ -9,6 +9,7 @@
 //   * swapped product (W fragment as the A operand): a lane owns a row of C, results leave as 8-byte pieces (MODE 0) or not at all
 //     (MODE 1: main loop only; the store is guarded by a condition that is never true);
 //   * one block per CU walks its XCD's tiles (persistent, as the shipped kernel) -- MODE bit 1 clear: one tile per block;
+//   * MODE bit 4: epilogue through a per-wave LDS slab (ds_write_b64 of the lane's 4-column groups, whole 256-byte rows out);
 //   * ablation of the main loop (with MODE bits 0 and 1 set): bit 2 = no LDS-DMA after the prologue, bit 3 = no fragment reads after the
 //     first (the MFMAs run on stale registers): 3 = full loop, 7 = MFMA + reads, 11 = MFMA + DMA, 15 = MFMA + barrier only.
 // extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_err)  -> TFLOP/s (max_err vs a naive kernel on a sample of C)
@@ -180,7 +181,33 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const u16* __restrict__
 
     // ---- epilogue (no LDS): acc[i][j][r] = C[m0 + wr 128 + 32 i + l31][n0 + wc 128 + 32 j + 8 (r / 4) + 4 hi + (r % 4)]
     const bool store = (MODE & 1) ? (acc[0][0][0] == 123456.789f) : true;     // MODE bit 0: main loop only
-    if (store) {
+    if (store && (MODE & 16)) {
+      // LDS-transposed epilogue: the stage that was read last (par ^ 1 after the loop's flip = the one NOT holding the next k-tile) is
+      // idle; every wave owns 8.5 KB of it: 32 rows x (128 columns + 8 pad) bf16.  Per 32-row slab: the lane (row l31) writes its
+      // sixteen 4-column groups as ds_write_b64, then the wave reads whole 256-byte rows back (16 lanes x 16 B) and stores them.
+      unsigned char* slab = smem + (par ^ 1) * STAGE + wave * 8704;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            *reinterpret_cast<uint2*>(slab + l31 * 272 + (32 * j + 8 * g + 4 * hi) * 2) = __builtin_bit_cast(uint2, __builtin_convertvector(v4, bf16x4));
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        uint4 rowv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) rowv[t] = *reinterpret_cast<const uint4*>(slab + (4 * t + (lane >> 4)) * 272 + (lane & 15) * 16);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          *reinterpret_cast<uint4*>(C + (size_t)(m0 + wr * 128 + 32 * i + 4 * t + (lane >> 4)) * ldc + n0 + wc * 128 + (lane & 15) * 8) = rowv[t];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+      __syncthreads();     // the next k-loop's DMA (any wave's pieces) overwrites this stage
+    } else if (store) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         u16* crow = C + (size_t)(m0 + wr * 128 + 32 * i + l31) * ldc + n0 + wc * 128 + 4 * hi;
@@ -244,8 +271,8 @@ extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_
     hipLaunchKernelGGL(gemm_w4_kernel<MD>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K);                        \
     break;
   auto launch = [&]() {
-    switch (mode & 15) {
-      W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(7) W4_CASE(11) W4_CASE(15)
+    switch (mode & 31) {
+      W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(7) W4_CASE(11) W4_CASE(15) W4_CASE(16) W4_CASE(18)
       default: break;
     }
   };

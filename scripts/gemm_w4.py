@@ -15,6 +15,9 @@ SHAPES = [("guide square", 8192, 8192, 8192), ("ff2", 262144, 512, 2048), ("out-
           ("qkv (plain store)", 262144, 1536, 512)]
 for name, M, N, K in SHAPES:
     modes = ((0, "one tile per block"), (2, "persistent"), (1, "one tile per block, main loop only"), (3, "persistent, main loop only"))
+    if "--epilogue" in sys.argv:
+        modes = ((18, "persistent, epilogue through an LDS slab (whole rows out)"), (16, "one tile per block, epilogue through an LDS slab"),
+                 (2, "persistent, direct 8-byte stores"), (3, "persistent, main loop only"))
     if "--ablation" in sys.argv:
         modes = ((3, "persistent, main loop only"), (7, "main loop without LDS-DMA (MFMA + fragment reads + barrier)"),
                  (11, "main loop without fragment reads (MFMA + LDS-DMA + barrier)"), (15, "MFMA + barrier only"))
