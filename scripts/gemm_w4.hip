@@ -256,8 +256,9 @@ extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_
   u16 *A, *W, *C;
   const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N;
   if (hipMalloc((void**)&A, na * 2) != hipSuccess || hipMalloc((void**)&W, nw * 2) != hipSuccess || hipMalloc((void**)&C, nc * 2) != hipSuccess) return -2.0;
-  hipLaunchKernelGGL(init_kernel, dim3(4096), dim3(256), 0, 0, A, na, 12345u, 2.0f);
-  hipLaunchKernelGGL(init_kernel, dim3(4096), dim3(256), 0, 0, W, nw, 777u, 0.1f);
+  const float zs = (mode & 32) ? 0.f : 1.f;      // mode bit 5: all-zero operands (the power argument: same instructions, no toggling)
+  hipLaunchKernelGGL(init_kernel, dim3(4096), dim3(256), 0, 0, A, na, 12345u, 2.0f * zs);
+  hipLaunchKernelGGL(init_kernel, dim3(4096), dim3(256), 0, 0, W, nw, 777u, 0.1f * zs);
   (void)hipMemset(C, 0, nc * 2);
   constexpr int LDS = 2 * 65536;
   int ncu = 256;

@@ -21,6 +21,11 @@ for name, M, N, K in SHAPES:
     if "--ablation" in sys.argv:
         modes = ((3, "persistent, main loop only"), (7, "main loop without LDS-DMA (MFMA + fragment reads + barrier)"),
                  (11, "main loop without fragment reads (MFMA + LDS-DMA + barrier)"), (15, "MFMA + barrier only"))
+    if "--zeros" in sys.argv:
+        if name != "guide square":
+            continue
+        modes = ((15, "MFMA + barrier only, random operands"), (15 + 32, "MFMA + barrier only, ALL-ZERO operands"),
+                 (3, "full main loop, random operands"), (3 + 32, "full main loop, ALL-ZERO operands"))
     for mode, what in modes:
         err = ctypes.c_double(-1.0)
         iters = 5 if M * N * K > 2 ** 38 else 20
