@@ -39,8 +39,8 @@ import torch.nn.functional as F
 # ----------------------------------------------------------------------------
 def repeat_by_cu_seqlens(x: torch.Tensor, cu_seqlens: torch.Tensor) -> torch.Tensor:
     """point_clouds.py:161-184 -- row b of x repeated (cu[b+1]-cu[b]) times."""
-    lens = (cu_seqlens[1:] - cu_seqlens[:-1]).to(torch.int64)
-    idx = torch.repeat_interleave(torch.arange(x.shape[0]), lens)
+    lens = (cu_seqlens[1:] - cu_seqlens[:-1]).to(device=x.device, dtype=torch.int64)
+    idx = torch.repeat_interleave(torch.arange(x.shape[0], device=x.device), lens)
     return x.index_select(0, idx)
 
 
@@ -63,7 +63,7 @@ def split_parts(pointclouds: torch.Tensor, points_per_part: torch.Tensor, cu_seq
 def posenc(x: torch.Tensor, num_freqs: int = 10) -> torch.Tensor:
     """embedding.py:29-58: [x, sin(f0 x), cos(f0 x), ..., sin(f9 x), cos(f9 x)], f_k = 2^k."""
     outs = [x]
-    freqs = 2.0 ** torch.linspace(0.0, num_freqs - 1, steps=num_freqs)
+    freqs = 2.0 ** torch.linspace(0.0, num_freqs - 1, steps=num_freqs, device=x.device)
     for f in freqs:
         fx = x * f.to(x.dtype)
         outs.append(torch.sin(fx))
@@ -85,7 +85,7 @@ def timestep_sinusoid(t: torch.Tensor, num_channels: int = 256) -> torch.Tensor:
     as configured at norm.py:50-52: [cos(t w_i), sin(t w_i)], w_i = exp(-ln(1e4) i/128).
     The frequencies are built in fp32 (as diffusers does) and the product/sin/cos in fp32."""
     half = num_channels // 2
-    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=t.device) / half
     w = torch.exp(exponent)
     arg = t[:, None].float() * w[None, :]
     return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
@@ -121,14 +121,33 @@ def varlen_attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor) -> torch.Tenso
     """flash_attn_varlen_qkvpacked_func(qkv (T,3,H,D), cu_seqlens, softmax_scale=D^-1/2,
     causal=False, softcap=0, dropout=0) as called at layer.py:106-111,123-128."""
     T, _, H, D = qkv.shape
-    out = torch.zeros((T, H, D), dtype=qkv.dtype)
+    out = torch.zeros((T, H, D), dtype=qkv.dtype, device=qkv.device)
     cu = cu_seqlens.tolist()
     for s in range(len(cu) - 1):
         a, b = cu[s], cu[s + 1]
         if b == a:
             continue
         q, k, v = (qkv[a:b, i].transpose(0, 1) for i in range(3))
-        out[a:b] = F.scaled_dot_product_attention(q, k, v).transpose(0, 1)
+        if qkv.is_cuda:
+            out[a:b] = _softmax_attention_chunked(q, k, v).transpose(0, 1)
+        else:
+            out[a:b] = F.scaled_dot_product_attention(q, k, v).transpose(0, 1)
+    return out
+
+
+def _softmax_attention_chunked(q, k, v, max_score_elems: int = 1 << 28):
+    """The device-side checker's attention (tests only, see ``sample(device=...)``): softmax(q k^T / sqrt(D)) v written out with
+    plain matmuls in the tensors' own dtype (fp32 / fp64), query rows in chunks so that the (H, chunk, L) score block stays below
+    ``max_score_elems`` (1 GiB of fp32) -- the math the CPU branch's F.scaled_dot_product_attention evaluates, without depending on
+    which fused SDPA backend a GPU build of torch would pick.  q, k, v: (H, L, D)."""
+    H, L, D = q.shape
+    scale = 1.0 / math.sqrt(D)
+    kt = k.transpose(1, 2)
+    out = torch.empty_like(q)
+    chunk = max(1, min(L, max_score_elems // max(1, H * L)))
+    for a in range(0, L, chunk):
+        p = torch.softmax(torch.matmul(q[:, a:a + chunk], kt) * scale, dim=-1)
+        out[:, a:a + chunk] = torch.matmul(p, v)
     return out
 
 
@@ -202,12 +221,15 @@ def solve_procrustes(source: torch.Tensor, target: torch.Tensor):
     sm = source.mean(dim=0, keepdim=True)
     tm = target.mean(dim=0, keepdim=True)
     Hm = (source - sm).t() @ (target - tm)
-    U, _, Vt = torch.linalg.svd(Hm)
+    # device-side checker: the 3 x 3 factorisation runs on the host LAPACK exactly as in the CPU oracle (the moments above are the
+    # device's work); a no-op for CPU tensors
+    U, _, Vt = torch.linalg.svd(Hm.cpu())
     R = Vt.t() @ U.t()
     if torch.det(R) < 0:
         Vt = Vt.clone()
         Vt[-1, :] *= -1
         R = Vt.t() @ U.t()
+    R = R.to(source.device)
     t = tm - sm @ R.t()
     return R, t.squeeze(0)
 
@@ -217,8 +239,9 @@ def fit_transformations(source, target, points_per_part, cu_seqlens_batch):
     B, P = points_per_part.shape
     ps = split_parts(source, points_per_part, cu_seqlens_batch)
     pt = split_parts(target, points_per_part, cu_seqlens_batch)
-    R = torch.zeros(B, P, 3, 3, dtype=source.dtype)
-    t = torch.zeros(B, P, 3, dtype=source.dtype)
+    R = torch.zeros(B, P, 3, 3, dtype=source.dtype, device=source.device)
+    t = torch.zeros(B, P, 3, dtype=source.dtype, device=source.device)
+    points_per_part = points_per_part.cpu()
     for b in range(B):
         for p in range(P):
             if points_per_part[b, p] == 0:
@@ -235,6 +258,7 @@ def rigidify_prediction_with_procrustes(prediction, condition, points_per_part, 
     ps = split_parts(condition, points_per_part, cu_seqlens_batch)
     pt = split_parts(prediction, points_per_part, cu_seqlens_batch)
     out = torch.zeros_like(prediction)
+    points_per_part = points_per_part.cpu()
     off = 0
     for b in range(B):
         for p in range(P):
@@ -263,8 +287,8 @@ def flow_sampler(flow_model_fn, x_1, num_steps, points_per_part, cu_seqlens_batc
     """sampler.py:11-74 with return_trajectory=True (the only way modeling.py:719 calls it)."""
     dt = 1.0 / num_steps
     x_t = x_1.clone()
-    traj = torch.empty((num_steps, *x_1.shape), dtype=x_1.dtype)
-    traj_xt = torch.empty((num_steps, *x_1.shape), dtype=x_1.dtype)
+    traj = torch.empty((num_steps, *x_1.shape), dtype=x_1.dtype, device=x_1.device)
+    traj_xt = torch.empty((num_steps, *x_1.shape), dtype=x_1.dtype, device=x_1.device)
     for step in range(num_steps):
         t = 1 - step * dt
         x_t, x0_hat = euler_step(x_t, t, dt, flow_model_fn)
@@ -288,19 +312,25 @@ def prepare_cu_seqlens(inputs):
 
 @torch.inference_mode()
 def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.float32,
-           max_steps: int | None = None):
+           max_steps: int | None = None, device=None):
     """sample_rectified_flow + fit_transformations on the last end-point (modeling.py:356-391).
 
     ``max_steps`` (oracle-only convenience for the bounded CPU baseline): run only the first
-    ``max_steps`` of ``num_steps`` flow steps (same dt and time grid)."""
-    sd = {k: v.to(dtype) for k, v in sd.items()}
-    cond = inputs["pointclouds"].to(dtype)
-    feats = inputs["features"].to(dtype)
-    scales = inputs["scales"].to(dtype)
-    x_1 = inputs["x_1"].to(dtype)
-    anchor = inputs["anchor_indices"]
-    ppp = inputs["points_per_part"]
-    cu_batch, cu_part = prepare_cu_seqlens(inputs)
+    ``max_steps`` of ``num_steps`` flow steps (same dt and time grid).
+
+    ``device`` (tests only): run this same restatement on a GPU through PyTorch-ROCm (plain fp32 / fp64 torch ops; attention by
+    ``_softmax_attention_chunked``, the 3 x 3 SVDs on the host) as the DEVICE-SIDE CHECKER for the configurations the CPU cannot
+    reach in test time (all 32 pairs of configs[1], all 50 steps of configs[4], 400 000-token samples).  It is pinned to the CPU
+    evaluation of this file -- and through it to the reference -- by tests/test_fullconfig_gpu.py::test_device_oracle_equals_cpu_oracle."""
+    device = torch.device("cpu") if device is None else torch.device(device)
+    sd = {k: v.to(device=device, dtype=dtype) for k, v in sd.items()}
+    cond = inputs["pointclouds"].to(device=device, dtype=dtype)
+    feats = inputs["features"].to(device=device, dtype=dtype)
+    scales = inputs["scales"].to(device=device, dtype=dtype)
+    x_1 = inputs["x_1"].to(device=device, dtype=dtype)
+    anchor = inputs["anchor_indices"].to(device)
+    ppp = inputs["points_per_part"].cpu()
+    cu_batch, cu_part = prepare_cu_seqlens({"points_per_part": ppp, "cu_seqlens": inputs["cu_seqlens"].cpu()})
     B = cu_batch.shape[0] - 1
 
     # feature capture of the sampling call (modeling.py:666-708): the model call with index num_steps - 1 (or the first one with
@@ -309,7 +339,7 @@ def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.
     call_count = [0]
 
     def fn(x, t):
-        ts = torch.full((B,), t, dtype=dtype)                                  # modeling.py:674
+        ts = torch.full((B,), t, dtype=dtype, device=device)                   # modeling.py:674
         is_last_call = (t < 1e-6) or (call_count[0] >= num_steps - 1)          # modeling.py:678
         if is_last_call and captured["features"] is None:                      # modeling.py:680-695
             r = dit_forward(sd, cfg, x, ts, cond, feats, scales, anchor, cu_batch, cu_part, return_transformer_features=True)
@@ -323,8 +353,8 @@ def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.
     else:
         dt = 1.0 / num_steps
         x_t = x_1.clone()
-        traj = torch.empty((max_steps, *x_1.shape), dtype=dtype)
-        traj_xt = torch.empty((max_steps, *x_1.shape), dtype=dtype)
+        traj = torch.empty((max_steps, *x_1.shape), dtype=dtype, device=device)
+        traj_xt = torch.empty((max_steps, *x_1.shape), dtype=dtype, device=device)
         for step in range(max_steps):
             t = 1 - step * dt
             x_t, x0_hat = euler_step(x_t, t, dt, fn)

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a -m gpu test that takes minutes (still part of -m gpu; deselect with -m 'gpu and not slow')")
 
 
 @pytest.fixture(scope="session")

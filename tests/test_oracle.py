@@ -385,3 +385,29 @@ def test_oracle_statistical_outlier_rule_on_a_known_case():
     dup = np.concatenate([grid, grid[:1]])                       # point 0 twice: with k = 2 both copies see only each other -> d = 0
     idx2, avg2 = O.remove_statistical_outlier(dup, nb_neighbors=2, std_ratio=10.0)
     assert avg2[0] == 0 and avg2[100] == 0 and 0 not in idx2 and 100 not in idx2
+
+
+def test_device_checker_attention_math_equals_sdpa_on_cpu():
+    """The explicit matmul + softmax attention the DEVICE-side checker uses (`_softmax_attention_chunked`, query rows in chunks) is the
+    function F.scaled_dot_product_attention evaluates on the CPU path -- checked here on CPU, with a chunk size that forces several
+    ragged chunks, in fp32 and fp64."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    for dtype, tol in ((torch.float32, 2e-6), (torch.float64, 1e-14)):
+        q, k, v = (torch.randn(8, 301, 64, generator=g, dtype=dtype) for _ in range(3))
+        ref = F.scaled_dot_product_attention(q, k, v)
+        got = O._softmax_attention_chunked(q, k, v, max_score_elems=8 * 301 * 37)
+        assert float((got - ref).abs().max()) <= tol
+        one = O._softmax_attention_chunked(q[:, :1], k[:, :1], v[:, :1])       # single-token segment: out = v
+        assert torch.equal(one, v[:, :1])
+
+
+def test_sample_device_argument_is_a_noop_on_cpu():
+    """`O.sample(..., device="cpu")` is the same evaluation as the default (the device argument only moves tensors)."""
+    g, inp = load_golden("l2_ragged_rigid")
+    cfg = dict(S.RAP_12); cfg["num_layers"] = int(g["num_layers"])
+    sd = S.make_weights(cfg, int(g["weight_seed"]))
+    a = O.sample(sd, cfg, inp, int(g["num_steps"]), bool(g["rigidity"]))
+    b = O.sample(sd, cfg, inp, int(g["num_steps"]), bool(g["rigidity"]), device="cpu")
+    for k in ("end_point_trajectory", "trajectory", "R", "t"):
+        assert torch.equal(a[k], b[k])
