@@ -18,15 +18,22 @@ asserts WORLD_SIZE == --gpus before anything is timed: the line can never report
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
   roofline      -- the dominant kernel (attention_f32_kernel): algorithmic FLOPs / HIP-event time, vs the
                    157.3 TFLOP/s fp32 matrix peak of gfx950;
-  cpu_baseline  -- the CPU oracle (restatement of the reference, pinned to it) timed on this box's host cores
-                   on a bounded sample (1 pair, 1 of 20 flow steps), extrapolated linearly; the one-off measurement of the
-                   LIVE reference over all 20 steps of that pair (build container) is cited from profiles/.
+  cpu_baseline  -- the reference timed on this box's host cores in this run: the LIVE reference (unmodified modules under
+                   /root/reference, kind "reference") when the mount exists, else the CPU oracle (restatement pinned to it, kind
+                   "port" -- the GPU box has no mount); a bounded sample: 1 pair, the first 1 and the first 3 of the 20 flow steps
+                   (two points -> a per-step slope and a fixed cost, extrapolated to 20 steps), or all 20 with --cpu-full.
+  ragged        -- the same path on a RAGGED packed batch in the reference's own regime (rap_amd.synthetic.ragged_regime_parts:
+                   samples of 2 / 8 / 64 parts, 200 ... 20 000 points per part, ~262 k points, not a multiple of any tile), in fp32 and
+                   bf16, with the same roofline object and the whole-call algorithmic TFLOP/s beside the uniform batch's.
   roofline_online_softmax -- the same dominant kernel in its ONLINE-softmax instantiation, measured on the same batch with the seeded
                    q/k-norm gains multiplied by --gamma-scale (default 3: every logit bound 8 max|gamma_q| max|gamma_k| > 40, so every
                    attention launch takes the online kernel): what a trained checkpoint with large gains runs; the kernel is chosen per
                    (layer, branch) launch, so one hot head costs 1 / (2 * layers) of the difference.
   parity_vs_reference_golden -- pair 0 of the timed batch against tests/golden/headline_c1_*.npz: the unmodified reference's
                    result for that pair over ALL flow steps (final cloud, last x_t, poses, every 32nd point of every step).
+  parity_vs_device_checker_last_pair -- the LAST pair of the timed batch against the pinned oracle evaluated on this GPU through
+                   PyTorch-ROCm in fp32 (test infrastructure, oracle/rap_oracle.py sample(device=...); all 32 pairs:
+                   tests/test_fullconfig_gpu.py).
 """
 from __future__ import annotations
 
@@ -99,43 +106,122 @@ def parse_args():
     ap.add_argument("--gamma-scale", type=float, default=3.0,
                     help="multiplier on the seeded q/k-norm gains for the extra 'roofline_online_softmax' leg (1 warm-up + 1 timed sample "
                          "call per precision; 0 = skip the leg)")
+    ap.add_argument("--workload", default="uniform", choices=["uniform", "ragged"],
+                    help="uniform = BASELINE configs[1] (--batch pairs x --views x --points; the headline); ragged = the HEADLINE run "
+                         "itself on the ragged reference-regime batch (the default run appends it as the 'ragged' object instead)")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the extra 'ragged' leg of a uniform run")
+    ap.add_argument("--ragged-points", type=int, default=262144)
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline over ALL flow steps of the pair (minutes) instead of 1 + 3 steps")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra bf16 measurement of the same workload that a float32 run appends as 'reduced_precision'")
     return ap.parse_args()
 
 
-def attention_flops_per_forward(batch, views, points, layers, heads=8, dh=64):
+def attention_flops_per_forward(parts, heads=8, dh=64):
     """Algorithmic FLOPs of the two attention launches of one layer, summed over the batch:
-    4 * H * Dh * L_seg per query token (QK^T and PV, 2 FLOP per MAC)."""
-    tp = batch * views * points
-    per_part = tp * 4 * heads * dh * points
-    per_sample = tp * 4 * heads * dh * views * points
+    4 * H * Dh * L_seg per query token (QK^T and PV, 2 FLOP per MAC) -> 4 * H * Dh * sum(L_seg^2).
+    parts: list over samples of part sizes."""
+    per_part = 4 * heads * dh * sum(n * n for sizes in parts for n in sizes)
+    per_sample = 4 * heads * dh * sum(sum(sizes) ** 2 for sizes in parts)
     return per_part, per_sample
 
 
-def cpu_baseline(cfg, sd, args, gpu_first_step):
-    """Oracle on the host cores: 1 pair, the first of `flow_steps` flow steps; linear extrapolation."""
+DENSE_FLOPS_PER_TOKEN_LAYER = 10.486e6      # SURVEY.md section 8d: qkv + out (x2 branches) + GEGLU feed-forward, d = 512
+EMBED_HEAD_FLOPS_PER_TOKEN = 0.97e6
+
+
+def call_flops(parts, layers, flow_steps):
+    """Algorithmic FLOPs of one sampling call."""
+    tp = sum(sum(sizes) for sizes in parts)
+    fp, fs = attention_flops_per_forward(parts)
+    return flow_steps * (layers * (tp * DENSE_FLOPS_PER_TOKEN_LAYER + fp + fs) + tp * EMBED_HEAD_FLOPS_PER_TOKEN)
+
+
+def cpu_baseline(cfg, sd, args, gpu_first_step, full=False):
+    """The reference on the host cores of THIS box in THIS run: 1 pair of the workload's geometry.
+    With /root/reference mounted: the unmodified reference modules (kind "reference"); otherwise the pinned restatement (kind
+    "port").  Bounded sample: the first 1 and the first 3 flow steps -> per-step slope + fixed cost -> 20-step figure; --cpu-full
+    times all steps.  Needs no GPU (tests/test_host_logic.py runs it on a tiny configuration)."""
     from oracle import rap_oracle as O
+    from oracle import ref_loader
     from rap_amd import synthetic as S
     # one process, 16 threads: the fastest setting on the 256-core GPU box (scripts/cpu_thread_sweep.py: 8/16/32/64/128/256
     # threads -> 3.5/2.7/3.0/3.4/5.1/35 s); more threads only add synchronisation overhead at these matrix sizes.
-    torch.set_num_threads(min(CPU_BASELINE_THREADS, os.cpu_count() or 1))
+    nproc = os.cpu_count() or 1
+    torch.set_num_threads(min(CPU_BASELINE_THREADS, nproc))
     inp = S.make_uniform_inputs(1, args.views, args.points, seed=1234)   # == pair 0 of rank 0's batch
-    t0 = time.perf_counter()
-    ref = O.sample(sd, cfg, inp, args.flow_steps, bool(args.rigidity), max_steps=1)
-    dt = time.perf_counter() - t0
     pts = args.views * args.points
-    out = {"value": pts / (dt * args.flow_steps), "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"1 pair ({args.views}x{args.points} pts), 1 of {args.flow_steps} flow steps incl. rigidity projection "
-                     f"and pose fit: {dt:.1f} s; linearly extrapolated to {args.flow_steps} steps",
-           "seconds_measured": dt}
-    # SE(3) / end-point deviation of the GPU path vs the CPU oracle on that same pair and step
-    x0_gpu, R_gpu, t_gpu = gpu_first_step
-    err = {"x0_max_abs": float((x0_gpu - ref["end_point_trajectory"][0]).abs().max()),
-           "rot_err_deg_max": float(O.rotation_error_deg(R_gpu, ref["R"][0]).max()),
-           "R_frob_max": float(torch.linalg.matrix_norm(R_gpu - ref["R"][0]).max()),
-           "trans_abs_max": float((t_gpu - ref["t"][0]).abs().max())}
+    S_ = args.flow_steps
+    live = ref_loader.reference_available()
+    rigid = bool(args.rigidity)
+    x_t0 = None           # x_t after flow step 0 (what both kinds can hand back)
+    ref_first = None
+    if live:
+        k = S_ if full else min(3, S_)
+        r = ref_loader.reference_time_steps(cfg, sd, inp, S_, rigid, max_steps=None if full else k)
+        st = r["step_start"]
+        t1 = st[1] - st[0]
+        tk = st[k] - st[0] if len(st) > k else st[-1] - st[0]
+        x_t0 = r["x_t_after_step"][0] if r["x_t_after_step"] else None
+        if r["result"] is not None:
+            ref_first = r["result"]
+    else:
+        k = S_ if full else min(3, S_)
+        t0 = time.perf_counter()
+        ref1 = O.sample(sd, cfg, inp, S_, rigid, max_steps=1)
+        t1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        refk = O.sample(sd, cfg, inp, S_, rigid, max_steps=k) if k > 1 else ref1
+        tk = time.perf_counter() - t0 if k > 1 else t1
+        x_t0 = ref1["trajectory"][0]
+        ref_first = ref1
+    if full:
+        total, how = tk, f"all {S_} flow steps timed"
+        slope = (tk - t1) / max(1, k - 1)
+    elif k > 1:
+        slope = (tk - t1) / (k - 1)                 # seconds per additional flow step
+        fixed = max(0.0, t1 - slope)                # model build / first-touch cost inside the first step
+        total = fixed + slope * S_
+        how = f"first 1 step {t1:.1f} s and first {k} steps {tk:.1f} s -> {slope:.2f} s per step + {fixed:.2f} s fixed, extrapolated to {S_} steps"
+    else:
+        slope, total, how = t1, t1 * S_, f"1 of {S_} steps, extrapolated linearly"
+    out = {"value": pts / total, "unit": "points/s", "cores": torch.get_num_threads(), "nproc": nproc,
+           "kind": "reference" if live else "port",
+           "implementation": ("unmodified reference modules under /root/reference (oracle/ref_loader.py; flash-attn / diffusers stand-ins)"
+                              if live else "oracle/rap_oracle.py, the restatement pinned to the reference (/root/reference is not mounted on this box)"),
+           "sample": f"1 pair ({args.views}x{args.points} pts) incl. per-step rigidity projection{'' if not full else ' and pose fit'}: {how}",
+           "steps_timed": k, "seconds_first_step": t1, "seconds_measured": (t1 + tk) if (not live and k > 1) else tk,
+           "seconds_per_flow_step": slope, "seconds_per_pair_all_steps": total, "extrapolated": not full}
+    err = None
+    if gpu_first_step is not None and x_t0 is not None:
+        x0_gpu, xt_gpu, R_gpu, t_gpu = gpu_first_step
+        err = {"x_t_after_step0_max_abs": float((xt_gpu - x_t0).abs().max())}
+        if ref_first is not None and not live:
+            err.update({"x0_max_abs": float((x0_gpu - ref_first["end_point_trajectory"][0]).abs().max()),
+                        "rot_err_deg_max": float(O.rotation_error_deg(R_gpu, ref_first["R"][0]).max()),
+                        "R_frob_max": float(torch.linalg.matrix_norm(R_gpu - ref_first["R"][0]).max()),
+                        "trans_abs_max": float((t_gpu - ref_first["t"][0]).abs().max())})
     return out, err
+
+
+def device_checker_last_pair(cfg, sd, args, last, inp_cpu, dev):
+    """The LAST pair of the timed batch vs the pinned oracle run on this GPU in fp32 through PyTorch-ROCm (test infrastructure)."""
+    from oracle import rap_oracle as O
+    from rap_amd import synthetic as S
+    b = args.batch - 1
+    one = S.make_inputs([[args.points] * args.views], seed=1234 + b)             # == sample b of rank 0's batch (per-sample seeds)
+    n = args.views * args.points
+    a0 = b * n
+    assert torch.equal(one["pointclouds"], inp_cpu["pointclouds"][a0:a0 + n]) and torch.equal(one["x_1"], inp_cpu["x_1"][a0:a0 + n])
+    ref = O.sample(sd, cfg, one, args.flow_steps, bool(args.rigidity), device=dev)
+    ep = last["end_point_trajectory"][:, a0:a0 + n]; tr = last["trajectory"][:, a0:a0 + n]
+    per_step = (ep - ref["end_point_trajectory"]).abs().amax(dim=(1, 2))
+    return {"pair": b, "checker": "oracle/rap_oracle.py sample(device=cuda), fp32 torch ops (pinned: tests/test_fullconfig_gpu.py)",
+            "final_cloud_max_abs": float((ep[-1] - ref["end_point_trajectory"][-1]).abs().max()),
+            "final_x_t_max_abs": float((tr[-1] - ref["trajectory"][-1]).abs().max()),
+            "R_frob_max": float(torch.linalg.matrix_norm(last["R"][b:b + 1] - ref["R"]).max()),
+            "t_max_abs": float((last["t"][b:b + 1] - ref["t"]).abs().max()),
+            "per_step_max_abs": {"max": float(per_step.max()), "first": float(per_step[0]), "last": float(per_step[-1])}}
 
 
 def golden_parity(args, last, data):
@@ -176,18 +262,17 @@ def reference_cpu_record():
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) outside torchrun: launch the N ranks ourselves -- the whole command a driver needs.
     Fails hard when the box has fewer than N GPUs instead of quietly timing one."""
-    import socket
     import subprocess
     selftest = os.environ.get("RAP_BENCH_LAUNCHER_SELFTEST") == "1"
     if not selftest:
         n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if n_dev < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} requested but {n_dev} GPU(s) visible; refusing to run fewer ranks than requested")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # rendezvous on 127.0.0.1 with port 0: the c10d store binds a free port itself (a port picked here by bind-and-close could be
+    # taken by another process before torchrun binds it -- ADVICE r03)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", f"--rdzv-id=rapbench{os.getpid()}", "--local-addr=127.0.0.1",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL across processes)
     env.setdefault("OMP_NUM_THREADS", "8")
@@ -263,10 +348,18 @@ def main():
     cfg = dict(S.RAP_12); cfg["num_layers"] = args.layers
     sd = S.make_weights(cfg, 0)
     # rank r owns pairs [r*batch, (r+1)*batch) of the global job; synthetic, seeded per pair
-    inp = S.make_inputs([[args.points] * args.views for _ in range(args.batch)], seed=1234 + rank * args.batch)
-    data = {k: v.to(dev) for k, v in inp.items()}
+    def make_workload(kind):
+        if kind == "ragged":
+            parts = S.ragged_regime_parts(args.ragged_points, seed=4321 + rank)
+            cpu = S.make_inputs(parts, seed=98765 + 1000 * rank)
+        else:
+            parts = [[args.points] * args.views for _ in range(args.batch)]
+            cpu = S.make_inputs(parts, seed=1234 + rank * args.batch)
+        return parts, cpu, {k: v.to(dev) for k, v in cpu.items()}
+
+    parts, inp, data = make_workload(args.workload)
     x_1 = data["x_1"]
-    pts_per_rank = args.batch * args.views * args.points
+    pts_per_rank = int(inp["pointclouds"].shape[0])
     lib = _lib.load()
     tuning = {}
     for kv in args.tuning:
@@ -287,7 +380,7 @@ def main():
             return sd
         return {k: (v * scale if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma") else v) for k, v in sd.items()}
 
-    def run_mode(dtype, steps, warmup, gamma_scale=1.0):
+    def run_mode(dtype, steps, warmup, gamma_scale=1.0, data=data, x_1=x_1):
         """W untimed + K timed sample calls with the transformer blocks in `dtype`; returns (elapsed, prof, last, flow)."""
         model = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
                                       num_heads=cfg["num_heads"], local_feat_dim=cfg["local_feat_dim"],
@@ -332,6 +425,7 @@ def main():
             gathered, last = one_step()
             enqueue += time.perf_counter() - te      # host time to ENQUEUE one sample call (nothing in it synchronises)
         torch.cuda.synchronize()
+        flow.check_pending()                          # deferred input validation: surface it here, outside the enqueue path
         local_elapsed = time.perf_counter() - t0          # this rank's own time, before the closing barrier
         barrier()
         elapsed = time.perf_counter() - t0
@@ -363,12 +457,13 @@ def main():
             elapsed = float(tmax.item())
         return elapsed, (list(prof_ms), list(prof_n)), last
 
-    def roofline_of(dtype, prof, elapsed, bounded=True):
+    def roofline_of(dtype, prof, elapsed, bounded=True, parts=parts):
         prof_ms, prof_n = prof
         if not (profile and prof_n[0] > 0 and prof_n[1] > 0):
             return None
         peak = PEAK_FP32_MATRIX_TFLOPS if dtype == "float32" else PEAK_16BIT_MATRIX_TFLOPS
-        f_part, f_samp = attention_flops_per_forward(args.batch, args.views, args.points, args.layers)
+        f_part, f_samp = attention_flops_per_forward(parts)
+        tokens = sum(sum(x) for x in parts)
         n_launch = int(prof_n[0] + prof_n[1])
         flops = f_part * int(prof_n[0]) + f_samp * int(prof_n[1])
         secs = (prof_ms[0] + prof_ms[1]) * 1e-3
@@ -376,20 +471,25 @@ def main():
         elem = 4 if dtype == "float32" else 2
         symbol = SHIPPED_ATTENTION_SYMBOL[(dtype, bool(bounded))]
         traffic, source = pmc_traffic(dtype, symbol)
+        if tokens != 32 * 2 * 4096 or any(len(x) != 2 or x[0] != 4096 or x[1] != 4096 for x in parts):
+            traffic, source = None, "the committed PMC passes measured the uniform configs[1] shape only"
         return {
             "kernel": "attention_f32_kernel" if dtype == "float32" else "attention_h16_kernel", "kernel_symbol": symbol,
             "softmax": "bounded, offset-free (every logit bound <= 40)" if bounded and dtype != "float16" else "online (running maximum)",
             "bound": "mfma",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": source,
-            "algorithmic_bytes_per_launch": 4 * elem * args.batch * args.views * args.points * 512,
+            # rocprofv3 --pmc cannot run inside this process: the figure is a committed constant of the builder's separate PMC passes
+            # for exactly this kernel symbol at the uniform configs[1] shape (profiles/pmc_traffic.json), not a measurement of this run
+            "traffic_measured_in_this_run": False,
+            "algorithmic_bytes_per_launch": 4 * elem * tokens * 512,
             "launches": n_launch, "avg_launch_ms": 1e3 * secs / n_launch, "flops_per_launch_avg": flops / n_launch,
             "per_part": {"launches": int(prof_n[0]), "avg_ms": prof_ms[0] / max(1, prof_n[0]),
                          "tflops": f_part * int(prof_n[0]) / (prof_ms[0] * 1e-3) / 1e12},
             "per_sample": {"launches": int(prof_n[1]), "avg_ms": prof_ms[1] / max(1, prof_n[1]),
                            "tflops": f_samp * int(prof_n[1]) / (prof_ms[1] * 1e-3) / 1e12},
             "gemm": {"launches": int(prof_n[2]), "total_ms": float(prof_ms[2]),
-                     "tflops": (args.batch * args.views * args.points * 10.486e6 * (int(prof_n[2]) / 6))
+                     "tflops": (tokens * DENSE_FLOPS_PER_TOKEN_LAYER * (int(prof_n[2]) / 6))
                                / (prof_ms[2] * 1e-3) / 1e12 if prof_n[2] else None},
             "fraction_of_step_time": {"attention": secs / elapsed, "gemm": prof_ms[2] * 1e-3 / elapsed},
             "measured_over": "the K timed steps" if run_mode.streams == 1 else
@@ -422,10 +522,33 @@ def main():
             "deviation_from_fp32_path": {"final_cloud_max_abs": float((a - b).abs().max()),
                                          "R_frob_max": float(torch.linalg.matrix_norm(l2["R"] - last["R"]).max()),
                                          "t_max_abs": float((l2["t"] - last["t"]).abs().max())}}
-        gp2 = golden_parity(args, l2, data)
+        gp2 = golden_parity(args, l2, data) if args.workload == "uniform" else None
         if gp2:
             secondary["deviation_from_reference_golden"] = {k: gp2[k] for k in ("final_cloud_max_abs", "R_frob_max", "t_max_abs")}
         del l2
+
+    # ---- the RAGGED reference-regime batch through the same path: fp32 (1 warm-up + 1 timed call) and bf16
+    ragged = None
+    uniform_call_flops = call_flops(parts, args.layers, args.flow_steps)
+    if args.workload == "uniform" and not args.no_ragged and world == 1:
+        rparts, rinp, rdata = make_workload("ragged")
+        rflops = call_flops(rparts, args.layers, args.flow_steps)
+        rpts = int(rinp["pointclouds"].shape[0])
+        ragged = {"workload": f"{len(rparts)} samples with 2 / 8 / 64 parts in turn, parts of 200 ... 20 000 points "
+                              f"(rap_amd.synthetic.ragged_regime_parts, seed 4321): {rpts} points (not a multiple of 256), "
+                              f"{sum(len(x) for x in rparts)} parts, longest sample {max(sum(x) for x in rparts)} points; "
+                              f"{args.flow_steps} flow steps, rap_{args.layers}, rigidity_forcing={'on' if args.rigidity else 'off'}",
+                  "points": rpts, "samples": len(rparts), "parts": sum(len(x) for x in rparts),
+                  "algorithmic_tflop_per_call": rflops / 1e12, "uniform_algorithmic_tflop_per_call": uniform_call_flops / 1e12}
+        for dt_name, k_steps in ((args.dtype, 1),) + ((("bfloat16", 2),) if args.dtype == "float32" and not args.no_secondary else ()):
+            er, pr, lr = run_mode(dt_name, k_steps, 1, data=rdata, x_1=rdata["x_1"])
+            finite = bool(torch.isfinite(lr["end_point_trajectory"][-1]).all() and torch.isfinite(lr["R"]).all())
+            ragged[DTYPE_TAG[dt_name]] = {
+                "points_per_s": rpts * k_steps / er, "ms_per_step": 1e3 * er / k_steps, "steps": k_steps, "warmup": 1,
+                "achieved_tflops_whole_call": rflops * k_steps / er / 1e12, "results_finite": finite,
+                "roofline": roofline_of(dt_name, pr, run_mode.prof_region_s, parts=rparts)}
+            del lr
+        del rdata
 
     # ---- the online-softmax instantiation of the dominant kernel: same batch, q/k-norm gains x gamma_scale (every bound > 40)
     online = None
@@ -469,8 +592,10 @@ def main():
             "metric": "registered points/sec @20 flow steps, 2-view N=4096", "value": value, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_TAG[args.dtype], "data": "synthetic",
-            "config": {"workload": f"{'configs[1]' if args.dtype == 'float32' else 'configs[2] per-GPU shard'}: "
-                                   f"batch={args.batch} pairs/GPU x {args.views} views x {args.points} pts, "
+            "config": {"workload": (f"RAGGED reference-regime batch ({len(parts)} samples, {pts_per_rank} points; NOT BASELINE's configuration): "
+                                    if args.workload == "ragged" else
+                                    f"{'configs[1]' if args.dtype == 'float32' else 'configs[2] per-GPU shard'}: "
+                                    f"batch={args.batch} pairs/GPU x {args.views} views x {args.points} pts, ") +
                                    f"{args.flow_steps} Euler flow steps, rap_{args.layers} (d=512, H=8), "
                                    f"{'fp32 (exact-fp32 MFMA)' if args.dtype == 'float32' else args.dtype + ' MFMA blocks, fp32 accumulate/residual/head'}, "
                                    f"rigidity_forcing={'on' if args.rigidity else 'off'}, final per-view SE(3) fit",
@@ -484,7 +609,8 @@ def main():
         # single call), the GPU's own pace once the queue is full (the driver's 20-step run: the call blocks on queue slots)
         result["host_call_ms_per_step"] = host_enqueue_ms
         result["rccl_ranks"] = world if distributed else 0        # ranks in the RCCL process group (0: single process, no group)
-        result["pairs_total"] = args.batch * world
+        result["pairs_total"] = len(parts) * world
+        result["achieved_tflops_whole_call"] = uniform_call_flops * world * args.steps / elapsed / 1e12
         result["bounded_attention_launches"] = f"{main_bounded} of {2 * args.layers}"
         if distributed:
             result["per_rank"] = {"elapsed_s": main_rank_elapsed, "all_gather_ms_per_step": main_gather_ms,
@@ -499,21 +625,35 @@ def main():
             result["reduced_precision"] = secondary
         if online:
             result["roofline_online_softmax"] = online
+        if ragged:
+            for tag in ("f32", "bf16"):
+                if tag in ragged:
+                    uni = (result["achieved_tflops_whole_call"] if tag == DTYPE_TAG[args.dtype] else
+                           uniform_call_flops / (secondary["ms_per_step"] * 1e-3) / 1e12 if secondary else None)
+                    ragged[tag]["uniform_achieved_tflops_whole_call"] = uni
+                    ragged[tag]["ragged_over_uniform_at_equal_flops"] = ragged[tag]["achieved_tflops_whole_call"] / uni if uni else None
+            result["ragged"] = ragged
         if world == 1 and not args.no_cpu_baseline:
-            n0 = args.views * args.points
-            x0_first = last["end_point_trajectory"][0][:n0]
-            ppp0 = data["points_per_part"][:1]
-            R0, t0_ = rap_amd.fit_transformations(data["pointclouds"][:n0], x0_first, ppp0, data["cu_seqlens"][:2])
-            base, err = cpu_baseline(cfg, sd, args, (x0_first.cpu(), R0.cpu()[0], t0_.cpu()[0]))
+            gpu_first = None
+            if args.workload == "uniform":
+                n0 = args.views * args.points
+                x0_first = last["end_point_trajectory"][0][:n0]
+                ppp0 = data["points_per_part"][:1]
+                R0, t0_ = rap_amd.fit_transformations(data["pointclouds"][:n0], x0_first, ppp0, data["cu_seqlens"][:2])
+                gpu_first = (x0_first.cpu(), last["trajectory"][0][:n0].cpu(), R0.cpu()[0], t0_.cpu()[0])
+            base, err = cpu_baseline(cfg, sd, args, gpu_first, full=args.cpu_full)
             rec = reference_cpu_record()
             if rec:
-                base["live_reference_all_steps"] = rec
+                base["live_reference_all_steps_build_container"] = rec
             result["cpu_baseline"] = base
-            result["se3_vs_cpu_oracle"] = err
-            base["gpu_over_cpu_port_extrapolated"] = value / base["value"]     # context only (port, 1 of 20 steps, extrapolated): never a headline
-        gp = golden_parity(args, last, data) if args.dtype == "float32" else None
+            if err:
+                result["se3_vs_cpu_oracle" if base["kind"] == "port" else "first_step_vs_cpu_reference"] = err
+            base["gpu_over_cpu"] = value / base["value"]     # context only (bounded CPU sample, extrapolated unless --cpu-full): never a headline
+        gp = golden_parity(args, last, data) if (args.dtype == "float32" and args.workload == "uniform") else None
         if gp:
             result["parity_vs_reference_golden"] = gp
+        if args.dtype == "float32" and args.workload == "uniform" and world == 1 and not args.no_cpu_baseline:
+            result["parity_vs_device_checker_last_pair"] = device_checker_last_pair(cfg, sd, args, last, inp, dev)
         print(json.dumps(result), file=json_out, flush=True)
     if distributed:
         dist.barrier()

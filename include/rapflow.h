@@ -24,6 +24,11 @@
 extern "C" {
 #endif
 
+/* ABI version of this header.  rap_version() returns the value the LIBRARY was built with; a caller compiled against another
+ * value must not use the library (round 4, version 4: rap_spinnet_describe gained `flags` and three entry points were removed in
+ * round 3 without a bump; the fp16-residual epilogue of rap_gemm_h16 moved from 6 to 7 and 6 is refused; rap_poison_on_flag is new). */
+#define RAPFLOW_ABI_VERSION 4
+
 typedef struct rap_model rap_model;
 
 /* PointCloudDiT hyper-parameters (reference config/model/flow_model/point_cloud_dit_12.yaml,
@@ -249,6 +254,13 @@ int rap_gemm_f32(int32_t epilogue, const float* A, int32_t lda, const float* W, 
                  int32_t M, int32_t N, int32_t K, const float* bias, const float* resid, int32_t ldr,
                  const uint8_t* anchor, const float* anchor_emb, int32_t heads, void* stream);
 int rap_geglu_interleave(const float* W, const float* b, float* Wp, float* bp, int32_t inner, int32_t K, void* stream);
+/* The work list of one attention launch, as rap_sample / rap_dit_forward build it (once per call, on the device): one item
+ * {seg_start, seg_len, q0, 0} (4 x int32) per `block_queries` (256) query rows of every segment of cu_seqlens (nseg + 1 entries),
+ * LONGEST SEGMENT FIRST when sort_ws (nseg ints of scratch) is given -- a block streams all keys of its segment, blocks are
+ * dispatched in order, so the long blocks of a ragged batch (reference: 200 ... 40 000 points per part) must not start last --
+ * segment order when sort_ws is NULL; items beyond the last one are zero (seg_len 0 = no work).  items_out: max_items x 4 int32. */
+int rap_build_attention_worklist(const int32_t* cu_seqlens, int32_t nseg, int32_t block_queries, int32_t* items_out,
+                                 int32_t max_items, int32_t* sort_ws, void* stream);
 /* flash_attn_varlen_qkvpacked_func equivalent (reference layer.py:106-111,123-128) on head-major qkv
  * [3][H][TP][64]; out (TP, H*64).  ws >= rap_attention_workspace_bytes(TP, nseg). */
 size_t rap_attention_workspace_bytes(int64_t TP, int32_t nseg);
@@ -274,19 +286,20 @@ int rap_adaln_table(const rap_model* m, const float* t, int32_t rows, float* scr
 /* ---- reduced-precision kernel-level entry points (dtype 1 = bf16, 2 = fp16; 16-bit tensors as uint16_t*) ---- */
 int rap_convert_h16(int32_t dtype, const float* src, uint16_t* dst, int64_t n, void* stream);
 /* C = A (M,K) W(N,K)^T, fp32 accumulate.  epilogue: 0 C half = acc + bias; 1 C fp32 = (resid +) acc + bias;
- * 6 C fp16 = fp16(resid + acc + bias) with `resid` pointing at an FP16 (M,N) matrix (required; row stride ldr; may alias C): the residual GEMM
- * of the 16-bit residual stream, one rounding of the fp32 sum, fp16 whatever the operand dtype;
+ * 7 C fp16 = fp16(resid + acc + bias) with `resid` pointing at an FP16 (M,N) matrix (required; row stride ldr; may alias C): the residual GEMM
+ * of the 16-bit residual stream, one rounding of the fp32 sum (saturating at +-65504), fp16 whatever the operand dtype
+ * (6 -- this epilogue's number before ABI version 4, and a different epilogue before that -- is refused);
  * 3 GEGLU on value/gate-interleaved W (C half (M,N/2)); 4 qkv split: q,k -> C half [2][H][M][64], v -> vt, the
  * TRANSPOSED image [H][vt_nblk][64 d][64 pos] the attention kernel consumes: token t sits in block t >> 6 at
  * pos = (t & 51) | ((t & 4) << 1) | ((t & 8) >> 1); vt_nblk * 64 >= M rounded up to 256; rows >= M are written as 0. */
 int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, void* C,
                  int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const float* resid, int32_t ldr,
                  int32_t heads, uint16_t* vt, int32_t vt_nblk, void* stream);
-/* Epilogues 1 and 6 of rap_gemm_h16 with the split-K form rap_sample uses for the K = 4d feed-forward GEMM of few-token calls (tuning
+/* Epilogues 1 and 7 of rap_gemm_h16 with the split-K form rap_sample uses for the K = 4d feed-forward GEMM of few-token calls (tuning
  * key 6): when rap_gemm_h16_splitk_workspace_bytes(M, N, K) > 0 (K >= 1024 and at most 128 tiles of 128 x 128), K is split over 2 or 4
  * blocks per tile that write fp32 partial tiles to ws, and a combine pass forms resid + (bias + sum of partials) in a fixed order
  * (deterministic; equals the unsplit result up to the fp32 association of the k-sum).  resid: fp32 (epilogue 1, may be NULL) or fp16
- * (epilogue 6, required) (M,N) matrix with row stride ldr, may alias C.  With a workspace size of 0 the call is rap_gemm_h16. */
+ * (epilogue 7, required) (M,N) matrix with row stride ldr, may alias C.  With a workspace size of 0 the call is rap_gemm_h16. */
 size_t rap_gemm_h16_splitk_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int rap_gemm_h16_splitk(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, void* C,
                         int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const void* resid, int32_t ldr, void* ws,
@@ -353,6 +366,11 @@ int rap_statistical_outliers(const float* points, int64_t N, int32_t nb_neighbor
  * != TP, bit 1 cu_seqlens ends, bit 2 cu_seqlens decreasing, bit 3 a sample's parts vs its span, bit 4 a negative size. */
 int rap_check_batch(const int64_t* points_per_part, const int32_t* cu_batch, int32_t B, int32_t P, int64_t TP, int32_t* flag_out,
                     void* stream);
+/* The deferred form of that check (no host read-back on the call path): enqueue rap_check_batch, the sampling call, then
+ * rap_poison_on_flag on every result buffer -- if *flag (device int32, as rap_check_batch wrote it) is non-zero, buf[0..n) is
+ * overwritten with NaN, so results of an inconsistent batch cannot be mistaken for poses.  rap_amd.RectifiedPointFlow does this by
+ * default and raises on the host the first time it can read the flag without stalling the stream. */
+int rap_poison_on_flag(const int32_t* flag, float* buf, int64_t n, void* stream);
 
 /* ---- measurement hooks (bench.py roofline leg) ----
  * When enabled, every attention and layer-GEMM launch inside rap_dit_forward / rap_sample is bracketed by two

@@ -459,3 +459,49 @@ def reference_sample(cfg, state_dict, inputs, num_steps, rigidity_forcing, dtype
     res, R, t = run()
     return {"end_point_trajectory": res["end_point_trajectory"], "trajectory": res["trajectory"], "R": R, "t": t,
             "transformer_features": captured["features"], "features_timestep": captured["t"]}
+
+
+class _StopAfter(Exception):
+    pass
+
+
+def reference_time_steps(cfg, state_dict, inputs, num_steps, rigidity_forcing, max_steps=None, dtype=torch.float32):
+    """bench.py's CPU-baseline leg when the mount is present: the reference's UNMODIFIED sampler loop (sampler.py:11-74) around its
+    own PointCloudDiT and procrustes, with the wall-clock time taken at the start of every flow step (= every call of the model
+    closure).  ``max_steps``: the closure raises a private exception when step ``max_steps`` is about to start, which ends the
+    reference's loop from outside -- nothing in the reference is edited, and the steps that did run are its own.
+    Returns {"step_start": [t_0 .. t_k], "x_t_after_step": [x_t after step 0 .. k-1] (the inputs of the following model calls),
+    "result": the full result dict when the loop ran to the end, else None}."""
+    import time
+    ns = load_reference()
+    model = build_reference_dit(cfg, state_dict, dtype)
+    cond = inputs["pointclouds"].to(dtype); feats = inputs["features"].to(dtype); scales = inputs["scales"].to(dtype)
+    anchor = inputs["anchor_indices"]; ppp = inputs["points_per_part"]; x_1 = inputs["x_1"].to(dtype)
+    cu_part = F.pad(torch.cumsum(ppp[ppp > 0], 0), (1, 0)).to(torch.int32)
+    cu_batch = inputs["cu_seqlens"].to(torch.int32)
+    B = cu_batch.shape[0] - 1
+    starts, xts = [], []
+
+    @torch.inference_mode()
+    def run():
+        def fn(x, t):
+            starts.append(time.perf_counter())
+            if len(starts) > 1:
+                xts.append(x.clone())
+            if max_steps is not None and len(starts) > max_steps:
+                raise _StopAfter()
+            ts = torch.full((B,), t, dtype=dtype)
+            return model(x=x, timesteps=ts, cond_coord=cond, local_features=feats, latent_features=None, scales=scales,
+                         anchor_indices=anchor, cu_seqlens_batch=cu_batch, cu_seqlens_part=cu_part)
+        try:
+            res = ns.get_sampler("euler")(flow_model_fn=fn, x_1=x_1, x_0=cond, condition=cond, points_per_part=ppp,
+                                          cu_seqlens_batch=cu_batch, anchor_indices=anchor, num_steps=num_steps,
+                                          return_trajectory=True, rigidity_forcing=rigidity_forcing)
+        except _StopAfter:
+            return None
+        R, t = ns.fit_transformations(cond, res["end_point_trajectory"][-1], ppp, cu_batch)
+        starts.append(time.perf_counter())
+        return {"end_point_trajectory": res["end_point_trajectory"], "trajectory": res["trajectory"], "R": R, "t": t}
+    result = run()
+    return {"step_start": starts, "x_t_after_step": xts, "result": result}
+

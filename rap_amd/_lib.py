@@ -13,6 +13,8 @@ from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librapflow.so")
 
+ABI_VERSION = 4        # RAPFLOW_ABI_VERSION of include/rapflow.h this binding was written against
+EPI_H_BIAS_RESID_H16 = 7   # rap_gemm_h16's fp16-residual epilogue (6 before ABI version 4; 6 is refused now)
 DTYPES = {"float32": 0, "fp32": 0, "bfloat16": 1, "bf16": 1, "float16": 2, "fp16": 2}
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP runtime error", -4: "allocation failure"}
@@ -76,12 +78,14 @@ SIGNATURES = {
     "rap_outlier_workspace_bytes": (c_size_t, [c_int64]),
     "rap_statistical_outliers": (c_int32, [_P, c_int64, c_int32, ctypes.c_double, _P, _P, _P, _P, c_size_t, _P]),
     "rap_check_batch": (c_int32, [_P, _P, c_int32, c_int32, c_int64, _P, _P]),
+    "rap_poison_on_flag": (c_int32, [_P, _P, c_int64, _P]),
     "rap_collate_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "rap_collate_transform": (c_int32, [_P, c_int32, _P, c_int32, c_int32, c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                         _P, _P, _P, c_size_t, _P]),
     "rap_gemm_f32": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32,
                                _P, _P, c_int32, _P]),
     "rap_geglu_interleave": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P]),
+    "rap_build_attention_worklist": (c_int32, [_P, c_int32, c_int32, _P, c_int32, _P, _P]),
     "rap_attention_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "rap_attention_f32": (c_int32, [_P, _P, c_int32, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "rap_layernorm_mod": (c_int32, [_P, _P, c_int64, c_int32, _P, c_int64, _P, _P]),
@@ -124,6 +128,9 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.rap_version() != ABI_VERSION:
+        raise RapError(f"{LIB_PATH} has ABI version {lib.rap_version()}, this binding expects {ABI_VERSION}: rebuild it "
+                       "(python -m rap_amd._build --force)")
     _lib = lib
     return lib
 

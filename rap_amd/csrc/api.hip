@@ -5,6 +5,7 @@
 #include "half.h"
 #include "kernels.h"
 
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -109,6 +110,10 @@ struct rap_model {
   const float *adaW1, *adab1, *adaW2, *adab2, *adaW3, *adab3;  // stacked over j = 2*layer + {0 self, 1 global}
   std::vector<LayerW> layers;
   const float *hW0, *hb0, *hW2, *hb2, *hW4;
+  // Configuration (compute / residual dtype) is read on the HOST while a call is being enqueued (workspace layout, kernel choice):
+  // the setters and the enqueueing entry points take this mutex, so a setter on one thread cannot change the layout of a call another
+  // thread is in the middle of enqueueing.  Work that is already enqueued is not affected by a later change.
+  mutable std::mutex cfg_mu;
 };
 
 static bool desc_ok(const rap_model_desc* d) {
@@ -153,7 +158,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   return RAP_ERR_INVALID;
 }
 
-extern "C" int rap_version(void) { return 1; }
+extern "C" int rap_version(void) { return RAPFLOW_ABI_VERSION; }
 extern "C" int rap_last_hip_error(void) { return g_last_hip_error; }
 
 extern "C" int64_t rap_weight_count(const rap_model_desc* desc) {
@@ -294,6 +299,7 @@ static int ensure_logit_bounds(rap_model* m, hipStream_t stream) {
 
 extern "C" int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* stream_) {
   if (!m) return RAP_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(m->cfg_mu);
   if (dtype == RAP_DT_F32) { m->dtype = dtype; return RAP_OK; }
   if (dtype != RAP_DT_BF16 && dtype != RAP_DT_F16) return RAP_ERR_INVALID;
   HalfWeights& hw = m->half[dtype];
@@ -331,6 +337,7 @@ extern "C" int rap_model_compute_dtype(const rap_model* m) { return m ? m->dtype
 // are 16-bit under Lightning "16-mixed", layer.py:155-164 adds them).  Ignored while the compute dtype is fp32.
 extern "C" int rap_model_set_residual_dtype(rap_model* m, int32_t dtype) {
   if (!m || (dtype != RAP_DT_F32 && dtype != RAP_DT_F16)) return RAP_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(m->cfg_mu);
   m->resid_dtype = dtype;
   return RAP_OK;
 }
@@ -347,8 +354,9 @@ struct Workspace {
   u16 *xnh, *qkh, *vth, *atth, *ffmidh; // reduced-precision mode: 16-bit activations (xn/qkv/att/ffmid are then unused)
   float* splitk_h;                      // reduced-precision mode, few-token calls only: fp32 partial planes of the split-K ff2 GEMM (else null)
   int vt_nblk;
+  int rows;                             // TQ = align_up(TP, 256): rows of every token-row buffer
   double* proc_partials;
-  int32_t *token_sample, *part_offsets;
+  int32_t *token_sample, *part_offsets, *attn_sort;
   AttnWorkItem *items_batch, *items_part;
   int max_items_batch, max_items_part;
   size_t total;
@@ -359,7 +367,12 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   const size_t d = m->d, L = m->L;
   size_t off = 0;
   auto take = [&](size_t bytes) { char* r = basep ? basep + off : nullptr; off += align_up(bytes, 256); return r; };
-  const size_t T = (size_t)TP;
+  // Every token-row buffer is carved at TQ = align_up(TP, 256) rows (round 4): the layer kernels run over TQ rows, so the persistent
+  // 256-row-tile GEMMs serve ANY token count (ragged batches are the reference's real regime, RAP_inference.yaml:30-36); rows
+  // TP .. TQ-1 are finite filler nobody reads (rows are independent in every kernel but attention, whose work lists and key
+  // ranges stop at the true segment ends).  See forward_step.
+  const size_t T = align_up((size_t)TP, 256);
+  w.rows = (int)T;
   w.base = (float*)take(T * d * 4);
   const bool h16 = m->dtype != RAP_DT_F32 && m->resid_dtype == RAP_DT_F16;
   w.h = h16 ? nullptr : (float*)take(T * d * 4);
@@ -375,7 +388,7 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
     w.ffmid = (float*)take(T * 4 * d * 4);     // also the static feature matrix (TP,128) during prepare
     w.hid1 = w.xn; w.hid2 = w.att; w.astatic = w.ffmid;
   } else {
-    w.vt_nblk = (int)(align_up(T, 256) / 64);  // V^T image: whole 64-token blocks, padded to the largest GEMM M tile
+    w.vt_nblk = (int)(T / 64);                 // V^T image: whole 64-token blocks over the padded rows
     w.xnh = (u16*)take(T * d * 2);
     w.qkh = (u16*)take(T * 2 * d * 2);         // q,k [2][H][T][64]
     w.vth = (u16*)take((size_t)w.vt_nblk * 64 * d * 2);   // [H][vt_nblk][64][64]
@@ -384,7 +397,9 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
     w.hid1 = (float*)w.ffmidh;                 // (T,d) fp32   = 4*T*d bytes
     w.hid2 = w.hid1 + T * d;                   // (T,d/2) fp32 = 2*T*d bytes
     w.astatic = (float*)w.ffmidh;
-    const int splits = gemm_h16_splits((int)TP, (int)d, (int)(4 * d));      // ff2: the one layer GEMM with K >= 1024
+    // ff2: the one layer GEMM with K >= 1024.  Reserved by SHAPE alone (tuning key 6 only gates the launch), so that the size
+    // rap_workspace_bytes reports cannot change between the query and the call
+    const int splits = gemm_h16_splits_by_shape((int)T, (int)d, (int)(4 * d));
     if (splits > 1) w.splitk_h = (float*)take((size_t)splits * T * d * 4);
   }
   w.ax = (float*)take(T * 64 * 4);
@@ -399,6 +414,7 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   w.max_items_part = (int)(TP / RAP_ATTN_BQ) + nseg_part + 1;
   w.items_batch = (AttnWorkItem*)take((size_t)w.max_items_batch * sizeof(AttnWorkItem));
   w.items_part = (AttnWorkItem*)take((size_t)w.max_items_part * sizeof(AttnWorkItem));
+  w.attn_sort = (int32_t*)take(((size_t)(nseg_part > B ? nseg_part : B) + 1) * 4);   // scratch of the longest-first work-list order
   w.proc_partials = (double*)take((size_t)nseg_part * RAP_PROC_CHUNKS * 16 * 8);
   w.Rc = (float*)take((size_t)nseg_part * 9 * 4);
   w.tc = (float*)take((size_t)nseg_part * 3 * 4);
@@ -408,20 +424,41 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
 
 extern "C" size_t rap_workspace_bytes(const rap_model* m, int64_t TP, int32_t B, int32_t nseg_part, int32_t rows) {
   if (!m || TP < 0 || B < 0 || nseg_part < 0 || rows < 0) return 0;
+  std::lock_guard<std::mutex> lock(m->cfg_mu);
   return carve_workspace(m, TP, B, nseg_part, rows, nullptr).total;
 }
 
 // ---------------------------------------------------------------------------------------------
 // prepare (step-invariant work) and one forward
 // ---------------------------------------------------------------------------------------------
+static int zero_rows(hipStream_t stream, void* base, size_t row_bytes, int row0, int row1) {
+  if (row1 <= row0) return RAP_OK;
+  if (hipMemsetAsync((char*)base + (size_t)row0 * row_bytes, 0, (size_t)(row1 - row0) * row_bytes, stream) != hipSuccess) {
+    rap_set_last_hip_error((int)hipGetLastError());
+    return RAP_ERR_HIP;
+  }
+  return RAP_OK;
+}
+
 static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t stream, const float* cond, const float* feat,
                           const float* scales, const uint8_t* anchor, const int32_t* cu_batch, const int32_t* cu_part,
                           int B, int nseg_part, int TP) {
   int rc;
   if ((rc = launch_token_sample(stream, cu_batch, B, w.token_sample))) return rc;
   const int bq = m->dtype == RAP_DT_F32 ? 0 : attention_h16_block_queries(m->dtype);
-  if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch, bq))) return rc;
-  if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part, bq))) return rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch, bq, w.attn_sort))) return rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part, bq, w.attn_sort))) return rc;
+  // Filler rows TP .. TQ-1 (TQ = align_up(TP, 256), see carve_workspace): every value a layer kernel reads there has to be FINITE,
+  // because the 16-bit attention's V^T image is blocked by 64 tokens and a masked key still multiplies its V column by p = 0
+  // (0 x NaN = NaN).  Zero the filler rows of the four buffers no kernel writes beyond row TP -- the step-invariant embedding
+  // part, PE(x_t), the attention output, the sample index of a token -- once per call; everything else in rows TP .. TQ-1 is then
+  // computed from those by row-independent kernels (LayerNorm, GEMMs) and stays finite.
+  const int TQ = w.rows, d = m->d;
+  if ((rc = zero_rows(stream, w.base, (size_t)d * 4, TP, TQ))) return rc;
+  if ((rc = zero_rows(stream, w.ax, 64 * 4, TP, TQ))) return rc;
+  if ((rc = zero_rows(stream, w.token_sample, 4, TP, TQ))) return rc;
+  if (m->dtype == RAP_DT_F32) { if ((rc = zero_rows(stream, w.att, (size_t)d * 4, TP, TQ))) return rc; }
+  else if ((rc = zero_rows(stream, w.atth, (size_t)d * 2, TP, TQ))) return rc;
   // base = [PE63(cond) | PE21(scale) | feat | 0] Wstatic^T + emb bias + anchor embedding   (embedding.py:155-179,
   // point_cloud_dit.py:119-139) -- everything in the embedding that does not depend on x_t.
   float* astatic = w.astatic;
@@ -434,18 +471,22 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
 
 // mod: (scale|shift) rows for this forward: row r at mod + r*mod_stride, LN j at + j*2d.
 static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stream, const float* x_t, const float* mod,
-                        long mod_stride, const int32_t* token_row, int TP, float* v_out, float* feats_out) {
+                        long mod_stride, const int32_t* token_row, int TP_valid, float* v_out, float* feats_out) {
   const int d = m->d, H = m->H;
   int rc;
   // embed = PE63(x_t) Wx^T + base
-  if ((rc = launch_posenc_x(stream, x_t, w.ax, TP))) return rc;
+  if ((rc = launch_posenc_x(stream, x_t, w.ax, TP_valid))) return rc;
+  // From here to the head every kernel runs over TQ = align_up(TP, 256) rows of the workspace (filler rows: prepare_static):
+  // the GEMMs see M % 256 == 0 whatever the batch, i.e. the persistent 256 x 256 kernels; the attention launches take TQ as the
+  // row count of the head-major planes and their work lists (true segment ends) for everything else.
+  const int TP = w.rows;
   {
     GemmParams g{};
     // 16-bit residual stream: the fp32 embedding lands in the (idle) FFN buffer and is rounded to fp16 once
     g.A = w.ax; g.lda = 64; g.W = m->Wx; g.ldw = 64; g.C = w.h16 ? w.hid1 : w.h; g.ldc = d; g.M = TP; g.N = d; g.K = 64;
     g.resid = w.base; g.ldr = d;
     if ((rc = launch_gemm_f32(stream, EPI_BIAS_RESID, g))) return rc;
-    if (w.h16 && (rc = launch_convert_h16(stream, RAP_DT_F16, w.hid1, w.h16, (size_t)TP * d))) return rc;
+    if (w.h16 && (rc = launch_convert_f16_sat(stream, w.hid1, w.h16, (size_t)TP * d))) return rc;
   }
   const int dt = m->dtype;
   const void* hres = w.h16 ? (const void*)w.h16 : (const void*)w.h;      // the residual stream as the 16-bit LayerNorms read it
@@ -551,25 +592,27 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
   // 16-bit residual stream: the fp32 head (and the caller's transformer_features) read an fp32 image of it -- written into the
   // caller's feature buffer when there is one, else into the q / k planes (T x 2d 16-bit values = T x d floats, dead after the last attention)
   const float* h_final = w.h;
+  int head_rows = TP;                       // the head's first GEMM reads TQ rows of a workspace buffer, TP_valid rows of a caller's
   if (w.h16) {
     float* img = feats_out ? feats_out : reinterpret_cast<float*>(w.qkh);
-    if ((rc = launch_convert_f16_to_f32(stream, w.h16, img, (size_t)TP * d))) return rc;
+    if (feats_out) head_rows = TP_valid;
+    if ((rc = launch_convert_f16_to_f32(stream, w.h16, img, (size_t)head_rows * d))) return rc;
     h_final = img;
   } else if (feats_out) {
-    if (hipMemcpyAsync(feats_out, w.h, (size_t)TP * d * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+    if (hipMemcpyAsync(feats_out, w.h, (size_t)TP_valid * d * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) {
       rap_set_last_hip_error((int)hipGetLastError());
       return RAP_ERR_HIP;
     }
   }
   // final_mlp (point_cloud_dit.py:111-117): Lin+SiLU, Lin+SiLU, Lin(no bias)
   GemmParams h0{};
-  h0.A = h_final; h0.lda = d; h0.W = m->hW0; h0.ldw = d; h0.C = w.hid1; h0.ldc = d; h0.M = TP; h0.N = d; h0.K = d; h0.bias = m->hb0;
+  h0.A = h_final; h0.lda = d; h0.W = m->hW0; h0.ldw = d; h0.C = w.hid1; h0.ldc = d; h0.M = head_rows; h0.N = d; h0.K = d; h0.bias = m->hb0;
   if ((rc = launch_gemm_f32(stream, EPI_BIAS_SILU, h0))) return rc;
   GemmParams h2{};
-  h2.A = w.hid1; h2.lda = d; h2.W = m->hW2; h2.ldw = d; h2.C = w.hid2; h2.ldc = d / 2; h2.M = TP; h2.N = d / 2; h2.K = d;
+  h2.A = w.hid1; h2.lda = d; h2.W = m->hW2; h2.ldw = d; h2.C = w.hid2; h2.ldc = d / 2; h2.M = head_rows; h2.N = d / 2; h2.K = d;
   h2.bias = m->hb2;
   if ((rc = launch_gemm_f32(stream, EPI_BIAS_SILU, h2))) return rc;
-  return launch_head_out3(stream, w.hid2, d / 2, m->hW4, v_out, TP, d / 2);
+  return launch_head_out3(stream, w.hid2, d / 2, m->hW4, v_out, TP_valid, d / 2);
 }
 
 extern "C" int rap_dit_forward(const rap_model* m, const float* x_t, const float* timesteps, const float* cond,
@@ -581,6 +624,7 @@ extern "C" int rap_dit_forward(const rap_model* m, const float* x_t, const float
   if (B <= 0 || VP < 0 || TP < 0 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
   if (TP == 0) return RAP_OK;
   if (!ws) return RAP_ERR_WORKSPACE;
+  std::lock_guard<std::mutex> lock(m->cfg_mu);
   Workspace w = carve_workspace(m, TP, B, VP, B, (char*)ws);
   if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
@@ -678,6 +722,7 @@ extern "C" int rap_sample(const rap_model* m, const float* cond, const float* fe
   if (B <= 0 || P <= 0 || TP <= 0 || num_steps <= 0 || TP > 0x7fffffffLL / 8 || (int64_t)B * P > 65535) return RAP_ERR_INVALID;
   const int np = B * P;
   if (!ws) return RAP_ERR_WORKSPACE;
+  std::lock_guard<std::mutex> lock(m->cfg_mu);
   Workspace w = carve_workspace(m, TP, B, np, num_steps, (char*)ws);
   if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
@@ -738,6 +783,15 @@ extern "C" int rap_geglu_interleave(const float* W, const float* b, float* Wp, f
 
 extern "C" size_t rap_attention_workspace_bytes(int64_t TP, int32_t nseg) {
   return ((size_t)(TP / RAP_ATTN_BQ) + (size_t)nseg + 1) * sizeof(AttnWorkItem);
+}
+
+// the work list of one attention launch as rap_sample / rap_dit_forward build it: one {seg_start, seg_len, q0, 0} item per
+// `block_queries` query rows of every segment, longest segment first when sort_ws (nseg ints) is given, zero items after the last
+extern "C" int rap_build_attention_worklist(const int32_t* cu_seqlens, int32_t nseg, int32_t block_queries, int32_t* items_out,
+                                            int32_t max_items, int32_t* sort_ws, void* stream) {
+  if (!cu_seqlens || !items_out || nseg < 0 || max_items < 0 || block_queries <= 0) return RAP_ERR_INVALID;
+  return launch_build_attn_worklist((hipStream_t)stream, cu_seqlens, nseg, reinterpret_cast<AttnWorkItem*>(items_out), max_items,
+                                    block_queries, sort_ws);
 }
 
 extern "C" int rap_attention_f32(const float* qkv_headmajor, const int32_t* cu_seqlens, int32_t nseg, float* out,
@@ -803,7 +857,7 @@ extern "C" int rap_gemm_h16(int32_t dtype, int32_t epilogue, const uint16_t* A, 
 }
 // the residual epilogues (1, 6) with an optional split-K workspace (what rap_sample hands ff2 on few-token calls)
 extern "C" size_t rap_gemm_h16_splitk_workspace_bytes(int32_t M, int32_t N, int32_t K) {
-  const int s = gemm_h16_splits(M, N, K);
+  const int s = gemm_h16_splits_by_shape(M, N, K);
   return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 extern "C" int rap_gemm_h16_splitk(int32_t dtype, int32_t epilogue, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, void* C,
@@ -1274,6 +1328,11 @@ extern "C" int rap_check_batch(const int64_t* points_per_part, const int32_t* cu
                                int32_t* flag_out, void* stream) {
   if (!points_per_part || !cu_batch || !flag_out || B <= 0 || P <= 0 || TP < 0) return RAP_ERR_INVALID;
   return launch_check_batch((hipStream_t)stream, points_per_part, cu_batch, B, P, (long)TP, flag_out);
+}
+
+extern "C" int rap_poison_on_flag(const int32_t* flag, float* buf, int64_t n, void* stream) {
+  if (!flag || !buf || n < 0) return RAP_ERR_INVALID;
+  return launch_poison_on_flag((hipStream_t)stream, flag, buf, (long)n);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -327,20 +327,76 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
   }
 }
 
-// One thread walks the segment table (nseg is small: samples or parts of one batch) and emits one
-// work item per 256-query block; unused slots get seg_len = 0.  Runs once per sample() call.
-__global__ void build_attn_worklist_kernel(const int32_t* __restrict__ cu, int nseg, AttnWorkItem* __restrict__ items,
-                                           int max_items, int bq) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int n = 0;
-  for (int s = 0; s < nseg; ++s) {
-    const int a = cu[s], b = cu[s + 1];
-    for (int q0 = 0; q0 < b - a && n < max_items; q0 += bq) {
-      AttnWorkItem w; w.seg_start = a; w.seg_len = b - a; w.q0 = q0; w.pad = 0;
-      items[n++] = w;
+// Work list of one attention launch: one item per 256-query block of every segment, LONGEST SEGMENT FIRST (round 4).  A block's
+// work is proportional to its segment's length (it streams all keys of the segment), and blocks are dispatched in blockIdx order:
+// with the items in segment order the 157 x 8 blocks of a 40 000-point part at the end of a ragged batch start last and the launch
+// drains on them alone; longest-processing-time-first puts the short blocks at the tail (the reference's batches are ragged:
+// 200 ... 40 000 points per part, config/RAP_inference.yaml:30-36).  Items of one segment stay adjacent, so the 8 blocks x
+// consecutive items that share an XCD's L2 still share K / V.  One block of 1024 threads, once per sample() call:
+//   rank[s] = #{j : len_j > len_s or (len_j == len_s and j < s)}  (lengths staged through LDS, O(nseg^2 / 1024) per thread),
+//   order[rank[s]] = s, exclusive scan of the item counts in rank order, then every thread emits the items of its ranks.
+// sort_ws: nseg ints; nullptr = segment order (kernel-level entry points without scratch).
+#define WL_THREADS 1024
+#define WL_TILE 4096
+__global__ __launch_bounds__(WL_THREADS) void build_attn_worklist_kernel(const int32_t* __restrict__ cu, int nseg, AttnWorkItem* __restrict__ items,
+                                                                          int max_items, int bq, int32_t* __restrict__ sort_ws) {
+  if (blockIdx.x != 0) return;
+  const int tid = threadIdx.x;
+  const AttnWorkItem none = {0, 0, 0, 0};
+  if (!sort_ws) {
+    if (tid != 0) return;
+    int n = 0;
+    for (int s = 0; s < nseg; ++s) {
+      const int a = cu[s], b = cu[s + 1];
+      for (int q0 = 0; q0 < b - a && n < max_items; q0 += bq) { const AttnWorkItem w = {a, b - a, q0, 0}; items[n++] = w; }
     }
+    for (; n < max_items; ++n) items[n] = none;
+    return;
   }
-  for (; n < max_items; ++n) { AttnWorkItem w; w.seg_start = 0; w.seg_len = 0; w.q0 = 0; w.pad = 0; items[n] = w; }
+  __shared__ int lens[WL_TILE];
+  __shared__ int partial[WL_THREADS];
+  __shared__ int total_items;
+  int32_t* order = sort_ws;            // [nseg]
+  // ---- ranks
+  for (int s0 = 0; s0 < nseg; s0 += WL_THREADS) {          // segments owned by this thread in this pass: s0 + tid
+    const int s = s0 + tid;
+    const int my = s < nseg ? cu[s + 1] - cu[s] : -1;
+    int rank = 0;
+    for (int j0 = 0; j0 < nseg; j0 += WL_TILE) {
+      __syncthreads();
+      for (int j = tid; j < WL_TILE && j0 + j < nseg; j += WL_THREADS) lens[j] = cu[j0 + j + 1] - cu[j0 + j];
+      __syncthreads();
+      const int nj = nseg - j0 < WL_TILE ? nseg - j0 : WL_TILE;
+      if (s < nseg)
+        for (int j = 0; j < nj; ++j) rank += (lens[j] > my || (lens[j] == my && j0 + j < s)) ? 1 : 0;
+    }
+    if (s < nseg) order[rank] = s;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- exclusive scan of the item counts in rank order: thread t owns ranks [t * per, (t + 1) * per)
+  const int per = (nseg + WL_THREADS - 1) / WL_THREADS;
+  const int r0 = tid * per, r1 = (r0 + per) < nseg ? (r0 + per) : nseg;
+  int sum = 0;
+  for (int r = r0; r < r1; ++r) { const int sg = order[r]; sum += (cu[sg + 1] - cu[sg] + bq - 1) / bq; }
+  partial[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int t = 0; t < WL_THREADS; ++t) { const int v = partial[t]; partial[t] = acc; acc += v; }
+    total_items = acc;
+  }
+  __syncthreads();
+  // ---- emit
+  int n = partial[tid];
+  for (int r = r0; r < r1; ++r) {
+    const int sg = order[r];
+    const int a = cu[sg], len = cu[sg + 1] - a;
+    for (int q0 = 0; q0 < len; q0 += bq, ++n)
+      if (n < max_items) { const AttnWorkItem w = {a, len, q0, 0}; items[n] = w; }
+  }
+  const int total = total_items < max_items ? total_items : max_items;
+  for (int i = total + tid; i < max_items; i += WL_THREADS) items[i] = none;
 }
 
 // One schedule ships: 4 waves x 64 queries per block (136 -> 142 TF at the C1 shapes).  The 8-wave / 512-query form (134 TF) and
@@ -350,10 +406,10 @@ rap_tuning_t g_rap_attn_split = 1;     // tuning key 5: 0 = never split few-toke
 static int attn_block_queries() { return RAP_ATTN_BQ; }
 
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,
-                               int max_items, int block_queries) {
+                               int max_items, int block_queries, int32_t* sort_ws) {
   if (max_items <= 0) return RAP_OK;
-  hipLaunchKernelGGL(build_attn_worklist_kernel, dim3(1), dim3(64), 0, stream, cu_seqlens, nseg, items, max_items,
-                     block_queries > 0 ? block_queries : attn_block_queries());
+  hipLaunchKernelGGL(build_attn_worklist_kernel, dim3(1), dim3(WL_THREADS), 0, stream, cu_seqlens, nseg, items, max_items,
+                     block_queries > 0 ? block_queries : attn_block_queries(), sort_ws);
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }

@@ -155,8 +155,8 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
         const float4 a1 = *reinterpret_cast<const float4*>(sf + row * 68 + col + 4);
         float rv[8];
         h16_unpack8<RAP_DT_F16>(rr[i][it], rv);
-        const typename H16<RAP_DT_F16>::T8 o8 = h16_pack8<RAP_DT_F16>(a0.x + rv[0], a0.y + rv[1], a0.z + rv[2], a0.w + rv[3],
-                                                                     a1.x + rv[4], a1.y + rv[5], a1.z + rv[6], a1.w + rv[7]);
+        const typename H16<RAP_DT_F16>::T8 o8 = f16_pack8_sat(a0.x + rv[0], a0.y + rv[1], a0.z + rv[2], a0.w + rv[3],
+                                                             a1.x + rv[4], a1.y + rv[5], a1.z + rv[6], a1.w + rv[7]);
         const int m = mw + i * 32 + row;
         if (m < p.M) *reinterpret_cast<uint4*>(C + (size_t)m * p.ldc + nw + col) = __builtin_bit_cast(uint4, o8);
       }
@@ -537,10 +537,13 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   // 16-bit results leave as 16-byte row pieces without an LDS transpose.  The v tiles keep the normal order (the V^T image wants a
   // lane to own a column).  Wave-uniform choice: a 64-column wave tile is one head of q, k or v.
   const bool swp = EPI == EPI_H_QKV_NORM && (n0 + wc * 64) < 2 * p.heads * 64;
-#define PH_MMA(H, G, FB)                                                                                      \
+  // SWP is a compile-time property of the k-loop COPY that runs (round 4, as in the persistent kernel below): as a run-time flag inside
+  // the phases the accumulators of the two alternatives are reconciled with register copies at every phase and the kernel spilled
+  // (44 bytes of scratch in the <EPI_H_QKV_NORM> instantiations).
+#define PH_MMA(SWP, H, G, FB)                                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                                          \
   if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                    \
-  if (swp) {                                                                                                  \
+  if constexpr (SWP) {                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                        \
       acc[2 * (H)][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[ks]), __builtin_bit_cast(T8, fa[0][ks]), acc[2 * (H)][G]);         \
       acc[2 * (H) + 1][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[ks]), __builtin_bit_cast(T8, fa[1][ks]), acc[2 * (H) + 1][G]); \
@@ -563,37 +566,45 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   GEMM_TS(2)
   if (STAG && wr == 1) { PH_BAR }          // wave row 1 runs one barrier behind
 
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
-    const bool last = t == nk - 1, pen = t == nk - 2;
-    // ---- q0: quadrant (h0, g0)
-    read_a(buf, 0); read_b(fb0, buf, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!last) { PH_PIECE(4, t + 1, buf ^ 1) PH_PIECE(5, t + 1, buf ^ 1) PH_VM(6) } else { PH_VM(2) }
-    PH_BAR
-    PH_MMA(0, 0, fb0)
-    PH_BAR
-    // ---- q1: quadrant (h0, g1)
-    read_b(fb1, buf, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!last) { PH_PIECE(6, t + 1, buf ^ 1) PH_PIECE(7, t + 1, buf ^ 1) PH_VM(6) } else { PH_VM(0) }
-    PH_BAR
-    PH_MMA(0, 1, fb1)
-    PH_BAR
-    // ---- q2: quadrant (h1, g1)
-    read_a(buf, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!last) { PH_PIECE(2, t + 1, buf ^ 1) PH_PIECE(3, t + 1, buf ^ 1) PH_VM(6) }
-    PH_BAR
-    PH_MMA(1, 1, fb1)
-    PH_BAR
-    // ---- q3: quadrant (h1, g0)
-    read_b(fb0, buf, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!last && !pen) { PH_PIECE(0, t + 2, buf) PH_PIECE(1, t + 2, buf) PH_VM(6) } else if (pen) { PH_VM(4) }
-    PH_BAR
-    PH_MMA(1, 0, fb0)
-    PH_BAR
+  auto k_tiles = [&](auto swp_c) __attribute__((always_inline)) {
+    constexpr bool SWP = decltype(swp_c)::value;
+    for (int t = 0; t < nk; ++t) {
+      const int buf = t & 1;
+      const bool last = t == nk - 1, pen = t == nk - 2;
+      // ---- q0: quadrant (h0, g0)
+      read_a(buf, 0); read_b(fb0, buf, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last) { PH_PIECE(4, t + 1, buf ^ 1) PH_PIECE(5, t + 1, buf ^ 1) PH_VM(6) } else { PH_VM(2) }
+      PH_BAR
+      PH_MMA(SWP, 0, 0, fb0)
+      PH_BAR
+      // ---- q1: quadrant (h0, g1)
+      read_b(fb1, buf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last) { PH_PIECE(6, t + 1, buf ^ 1) PH_PIECE(7, t + 1, buf ^ 1) PH_VM(6) } else { PH_VM(0) }
+      PH_BAR
+      PH_MMA(SWP, 0, 1, fb1)
+      PH_BAR
+      // ---- q2: quadrant (h1, g1)
+      read_a(buf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last) { PH_PIECE(2, t + 1, buf ^ 1) PH_PIECE(3, t + 1, buf ^ 1) PH_VM(6) }
+      PH_BAR
+      PH_MMA(SWP, 1, 1, fb1)
+      PH_BAR
+      // ---- q3: quadrant (h1, g0)
+      read_b(fb0, buf, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last && !pen) { PH_PIECE(0, t + 2, buf) PH_PIECE(1, t + 2, buf) PH_VM(6) } else if (pen) { PH_VM(4) }
+      PH_BAR
+      PH_MMA(SWP, 1, 0, fb0)
+      PH_BAR
+    }
+  };
+  if constexpr (EPI == EPI_H_QKV_NORM) {
+    if (swp) k_tiles(std::true_type{}); else k_tiles(std::false_type{});
+  } else {
+    k_tiles(std::false_type{});
   }
   GEMM_TS(3)
   if (STAG && wr == 0) { PH_BAR }          // equal barrier counts for both wave rows
@@ -926,8 +937,8 @@ __global__ __launch_bounds__(256) void gemm_h16_splitk_combine_kernel(const floa
   if constexpr (H16OUT) {
     float rv[8];
     h16_unpack8<RAP_DT_F16>(*reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(resid) + (size_t)m * ldr + c), rv);
-    const typename H16<RAP_DT_F16>::T8 o8 = h16_pack8<RAP_DT_F16>(v[0] + rv[0], v[1] + rv[1], v[2] + rv[2], v[3] + rv[3], v[4] + rv[4],
-                                                                 v[5] + rv[5], v[6] + rv[6], v[7] + rv[7]);
+    const typename H16<RAP_DT_F16>::T8 o8 = f16_pack8_sat(v[0] + rv[0], v[1] + rv[1], v[2] + rv[2], v[3] + rv[3], v[4] + rv[4],
+                                                         v[5] + rv[5], v[6] + rv[6], v[7] + rv[7]);
     *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(C) + (size_t)m * ldc + c) = __builtin_bit_cast(uint4, o8);
   } else {
     float* out = reinterpret_cast<float*>(C) + (size_t)m * ldc + c;
@@ -942,11 +953,12 @@ __global__ __launch_bounds__(256) void gemm_h16_splitk_combine_kernel(const floa
 }
 
 extern rap_tuning_t g_rap_gemm_splitk;      // gemm_f32.hip, tuning key 6: split K for few-row calls (fp32 GEMMs and these)
-int gemm_h16_splits(int M, int N, int K) {
-  if (!g_rap_gemm_splitk || M <= 0 || N % 128 != 0 || K < 1024 || (K / 64) % 4 != 0) return 1;
+int gemm_h16_splits_by_shape(int M, int N, int K) {
+  if (M <= 0 || N % 128 != 0 || K < 1024 || (K / 64) % 4 != 0) return 1;
   const long tiles = (long)((M + 127) / 128) * (N / 128);
   return tiles <= 64 ? 4 : tiles <= 128 ? 2 : 1;
 }
+int gemm_h16_splits(int M, int N, int K) { return g_rap_gemm_splitk ? gemm_h16_splits_by_shape(M, N, K) : 1; }
 
 template <int DT>
 static int launch_splitk(hipStream_t stream, int epilogue, const GemmParamsH& p, int splits) {
@@ -1044,6 +1056,25 @@ __global__ __launch_bounds__(256) void convert_h16_kernel(const float* __restric
     const float4 v = reinterpret_cast<const float4*>(src)[i];
     reinterpret_cast<uint2*>(dst)[i] = h16_pack4<DT>(v.x, v.y, v.z, v.w);
   }
+}
+
+// the fp32 embedding rounded into the fp16 residual stream: saturating (half.h f16_sat)
+__global__ __launch_bounds__(256) void convert_f16_sat_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n4) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    reinterpret_cast<uint2*>(dst)[i] = h16_pack4<RAP_DT_F16>(f16_sat(v.x), f16_sat(v.y), f16_sat(v.z), f16_sat(v.w));
+  }
+}
+int launch_convert_f16_sat(hipStream_t stream, const float* src, u16* dst, size_t n) {
+  if (n == 0) return RAP_OK;
+  if (n % 4 != 0) return RAP_ERR_INVALID;
+  const size_t n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
+  hipLaunchKernelGGL(convert_f16_sat_kernel, dim3(grid), dim3(256), 0, stream, src, dst, n4);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
 }
 
 int launch_convert_h16(hipStream_t stream, int dtype, const float* src, u16* dst, size_t n) {

@@ -62,6 +62,13 @@ template <int DT> __device__ __forceinline__ typename H16<DT>::T8 h16_pack8(floa
   f32x8 v = {a, b, c, d, e, f, g, h};
   return __builtin_convertvector(v, typename H16<DT>::T8);
 }
+// Saturating fp16 pack for the 16-bit RESIDUAL STREAM (round 4): a plain float -> _Float16 conversion turns |x| > 65504
+// into inf, which the next LayerNorm turns into NaN for the whole row; the stream instead saturates at the largest finite fp16
+// (v_med3_f32, one VALU instruction per value; NaN stays NaN).  Operand and weight conversions do not saturate (RNE, as torch's).
+__device__ __forceinline__ float f16_sat(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+__device__ __forceinline__ typename H16<RAP_DT_F16>::T8 f16_pack8_sat(float a, float b, float c, float d, float e, float f, float g, float h) {
+  return h16_pack8<RAP_DT_F16>(f16_sat(a), f16_sat(b), f16_sat(c), f16_sat(d), f16_sat(e), f16_sat(f), f16_sat(g), f16_sat(h));
+}
 template <int DT> __device__ __forceinline__ void h16_unpack8(uint4 raw, float (&out)[8]) {
   const typename H16<DT>::T8 v = __builtin_bit_cast(typename H16<DT>::T8, raw);
 #pragma unroll

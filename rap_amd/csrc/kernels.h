@@ -47,8 +47,9 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p);
 struct AttnWorkItem { int seg_start, seg_len, q0, pad; };
 // block_queries: query rows per work item; 0 = what the selected fp32 attention variant uses (256 or 512),
 // the 16-bit attention kernel always takes 256.
+// sort_ws: nseg ints of scratch -> items in longest-segment-first order (round 4); nullptr -> segment order
 int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, int nseg, AttnWorkItem* items,
-                               int max_items, int block_queries);
+                               int max_items, int block_queries, int32_t* sort_ws = nullptr);
 // bound: optional per-head upper bounds (device, H floats) on the logits q.k/8 -> bounded-softmax instantiation
 // splits > 1 (few-token calls, needs bound): key ranges per work item, partial O in part_o [splits][TP][heads*64] and partial row
 // sums in part_l [splits][TP][heads], then one combine pass.  attention_f32_splits() picks the count for a work list (1-4).
@@ -93,6 +94,7 @@ int launch_rigid_apply(hipStream_t stream, const float* src, const float* R, con
 int launch_token_sample(hipStream_t stream, const int32_t* cu_batch, int B, int32_t* token_sample);
 int launch_part_offsets(hipStream_t stream, const int64_t* points_per_part, int nparts, int32_t* part_offsets, long limit = -1);
 int launch_check_batch(hipStream_t stream, const int64_t* points_per_part, const int32_t* cu_batch, int B, int P, long TP, int32_t* flag);
+int launch_poison_on_flag(hipStream_t stream, const int32_t* flag, float* buf, long n);
 // weight packing helpers (model creation)
 int launch_copy_cols(hipStream_t stream, const float* src, int src_ld, int src_col0, float* dst, int dst_ld,
                      int dst_col0, int rows, int cols);
@@ -109,7 +111,9 @@ enum GemmEpilogueH {
   EPI_H_BIAS_RESID_F32 = 1,  // C fp32 (M,N) = (resid +) acc (+ bias[n])      (resid may alias C)
   EPI_H_GEGLU = 3,           // W rows pre-interleaved [32 value | 32 gate]: C half (M,N/2) = (h + bh) * gelu_erf(g + bg)
   EPI_H_QKV = 4,             // N = 3*H*64: q,k -> C half [2][H][M][64]; v -> vt half [H][vt_nblk][64 d][64 pos] (half.h vt_pos)
-  EPI_H_BIAS_RESID_H16 = 6,  // C fp16 (M,N) = fp16(resid_h (fp16) + acc + bias[n]), ONE rounding from the fp32 sum   (resid_h may alias C):
+  // 6 is retired: it meant "residual + LayerNorm" in round 2 and "fp16 residual" in round 3 under the same number;
+  // the fp16-residual epilogue is 7 since ABI version 4 and 6 is refused.
+  EPI_H_BIAS_RESID_H16 = 7,  // C fp16 (M,N) = fp16(resid_h (fp16) + acc + bias[n]), ONE rounding from the fp32 sum   (resid_h may alias C):
                              // the residual GEMMs of the 16-bit residual stream (rap_model_set_residual_dtype), whatever the operand dtype
   EPI_H_QKV_NORM = 5,        // EPI_H_QKV with MultiHeadRMSNorm (norm.py:28-33) fused: q,k rows are normalised from the fp32 accumulators,
                              // multiplied by gamma and by q_mul / 8 before the single rounding to 16 bit (phase-split kernel only)
@@ -132,6 +136,8 @@ struct GemmParamsH {
 };
 // 1 = no split; 2 or 4 for GEMMs with K >= 1024 whose 128 x 128 tile grid covers at most a quarter / half of the CUs (tuning key 6)
 int gemm_h16_splits(int M, int N, int K);
+// the same rule without tuning key 6: what a workspace has to reserve (the key only gates the launch)
+int gemm_h16_splits_by_shape(int M, int N, int K);
 int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p);
 int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t* dst, size_t n);
 // attention on q,k half [2][H][TP][64] + transposed-blocked v (vt); out half (TP, H*64)
@@ -150,6 +156,7 @@ int launch_layernorm_mod_h16(hipStream_t stream, int dtype, const void* x, int x
 int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const void* x, int x_f16, uint16_t* out, int TP, int d,
                                 const float* gain, const float* shift);
 int launch_convert_f16_to_f32(hipStream_t stream, const uint16_t* src, float* dst, size_t n);
+int launch_convert_f16_sat(hipStream_t stream, const float* src, uint16_t* dst, size_t n);    // fp32 -> fp16, saturating at +-65504
 // q_mul: factor of the q plane (8 = the reference's sqrt(Dh); RAP_QMUL_PRESCALED = log2(e) for the pre-scaled attention path)
 #define RAP_QMUL_PRESCALED 1.44269504088896340736f
 int launch_qknorm_h16(hipStream_t stream, int dtype, uint16_t* qk, int TP, int heads, const float* gamma_q,

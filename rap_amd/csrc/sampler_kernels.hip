@@ -139,6 +139,21 @@ int launch_check_batch(hipStream_t stream, const int64_t* points_per_part, const
   return RAP_OK;
 }
 
+// Deferred form of the check above (round 4): if *flag != 0 (what check_batch_kernel wrote for this batch), overwrite n floats with
+// quiet NaNs -- the results of a sampling call on an inconsistent batch become unmistakable without the host reading anything back.
+__global__ __launch_bounds__(256) void poison_on_flag_kernel(const int32_t* __restrict__ flag, float* __restrict__ buf, long n) {
+  if (*flag == 0) return;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) buf[i] = __builtin_nanf("");
+}
+int launch_poison_on_flag(hipStream_t stream, const int32_t* flag, float* buf, long n) {
+  if (n <= 0) return RAP_OK;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(poison_on_flag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, flag, buf, n);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight re-packing (model creation only)
 // ---------------------------------------------------------------------------------------------

@@ -64,12 +64,27 @@ class RectifiedPointFlow:
         self.rigidity_forcing = rigidity_forcing
         self.return_end_point_trajectory = return_end_point_trajectory
         self.last_poses = None
-        # the reference asserts the batch layout in split_parts (utils/point_clouds.py:33-52, 41-44) on every call; here the check is
-        # one tiny device kernel + one 4-byte read per call, ON by default since round 3 (a malformed points_per_part must not yield
-        # wrong poses silently).  RAP_VALIDATE_INPUTS=0 / validate_inputs=False turn it off (a latency-critical caller that has
-        # validated its batches itself); it is skipped while the stream is being captured into a HIP graph (a capture cannot read
-        # back), where rap_sample's clamping of the part table still rules out out-of-bounds reads.
-        self.validate_inputs = (os.environ.get("RAP_VALIDATE_INPUTS", "1") != "0") if validate_inputs is None else bool(validate_inputs)
+        # The reference asserts the batch layout in split_parts (utils/point_clouds.py:33-52, 41-44) on every call.  Here:
+        #   "deferred" (default; True means the same): one tiny device kernel writes a verdict flag BEFORE the sampling call is
+        #       enqueued, the results of a call whose flag is non-zero are overwritten with NaN on the device
+        #       (rap_poison_on_flag), and the flag travels to pinned host memory behind an event.  The call itself never waits for
+        #       the GPU; ValueError is raised the first time the flag can be read without stalling -- at the next sampling call of
+        #       this object, or from check_pending() / synchronize().  (Round 3 read the flag back inside the call: one host sync
+        #       per call -- and per shard -- which serialised the ~3 300 enqueues behind the previous call's GPU work.)
+        #   "eager": read the flag back before enqueueing (one host sync per call), raise immediately -- the reference's behaviour.
+        #   False / RAP_VALIDATE_INPUTS=0: no check (a latency-critical caller that validated its batches itself).
+        # Skipped while the stream is being captured into a HIP graph (a capture cannot read back); rap_sample's clamping of the
+        # part table rules out out-of-bounds reads in every mode.
+        if validate_inputs is None:
+            env_v = os.environ.get("RAP_VALIDATE_INPUTS", "1")
+            validate_inputs = False if env_v == "0" else ("eager" if env_v == "eager" else "deferred")
+        if validate_inputs is True:
+            validate_inputs = "deferred"
+        if validate_inputs not in (False, "deferred", "eager"):
+            raise ValueError(f"validate_inputs must be False, True, 'deferred' or 'eager' (got {validate_inputs!r})")
+        self.validate_inputs = validate_inputs
+        self._pending: list = []          # deferred verdicts: (event, pinned host int32, description)
+        self._pin, self._pin_next = None, 0
         # Concurrent batch shards (opt-in, num_streams > 1): samples are independent, so a batch can be run as contiguous shards on
         # several HIP streams.  Round 3: the shards now really fork -- one event recorded on the caller's stream BEFORE
         # any shard is enqueued, every auxiliary stream waits on that event, shard 0 is enqueued LAST on the caller's stream.  (The
@@ -111,6 +126,7 @@ class RectifiedPointFlow:
         d = self._prepare_data(data_dict)
         B = d["ppp"].shape[0]
         n = min(self._resolved_streams(), B)
+        d["flag"] = self._validate(d)             # once for the whole batch, before any shard is forked
         if n <= 1:
             return self._sample_shard(d, x_1, return_transformer_features)
         cond = d["cond"]
@@ -133,7 +149,7 @@ class RectifiedPointFlow:
             b0, b1 = cuts[k], cuts[k + 1]
             t0, t1 = cu_host[b0], cu_host[b1]
             shard = dict(cond=cond[t0:t1], feats=d["feats"][t0:t1], scales=d["scales"][b0:b1], anchor=d["anchor"][t0:t1],
-                         ppp=d["ppp"][b0:b1], cu_batch=None)
+                         ppp=d["ppp"][b0:b1], cu_batch=None, flag=d["flag"])
             if k == 0 or sequential:
                 shard["cu_batch"] = d["cu_batch"][: b1 + 1] if k == 0 else (d["cu_batch"][b0: b1 + 1] - int(t0)).contiguous()
                 parts[k] = self._sample_shard(shard, x_1[t0:t1], return_transformer_features)
@@ -146,7 +162,7 @@ class RectifiedPointFlow:
             with torch.cuda.stream(st):
                 shard["cu_batch"] = (d["cu_batch"][b0: b1 + 1] - int(t0)).contiguous()
                 parts[k] = self._sample_shard(shard, x_1[t0:t1], return_transformer_features)
-            for v in (cond, d["feats"], d["scales"], d["anchor"], d["ppp"], d["cu_batch"], x_1):
+            for v in (cond, d["feats"], d["scales"], d["anchor"], d["ppp"], d["cu_batch"], x_1) + ((d["flag"],) if d["flag"] is not None else ()):
                 v.record_stream(st)                                  # caching-allocator safety: these are read on `st`
         if not sequential:
             for k in range(1, nsh):
@@ -161,6 +177,64 @@ class RectifiedPointFlow:
                 v.record_stream(cur)                                 # allocated on an auxiliary stream, last read (the cat) on `cur`
         return res
 
+    # ---- input validation (split_parts' asserts, utils/point_clouds.py:33-52) ------------------------------------------------
+    def _validate(self, d: dict):
+        """Enqueue rap_check_batch for a prepared batch.  Returns the device flag (deferred mode: the sampling call poisons its
+        results with it) or None (eager mode / off / graph capture).  Raises for verdicts of EARLIER calls that have arrived."""
+        self.check_pending(block=False)
+        if not self.validate_inputs or torch.cuda.is_current_stream_capturing():
+            return None
+        cond = d["cond"]
+        device = cond.device
+        B, P = d["ppp"].shape
+        lib = _lib.load()
+        flag = torch.zeros(1, dtype=torch.int32, device=device)
+        _lib.check(lib.rap_check_batch(_lib.ptr(d["ppp"]), _lib.ptr(d["cu_batch"]), B, P, cond.shape[0], _lib.ptr(flag),
+                                       _lib.current_stream(device)), "rap_check_batch")
+        if self.validate_inputs == "eager":
+            bits = int(flag.item())
+            if bits:
+                raise ValueError(self._inconsistent(bits))
+            return None
+        if len(self._pending) >= 64:               # a caller that never lets a verdict arrive: settle the oldest ones now
+            self.check_pending(block=True)
+        if self._pin is None:
+            self._pin = torch.zeros(128, dtype=torch.int32).pin_memory()     # ring of verdict slots (> the 64 that can be pending)
+        host = self._pin[self._pin_next:self._pin_next + 1]
+        self._pin_next = (self._pin_next + 1) % self._pin.numel()
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))       # BEFORE the sampling call is enqueued: ready within microseconds
+        self._pending.append((ev, host, f"batch of {B} sample(s), {cond.shape[0]} points"))
+        return flag
+
+    @staticmethod
+    def _inconsistent(bits: int) -> str:
+        return (f"inconsistent batch (flags {bits:#x}): sum(points_per_part) must equal the number of points and "
+                "match cu_seqlens per sample (reference: split_parts, utils/point_clouds.py:33-52)")
+
+    def check_pending(self, block: bool = True) -> None:
+        """Raise ValueError if a DEFERRED input check of an earlier call failed (its results were overwritten with NaN on the
+        device).  ``block=False`` looks only at verdicts that have already arrived (never waits for the GPU)."""
+        keep, bad = [], None
+        for ev, host, what in self._pending:
+            if not block and not ev.query():
+                keep.append((ev, host, what))
+                continue
+            if block:
+                ev.synchronize()
+            bits = int(host.item())
+            if bits and bad is None:
+                bad = (bits, what)
+        self._pending = keep
+        if bad is not None:
+            raise ValueError(self._inconsistent(bad[0]) + f" -- reported for an earlier call ({bad[1]}); its results are NaN")
+
+    def synchronize(self) -> None:
+        """Wait for the device and surface deferred validation errors (the natural place for a caller that is about to read results)."""
+        torch.cuda.synchronize()
+        self.check_pending(block=True)
+
     def _sample_shard(self, d: dict, x_1: torch.Tensor | None, return_transformer_features: bool) -> dict:
         """rap_sample on the current stream for one (shard of a) prepared batch."""
         cond = d["cond"]
@@ -172,26 +246,24 @@ class RectifiedPointFlow:
         model = self.flow_model
         model._activate(device)
         lib = _lib.load()
-        if self.validate_inputs and not torch.cuda.is_current_stream_capturing():
-            flag = torch.zeros(1, dtype=torch.int32, device=device)
-            _lib.check(lib.rap_check_batch(_lib.ptr(d["ppp"]), _lib.ptr(d["cu_batch"]), B, P, TP, _lib.ptr(flag),
-                                           _lib.current_stream(device)), "rap_check_batch")
-            bits = int(flag.item())
-            if bits:
-                raise ValueError(f"inconsistent batch (flags {bits:#x}): sum(points_per_part) must equal the number of points and "
-                                 "match cu_seqlens per sample (reference: split_parts, utils/point_clouds.py:33-52)")
         traj_x0 = torch.empty((S, TP, 3), dtype=torch.float32, device=device)     # sampler.py:47-49
         traj_xt = torch.empty((S, TP, 3), dtype=torch.float32, device=device)
         R = torch.empty((B, P, 3, 3), dtype=torch.float32, device=device)
         t = torch.empty((B, P, 3), dtype=torch.float32, device=device)
         feats_out = torch.empty((TP, model.embed_dim), dtype=torch.float32, device=device) if return_transformer_features else None
         ws = workspace(device, lib.rap_workspace_bytes(model._handle, TP, B, B * P, S))
+        stream = _lib.current_stream(device)
         with torch.cuda.device(device):
             rc = lib.rap_sample(model._handle, _lib.ptr(cond), _lib.ptr(d["feats"]), _lib.ptr(d["scales"]), _lib.ptr(d["anchor"]),
                                 _lib.ptr(d["ppp"]), _lib.ptr(d["cu_batch"]), _lib.ptr(x_1), B, P, TP, S,
                                 1 if self.rigidity_forcing else 0, _lib.ptr(traj_x0), _lib.ptr(traj_xt), _lib.ptr(R),
-                                _lib.ptr(t), _lib.ptr(feats_out), _lib.ptr(ws), ws.numel(), _lib.current_stream(device))
-        _lib.check(rc, "rap_sample")
+                                _lib.ptr(t), _lib.ptr(feats_out), _lib.ptr(ws), ws.numel(), stream)
+            _lib.check(rc, "rap_sample")
+            flag = d.get("flag")
+            if flag is not None:
+                # deferred validation: an inconsistent batch yields NaN poses and a NaN final cloud, never plausible numbers
+                for buf in (R, t, traj_x0[S - 1], traj_xt[S - 1]):
+                    _lib.check(lib.rap_poison_on_flag(_lib.ptr(flag), _lib.ptr(buf), buf.numel(), stream), "rap_poison_on_flag")
         out = {"end_point_trajectory": traj_x0, "trajectory": traj_xt, "R": R, "t": t}
         if return_transformer_features:
             out["transformer_features"] = feats_out
@@ -218,28 +290,67 @@ class RectifiedPointFlow:
         return result
 
     @torch.inference_mode()
-    def sample_generations(self, data_dict: dict, x_1_list=None, use_average_rigidity_rmse: bool = True) -> dict:
-        """``n_generations`` sampling calls + the reference's rigidity-based selection (test_step, modeling.py:397-592):
+    def sample_generations(self, data_dict: dict, x_1_list=None, use_average_rigidity_rmse: bool = True,
+                           batch_generations: bool | None = None) -> dict:
+        """``n_generations`` samples per object + the reference's rigidity-based selection (test_step, modeling.py:397-592):
         per generation the trajectory, final cloud and poses; per object the generation whose rigidity RMSE is smallest --
         averaged over all end-point trajectory steps (``use_average_rigidity_rmse``, modeling.py:466-500) or taken at the
-        final step (:501-504).  Everything stays on the device."""
+        final step (:501-504).  Everything stays on the device.
+
+        The reference loops the generations one after the other (modeling.py:351-361).  Generations are independent samples of
+        the same objects (same condition / features, their own x_1), so here the G x B samples ride in ONE ``rap_sample`` call
+        (round 4; ``batch_generations=False`` or more than 65 535 parts restore the loop): with the shipped ``batch_size: 1`` a
+        single generation leaves the GPU at the launch floor, and G of them cost about what one does.  Each generation's noise is
+        drawn exactly as the loop would draw it (one ``randn_like`` per generation, in order).  The rigidity RMSEs of all
+        generations come out of one trajectory pass over the stacked batch."""
         from .selection import (average_trajectory_rigidity_rmse, compute_rigidity_rmse, select_generations_by_rigidity)
         G = int(self.n_generations)
         d = self._prepare_data(data_dict)
-        gens = []
-        for g in range(G):
-            x_1 = None if x_1_list is None else x_1_list[g]
-            gens.append(self.sample_and_register(data_dict, x_1=x_1))
         cond, ppp, cu, scales = d["cond"], d["ppp"], d["cu_batch"], d["scales"]
-        if use_average_rigidity_rmse and self.return_end_point_trajectory:
-            rig = [average_trajectory_rigidity_rmse(cond, o["end_point_trajectory"], ppp, cu, scales) for o in gens]
+        B, P = ppp.shape
+        TP = cond.shape[0]
+        if batch_generations is None:
+            batch_generations = os.environ.get("RAP_BATCH_GENERATIONS", "1") != "0"
+        stacked_call = batch_generations and G > 1 and G * B * P <= 65535 and G * TP <= 0x7fffffff // 8
+        avg = use_average_rigidity_rmse and self.return_end_point_trajectory
+        if stacked_call:
+            device = cond.device
+            x_1 = torch.cat([torch.randn_like(cond) if x_1_list is None or x_1_list[g] is None else _f32c(x_1_list[g].to(device))
+                             for g in range(G)])
+            offs = (torch.arange(G, device=device, dtype=torch.int32) * TP)[:, None]
+            big = dict(cond=cond.repeat(G, 1), feats=d["feats"].repeat(G, 1), scales=scales.repeat(G), anchor=d["anchor"].repeat(G),
+                       ppp=ppp.repeat(G, 1),
+                       cu_batch=torch.cat([(cu[:-1][None, :] + offs).reshape(-1), cu.new_full((1,), G * TP)]).contiguous(),
+                       flag=self._validate(d))                       # the G copies are consistent iff the batch is
+            n_streams = self.num_streams
+            try:
+                self.num_streams = 1          # the stacked call fills the chip by itself; shards would only cut it up again
+                o = self._sample_shard(big, x_1, False)
+            finally:
+                self.num_streams = n_streams
+            ep, tr = o["end_point_trajectory"], o["trajectory"]
+            Rg, tg = o["R"].view(G, B, P, 3, 3), o["t"].view(G, B, P, 3)
+            gens = [{"end_point_trajectory": ep[:, g * TP:(g + 1) * TP], "trajectory": tr[:, g * TP:(g + 1) * TP],
+                     "R": Rg[g], "t": tg[g]} for g in range(G)]
+            if avg:
+                stacked = average_trajectory_rigidity_rmse(big["cond"], ep, big["ppp"], big["cu_batch"], big["scales"]).view(G, B)
+            else:
+                stacked = compute_rigidity_rmse(big["cond"], ep[-1], o["R"], o["t"], big["ppp"], big["cu_batch"], big["scales"]).view(G, B)
+            finals = ep[-1].view(G, TP, 3)
         else:
-            rig = [compute_rigidity_rmse(cond, o["end_point_trajectory"][-1], o["R"], o["t"], ppp, cu, scales) for o in gens]
-        stacked = torch.stack(rig)                                                          # (G,B)
-        finals = torch.stack([o["end_point_trajectory"][-1] for o in gens])
-        best, cloud, R, t = select_generations_by_rigidity(stacked, finals, torch.stack([o["R"] for o in gens]),
-                                                           torch.stack([o["t"] for o in gens]), cu)
+            gens = []
+            for g in range(G):
+                x_1 = None if x_1_list is None else x_1_list[g]
+                gens.append(self.sample_and_register(data_dict, x_1=x_1))
+            if avg:
+                rig = [average_trajectory_rigidity_rmse(cond, o["end_point_trajectory"], ppp, cu, scales) for o in gens]
+            else:
+                rig = [compute_rigidity_rmse(cond, o["end_point_trajectory"][-1], o["R"], o["t"], ppp, cu, scales) for o in gens]
+            stacked = torch.stack(rig)                                                          # (G,B)
+            finals = torch.stack([o["end_point_trajectory"][-1] for o in gens])
+            Rg, tg = torch.stack([o["R"] for o in gens]), torch.stack([o["t"] for o in gens])
+        best, cloud, R, t = select_generations_by_rigidity(stacked, finals, Rg, tg, cu)
         return {"generations": gens, "rigidity_rmse": stacked, "best_gen_indices": best, "pointclouds_selected": cloud,
-                "rotations_selected": R, "translations_selected": t}
+                "rotations_selected": R, "translations_selected": t, "generations_in_one_call": bool(stacked_call)}
 
     sample = sample_rectified_flow   # the name BASELINE.json's north_star uses

@@ -192,3 +192,39 @@ def make_inputs(parts: Sequence[Sequence[int]], seed: int = 1234, feat_dim: int 
 def make_uniform_inputs(batch: int, views: int, n_points: int, seed: int = 1234, feat_dim: int = 32):
     """BASELINE.json geometry: ``batch`` samples of ``views`` x ``n_points``."""
     return make_inputs([[n_points] * views for _ in range(batch)], seed=seed, feat_dim=feat_dim)
+
+
+def ragged_regime_parts(total_points: int = 262144, seed: int = 4321) -> list[list[int]]:
+    """Part sizes of a RAGGED packed batch in the reference's own regime (config/RAP_inference.yaml:30-36, demo.py:568-571: 2 ... 512
+    parts per sample, 200 ... 20 000 points per part after voxel-adaptive FPS, <= 400 000 points per batch): samples with P = 2, 8
+    and 64 parts in turn, part sizes log-uniform in a range per kind (two scans: 2 000 ... 20 000; eight views: 500 ... 8 000;
+    sixty-four fragments: 200 ... 1 200), until ``total_points`` is reached -- the last part is cut so that the total is
+    ``total_points - 133`` (NOT a multiple of any tile size).  Seeded (CPU generator); about 262 k points by default = the token
+    count of BASELINE configs[1]."""
+    g = torch.Generator().manual_seed(seed)
+    kinds = [(2, 2000, 20000), (8, 500, 8000), (64, 200, 1200)]
+    target = int(total_points) - 133
+    parts, total, k = [], 0, 0
+    while total < target:
+        P, lo, hi = kinds[k % len(kinds)]
+        k += 1
+        u = torch.rand(P, generator=g, dtype=torch.float64)
+        sizes = [int(round(math.exp(math.log(lo) + float(x) * (math.log(hi) - math.log(lo))))) for x in u]
+        room = target - total
+        if sum(sizes) > room:                       # cut the last sample to the budget (drop parts that no longer fit)
+            cut, acc = [], 0
+            for n in sizes:
+                if acc + n <= room:
+                    cut.append(n); acc += n
+                elif room - acc >= 200:
+                    cut.append(room - acc); acc = room
+                    break
+            if not cut:
+                if parts:
+                    parts[-1][-1] += room           # a sliver: give it to the previous sample's last part
+                    total += room
+                break
+            sizes = cut
+        parts.append(sizes)
+        total += sum(sizes)
+    return parts

@@ -12,7 +12,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 TP, H = 262144, 8
 nblk = TP // 64
 dt = 1
-for name, epi, N, K in (("qkv + qk-norm", 5, 1536, 512), ("out-proj fp16 stream", 6, 512, 512), ("ff1 GEGLU", 3, 4096, 512), ("ff2 fp16 stream", 6, 512, 2048),
+for name, epi, N, K in (("qkv + qk-norm", 5, 1536, 512), ("out-proj fp16 stream", 7, 512, 512), ("ff1 GEGLU", 3, 4096, 512), ("ff2 fp16 stream", 7, 512, 2048),
                         ("out-proj fp32 stream", 1, 512, 512), ("ff2 fp32 stream", 1, 512, 2048)):
     A = torch.randn(TP, K, device=dev, generator=g).to(torch.bfloat16)
     W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
@@ -24,7 +24,7 @@ for name, epi, N, K in (("qkv + qk-norm", 5, 1536, 512), ("out-proj fp16 stream"
     else:
         Cw = N // 2 if epi == 3 else N
         C = torch.zeros(TP, Cw, device=dev, dtype={1: torch.float32, 6: torch.float16, 3: torch.bfloat16}[epi])
-        resid = C if epi in (1, 6) else None
+        resid = C if epi in (1, 7) else None
         fn = lambda: lib.rap_gemm_h16(dt, epi, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(C), Cw, TP, N, K, _lib.ptr(bias), _lib.ptr(resid), Cw if resid is not None else 0, 0, _lib.ptr(None), 0, st())  # noqa: E731
     row = {"gemm": name, "N": N, "K": K}
     for pz in (1, 0):

@@ -25,7 +25,7 @@ PERSISTENT = "--persistent" in sys.argv
 raw.rap_set_tuning.restype = ctypes.c_int; raw.rap_set_tuning.argtypes = [ctypes.c_int32, ctypes.c_int32]
 assert raw.rap_set_tuning(11, 1 if PERSISTENT else 0) == 0
 cases = [("plain 16-bit out", 0, 512, 512), ("plain 16-bit out", 0, 512, 2048), ("plain 16-bit out", 0, 1536, 512), ("GEGLU", 3, 4096, 512),
-         ("fp16 residual", 6, 512, 512), ("qkv + qk-norm", 5, 1536, 512)]
+         ("fp16 residual", 7, 512, 512), ("qkv + qk-norm", 5, 1536, 512)]
 raw.rap_gemm_h16_qkvnorm.restype = ctypes.c_int
 raw.rap_gemm_h16_qkvnorm.argtypes = [ctypes.c_int32, P, ctypes.c_int32, P, ctypes.c_int32, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, P, P, ctypes.c_float, P,
                                      ctypes.c_int32, P]
@@ -41,8 +41,8 @@ for name, epi, N, K in cases:
     W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(N, device=dev, generator=g)
     Cw = N // 2 if epi == 3 else N
-    C = torch.zeros(TP, Cw, device=dev, dtype=torch.float16 if epi == 6 else torch.bfloat16)
-    resid = C if epi == 6 else None
+    C = torch.zeros(TP, Cw, device=dev, dtype=torch.float16 if epi == 7 else torch.bfloat16)
+    resid = C if epi == 7 else None
     vt = torch.zeros(8 * (TP // 64) * 64 * 64, device=dev, dtype=torch.bfloat16) if epi == 5 else None
     gq = torch.ones(8, 64, device=dev)
     nblocks = (TP // 256) * (N // 256)

@@ -120,7 +120,8 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
 def test_splitk_rule_of_the_16bit_residual_gemm_is_host_arithmetic():
     """rap_gemm_h16_splitk_workspace_bytes states the few-token split-K rule of the 16-bit residual GEMMs (gemm_h16.hip:
     gemm_h16_splits): K >= 1024 with K / 64 a multiple of 4, at most 64 tiles of 128 x 128 -> 4 partial planes, at most 128 -> 2,
-    otherwise none; tuning key 6 switches it off.  Pure host arithmetic -- and the entry point refuses a short workspace, other
+    otherwise none.  Round 4: the size is a function of the SHAPE alone -- tuning key 6 gates the launch, not the
+    reservation, so a workspace sized before the key is toggled is never too small.  Pure host arithmetic -- and the entry point refuses a short workspace, other
     epilogues and NULL operands before it touches the device."""
     import ctypes
     from rap_amd import _lib
@@ -137,11 +138,16 @@ def test_splitk_rule_of_the_16bit_residual_gemm_is_host_arithmetic():
     assert q(0, 512, 2048) == 0 and q(-5, 512, 2048) == 0
     try:
         assert lib.rap_set_tuning(6, 0) == 0
-        assert q(2048, 512, 2048) == 0
+        assert q(2048, 512, 2048) == 4 * plane(2048, 512)      # still reserved: the key only gates the launch
     finally:
         assert lib.rap_set_tuning(6, 1) == 0
     N, one = ctypes.c_void_p(0), ctypes.c_void_p(256)
-    assert lib.rap_gemm_h16_splitk(1, 6, N, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 1 << 30, N) == -1      # NULL A
+    assert lib.rap_gemm_h16_splitk(1, 7, N, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 1 << 30, N) == -1      # NULL A
     assert lib.rap_gemm_h16_splitk(1, 3, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 1 << 30, N) == -1    # not a residual epilogue
-    assert lib.rap_gemm_h16_splitk(1, 6, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 4 * plane(2048, 512) - 1, N) == -2   # short workspace
-    assert lib.rap_gemm_h16_splitk(1, 6, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, N, 0, N) == -2             # no workspace
+    assert lib.rap_gemm_h16_splitk(1, 7, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 4 * plane(2048, 512) - 1, N) == -2   # short workspace
+    assert lib.rap_gemm_h16_splitk(1, 7, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, N, 0, N) == -2             # no workspace
+    # epilogue 6 (two different meanings in rounds 2 and 3) is retired with ABI version 4: refused, never reinterpreted
+    assert lib.rap_gemm_h16_splitk(1, 6, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 1 << 30, N) == -1
+    assert lib.rap_gemm_h16(1, 6, one, 512, one, 512, one, 512, 256, 512, 512, N, one, 512, 0, N, 0, N) == -1
+    assert lib.rap_version() == _lib.ABI_VERSION == 4
+    assert lib.rap_poison_on_flag(N, one, 4, N) == -1 and lib.rap_poison_on_flag(one, N, 4, N) == -1

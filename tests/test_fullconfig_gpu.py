@@ -189,3 +189,37 @@ def test_400k_token_sample_matches_the_checker(dev):
         assert e["final_cloud"] <= ctol and e["final_x_t"] <= ctol, (dtype, e)
         if dtype == "float32":
             assert e["R_frob"] <= TOL_R and e["t"] <= TOL_T, e
+
+
+def test_ragged_regime_batch_on_the_padded_fast_path(dev):
+    """Round 4: every token-row buffer of the workspace is carved at align_up(TP, 256) rows and the layer kernels run over the padded
+    row count, so a RAGGED batch (the reference's real regime, RAP_inference.yaml:30-36) takes the same persistent GEMMs as the
+    uniform one.  A ragged reference-regime batch (~70 k points in samples of 2 / 8 / 64 parts, not a multiple of 256):
+    (1) fp32 equals the device-side checker at the stated tolerances; (2) the filler rows never leak: with the WHOLE workspace
+    pre-filled with NaN bit patterns the results are bit-identical, in fp32 and in both 16-bit modes (the 16-bit attention multiplies
+    masked keys by p = 0, so a non-finite filler V column would poison real rows); (3) the work list is longest-segment-first."""
+    from rap_amd import flow_model as FM
+    cfg, sd = _weights(2)
+    parts = S.ragged_regime_parts(70000, seed=11)
+    inp = S.make_inputs(parts, seed=501)
+    TP = int(inp["pointclouds"].shape[0])
+    assert TP % 256 != 0
+    ref = None
+    for dtype in ("float32", "bfloat16", "float16"):
+        out, _ = _hip(cfg, sd, inp, 2, True, dev, dtype=dtype)
+        for buf in FM._WORKSPACES.values():
+            buf.fill_(0xFF)                                   # NaN in fp32, bf16 and fp16
+        torch.cuda.synchronize()
+        again, _ = _hip(cfg, sd, inp, 2, True, dev, dtype=dtype)
+        for k in ("end_point_trajectory", "trajectory", "R", "t"):
+            assert torch.isfinite(again[k]).all(), (dtype, k)
+            assert torch.equal(out[k], again[k]), (dtype, k)
+        if dtype == "float32":
+            ref, _ = _checker(cfg, sd, inp, 2, True, dev)
+            e = _errors(out, ref, inp["cu_seqlens"], inp["points_per_part"])
+            _record({"case": "ragged_regime_70k", "dtype": "f32", **e})
+            _assert_fp32(e)
+        else:
+            e = _errors(out, ref, inp["cu_seqlens"], inp["points_per_part"])
+            _record({"case": "ragged_regime_70k", "dtype": dtype, **e})
+            assert e["final_cloud"] <= 5e-2 and e["R_frob"] <= 1e-1, (dtype, e)

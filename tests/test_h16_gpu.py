@@ -196,7 +196,7 @@ def test_gemm_h16_qkv_with_fused_qknorm(lib, dev, dt, M, K, q_mul):
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("M,K", [(100, 512), (1000, 512), (777, 2048)])
 def test_gemm_h16_fp16_residual_epilogue(lib, dev, dt, M, K):
-    """Epilogue 6 (the residual GEMMs of the 16-bit residual stream): C fp16 = fp16(resid fp16 + A W^T + bias), in place, the sum
+    """Epilogue 7 (the residual GEMMs of the 16-bit residual stream): C fp16 = fp16(resid fp16 + A W^T + bias), in place, the sum
     formed in fp32 and rounded ONCE -- within one fp16 rounding of the fp64 evaluation on the same rounded operands, for both operand
     dtypes and both shipped kernels (M <= 128: 128 x 128 tiles; above: the phase-split 256 x 256 kernel)."""
     g = torch.Generator().manual_seed(41)
@@ -206,18 +206,27 @@ def test_gemm_h16_fp16_residual_epilogue(lib, dev, dt, M, K):
     h0 = (torch.randn(M, N, generator=g) * 3).to(torch.float16)
     ref = h0.double() + A.double() @ W.double().T + bias.double()
     Ad, Wd, bd, hd = A.to(dev), W.to(dev), bias.to(dev), h0.to(dev).clone()
-    gemm_h(lib, dev, dt, 6, Ad, Wd, hd, M, N, K, bias=bd, resid=hd)
+    gemm_h(lib, dev, dt, 7, Ad, Wd, hd, M, N, K, bias=bd, resid=hd)
     err = (hd.cpu().double() - ref).abs() / (ref.abs() + 1e-2)
     assert err.max().item() < 1.01 * ULP[2] + 1e-4, err.max().item()      # ULP[2]: one fp16 rounding (+ fp32 accumulation noise)
+    # the stream SATURATES instead of overflowing to inf (round 4): residual rows near the fp16 maximum plus a positive
+    # product stay at +-65504 (and finite values below it are untouched, as the comparison above shows)
+    big = torch.full((M, N), 65000.0).to(torch.float16); big[::2] = -65000.0
+    sgn = torch.where(torch.arange(M) % 2 == 0, -1.0, 1.0)[:, None]
+    A2 = to_h(torch.ones(M, K) * sgn, dt); W2 = to_h(torch.full((N, K), 4.0), dt)         # |A W^T| = 4 K >= 2048: the sum leaves the fp16 range
+    A2d, W2d, bigd = A2.to(dev), W2.to(dev), big.to(dev).clone()
+    gemm_h(lib, dev, dt, 7, A2d, W2d, bigd, M, N, K, resid=bigd)
+    assert torch.isfinite(bigd).all() and bool((bigd.abs().float() == 65504.0).all())
+    assert bool((torch.sign(bigd.float()) == sgn.to(dev)).all())
     # the epilogue needs its residual: without one the call is refused (a plain fp16-output GEMM is epilogue 0 with dtype fp16)
-    rc = lib.rap_gemm_h16(dt, 6, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(hd), N, M, N, K, _lib.ptr(bd), _lib.ptr(None), 0, 0, _lib.ptr(None), 0,
+    rc = lib.rap_gemm_h16(dt, 7, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(hd), N, M, N, K, _lib.ptr(bd), _lib.ptr(None), 0, 0, _lib.ptr(None), 0,
                           stream(dev))
     assert rc == -1
 
 
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("epi,M,N,K", [(0, 16384, 2048, 512), (1, 65536, 512, 2048), (3, 16384, 2048, 512), (4, 32768, 1536, 512),
-                                       (5, 32768, 1536, 512), (6, 65536, 512, 512), (6, 65536, 512, 128)])
+                                       (5, 32768, 1536, 512), (7, 65536, 512, 512), (7, 65536, 512, 128)])
 def test_persistent_gemm_is_bit_identical_to_the_one_tile_per_block_kernel(lib, dev, dt, epi, M, N, K):
     """Round 3: full-tile shapes (M % 256 == 0, at least 512 tiles) run on the PERSISTENT phase-split kernel (one block per CU walks its
     XCD's tiles, the k-tiles of consecutive output tiles form one DMA stream); rap_set_tuning(11, 0) restores one 256 x 256 tile per
@@ -239,9 +248,9 @@ def test_persistent_gemm_is_bit_identical_to_the_one_tile_per_block_kernel(lib, 
             elif epi == 1:
                 g2 = torch.Generator(device=dev).manual_seed(5)
                 C = torch.randn(M, N, device=dev, generator=g2); gemm_h(lib, dev, dt, 1, A, W, C, M, N, K, bias=bias, resid=C)
-            elif epi == 6:
+            elif epi == 7:
                 g2 = torch.Generator(device=dev).manual_seed(5)
-                C = torch.randn(M, N, device=dev, generator=g2).to(torch.float16); gemm_h(lib, dev, dt, 6, A, W, C, M, N, K, bias=bias, resid=C)
+                C = torch.randn(M, N, device=dev, generator=g2).to(torch.float16); gemm_h(lib, dev, dt, 7, A, W, C, M, N, K, bias=bias, resid=C)
             elif epi == 3:
                 C = torch.zeros(M, N // 2, dtype=TORCH_DT[dt], device=dev); gemm_h(lib, dev, dt, 3, A, W, C, M, N, K, bias=bias, ldc=N // 2)
             else:
@@ -260,13 +269,13 @@ def test_persistent_gemm_is_bit_identical_to_the_one_tile_per_block_kernel(lib, 
     assert torch.equal(c1.view(torch.int16) if c1.dtype != torch.float32 else c1, c0.view(torch.int16) if c0.dtype != torch.float32 else c0)
     if v1 is not None:
         assert torch.equal(v1.view(torch.int16), v0.view(torch.int16))
-    if epi in (0, 1, 6):                         # spot check against fp64 on rows from every part of the tile walk
+    if epi in (0, 1, 7):                         # spot check against fp64 on rows from every part of the tile walk
         rows = torch.randint(0, M, (64,), generator=torch.Generator().manual_seed(3)).to(dev)
         ref = A[rows].double() @ W.double().T + bias.double()
         if epi != 0:
             g2 = torch.Generator(device=dev).manual_seed(5)
             r0 = torch.randn(M, N, device=dev, generator=g2)
-            ref = ref + (r0.to(torch.float16) if epi == 6 else r0)[rows].double()
+            ref = ref + (r0.to(torch.float16) if epi == 7 else r0)[rows].double()
         if epi == 1:                             # fp32 out: absolute error of the fp32 accumulation of K exact 16-bit products
             err = (c1[rows].double() - ref).abs().max().item()
             assert err < 5e-5 * max(1.0, K / 512), err
@@ -298,7 +307,7 @@ def test_gemm_h16_full_size_linearity_property(lib, dev, dt):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("epi", [1, 6], ids=["fp32-stream", "fp16-stream"])
+@pytest.mark.parametrize("epi", [1, 7], ids=["fp32-stream", "fp16-stream"])
 @pytest.mark.parametrize("M,splits", [(100, 4), (2048, 4), (3000, 2), (9000, 1)])
 def test_gemm_h16_splitk_of_the_residual_gemm(lib, dev, dt, epi, M, splits):
     """Few-token calls (round 3): ff2 (N = 512, K = 2048) has at most 128 tiles of 128 x 128 and a chain of 32 k-tiles per tile, so K is
@@ -312,11 +321,11 @@ def test_gemm_h16_splitk_of_the_residual_gemm(lib, dev, dt, epi, M, splits):
     A = to_h(torch.randn(M, K, generator=g), dt); W = to_h(torch.randn(N, K, generator=g) / K ** 0.5, dt)
     bias = torch.randn(N, generator=g)
     h0 = (torch.randn(M, N, generator=g) * 3)
-    h0 = h0.to(torch.float16) if epi == 6 else h0
+    h0 = h0.to(torch.float16) if epi == 7 else h0
     ref = h0.double() + A.double() @ W.double().T + bias.double()
     Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
     ws = workspace(dev, max(need, 256))
-    bits = torch.int16 if epi == 6 else torch.int32
+    bits = torch.int16 if epi == 7 else torch.int32
 
     def run(ws_bytes=None):
         hd = h0.to(dev).clone()
@@ -327,7 +336,7 @@ def test_gemm_h16_splitk_of_the_residual_gemm(lib, dev, dt, epi, M, splits):
 
     rc, out = run()
     assert rc == 0
-    if epi == 6:
+    if epi == 7:
         err = (out.double() - ref).abs() / (ref.abs() + 1e-2)
         assert err.max().item() < 1.01 * ULP[2] + 1e-4, err.max().item()     # one fp16 rounding (+ fp32 accumulation noise)
     else:
@@ -341,7 +350,7 @@ def test_gemm_h16_splitk_of_the_residual_gemm(lib, dev, dt, epi, M, splits):
     finally:
         assert lib.rap_set_tuning(6, 1) == 0
     assert rc3 == 0
-    if epi == 6:
+    if epi == 7:
         d = (out.double() - unsplit.double()).abs() / (ref.abs() + 1e-2)
         assert d.max().item() < 2.01 * ULP[2], d.max().item()                # at most the neighbouring fp16 value
     else:

@@ -129,14 +129,17 @@ def test_fp32_all_steps_match_the_reference(name, dev):
         assert e["R_frob"] <= 1e-3 and e["t"] <= 1e-3, e
 
 
+@pytest.mark.parametrize("stream", ["float32", "auto"], ids=["fp32-stream", "shipped-default-stream"])
 @pytest.mark.parametrize("dtype,cloud_tol,R_tol", [("bfloat16", 5e-2, 1e-1), ("float16", 1e-2, 2e-2)])
 @pytest.mark.parametrize("name", ["headline_c1_rigid", "headline_c3_rigid", "headline_c2_rank1", "headline_c1_ragged", "headline_c1_rap16"])
-def test_16bit_all_steps_deviation_from_the_reference(name, dtype, cloud_tol, R_tol, dev):
-    """north_star: report the measured deviation of the reduced-precision modes -- against the reference's fp32 result."""
+def test_16bit_all_steps_deviation_from_the_reference(name, dtype, cloud_tol, R_tol, stream, dev):
+    """north_star: report the measured deviation of the reduced-precision modes -- against the reference's fp32 result.  Both with the
+    fp32 residual stream and with the SHIPPED default ("auto": fp16 stream under bf16 operands, saturating at +-65504 since round 4;
+    fp32 stream under fp16 operands) -- ADVICE r03: the headline suite must run the configuration users get."""
     g = _golden(name)
-    out = _run_sample(g, dtype, dev)
+    out = _run_sample(g, dtype, dev, residual_dtype=stream)
     e = _errors(out, g)
-    _record({"case": name, "dtype": dtype, **{k: v for k, v in e.items() if not k.startswith("per_step")},
+    _record({"case": name, "dtype": dtype, "residual_stream": stream, **{k: v for k, v in e.items() if not k.startswith("per_step")},
              "per_step_end_point_max": max(e["per_step_end_point"]), "per_step_end_point_last": e["per_step_end_point"][-1]})
     assert e["final_end_point"] <= cloud_tol and e["R_frob"] <= R_tol and e["t"] <= cloud_tol, e
     nonempty = torch.from_numpy(g["R"]).abs().sum(dim=(-1, -2)) > 0      # an empty part has R = 0, t = 0 in the reference too (procrustes.py:71-76)

@@ -114,3 +114,40 @@ def test_shard_cuts_balance_tokens_at_sample_boundaries():
             assert all(cu_e[b] > cu_e[a] for a, b in zip(c, c[1:])), (cu_e, n, c)
     off = [1000, 1100, 6000, 6100]                            # offsets that do not start at 0 (a shard of a larger batch)
     assert shard_cuts(off, 2) == [0, 2, 3] or shard_cuts(off, 2) == [0, 1, 3]
+
+
+def test_bench_cpu_baseline_times_the_live_reference_when_the_mount_exists():
+    """bench.py's cpu_baseline leg (north_star: "the reference timed on the host cores of the same box in the
+    same run"): with /root/reference mounted it times the UNMODIFIED reference modules (kind "reference"), otherwise the pinned port;
+    two timing points (1 and 3 flow steps) give a per-step slope.  Tiny configuration here (2 layers, 2 x 64 points, 6 steps)."""
+    import types
+    import torch
+    import bench
+    from oracle import ref_loader
+    from rap_amd import synthetic as S
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    sd = S.make_weights(cfg, 0)
+    args = types.SimpleNamespace(views=2, points=64, flow_steps=6, rigidity=1)
+    nthreads = torch.get_num_threads()
+    try:
+        base, err = bench.cpu_baseline(cfg, sd, args, None)
+        full, _ = bench.cpu_baseline(cfg, sd, args, None, full=True)
+    finally:
+        torch.set_num_threads(nthreads)
+    assert base["kind"] == ("reference" if ref_loader.reference_available() else "port")
+    assert base["steps_timed"] == 3 and base["extrapolated"] and not full["extrapolated"] and full["steps_timed"] == 6
+    assert base["value"] > 0 and base["seconds_per_flow_step"] > 0 and base["nproc"] >= base["cores"] >= 1
+    assert err is None
+    assert base["seconds_per_pair_all_steps"] > 0 and full["seconds_per_pair_all_steps"] > 0       # (tiny sizes: no ratio claim)
+
+
+def test_ragged_regime_batch_is_in_the_reference_regime():
+    from rap_amd import synthetic as S
+    parts = S.ragged_regime_parts(262144, seed=4321)
+    total = sum(sum(x) for x in parts)
+    assert total == 262144 - 133 and total % 256 != 0
+    assert {len(x) for x in parts[:3]} == {2, 8, 64}
+    assert all(200 <= n <= 20000 for x in parts for n in x)
+    assert parts == S.ragged_regime_parts(262144, seed=4321)          # seeded
+    # 64-part samples: B * P of the padded table stays far below the 65 535-part limit of rap_sample
+    assert len(parts) * max(len(x) for x in parts) < 65535

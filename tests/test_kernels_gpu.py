@@ -528,3 +528,37 @@ def test_transform_and_collate_fp32_input_large_batch_properties(dev):
     assert torch.equal(out["anchor_indices"].view(32, 2, 4096)[:, 0], torch.ones(32, 4096, dtype=torch.bool, device=dev))
     with pytest.raises(ValueError):
         rap_amd.transform_and_collate(samples[:2], 2, order=torch.full((2 * 8192,), 5000, dtype=torch.int64))
+
+
+@pytest.mark.parametrize("nseg", [1, 7, 300, 1500, 5000])
+def test_attention_worklist_is_longest_segment_first_and_complete(lib, dev, nseg):
+    """Round 4: rap_sample's attention work lists are emitted longest-segment-first (LPT: a block's work is its segment's length).
+    Every (segment, 256-query block) appears exactly once, in non-increasing segment length (ties in segment order), the tail is
+    zero items, and without scratch the list is in segment order -- incl. empty segments and more segments than threads / LDS tile."""
+    g = torch.Generator().manual_seed(nseg)
+    lens = torch.randint(0, 3000, (nseg,), generator=g)
+    lens[torch.rand(nseg, generator=g) < 0.1] = 0
+    if nseg > 2:
+        lens[1] = 40000; lens[nseg - 1] = 40000                      # a tie between the two longest
+    cu = torch.zeros(nseg + 1, dtype=torch.int32); cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    n_items = int(((lens + 255) // 256).sum())
+    max_items = n_items + 37
+    cud = cu.to(dev)
+    expect = {(int(cu[s]), int(lens[s]), q0) for s in range(nseg) for q0 in range(0, int(lens[s]), 256)}
+    for sorted_ in (True, False):
+        items = torch.full((max_items, 4), -1, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(nseg, 1), dtype=torch.int32, device=dev) if sorted_ else None
+        _lib.check(lib.rap_build_attention_worklist(_lib.ptr(cud), nseg, 256, _lib.ptr(items), max_items, _lib.ptr(ws), stream(dev)), "worklist")
+        torch.cuda.synchronize()
+        it = items.cpu()
+        assert bool((it[n_items:] == 0).all()) and bool((it[:, 3] == 0).all())
+        got = [(int(a), int(b), int(c)) for a, b, c, _ in it[:n_items].tolist()]
+        assert len(set(got)) == n_items and set(got) == expect
+        seg_len = it[:n_items, 1]
+        if sorted_:
+            assert bool((seg_len[1:] <= seg_len[:-1]).all())
+            starts = it[:n_items, 0]
+            same = seg_len[1:] == seg_len[:-1]
+            assert bool((starts[1:][same] >= starts[:-1][same]).all())       # ties: segment order, a segment's items adjacent
+        else:
+            assert [x[0] for x in got] == sorted(x[0] for x in got)

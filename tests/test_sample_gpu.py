@@ -301,12 +301,24 @@ def test_sample_generations_selects_by_rigidity(dev):
     d = to_dev(inp, dev)
     flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=4, rigidity_forcing=False, n_generations=3)
     x1s = [torch.randn(inp["x_1"].shape, generator=torch.Generator().manual_seed(s)).to(dev) for s in (104, 109, 101)]
-    out = flow.sample_generations(d, x_1_list=x1s)
     g, _ = load_golden("selection_g3")
-    assert torch.equal(out["best_gen_indices"].cpu(), torch.from_numpy(g["avg_best_gen_indices"]))
-    ref = torch.from_numpy(g["avg_rigidity_rmse"])
-    assert ((out["rigidity_rmse"].cpu() - ref).abs() / ref).max().item() < 1e-4       # sampled on the GPU, not from the fixture
-    assert (out["pointclouds_selected"].cpu() - torch.from_numpy(g["avg_pointclouds_selected"])).abs().max().item() < 5e-5
+    outs = {}
+    for batched in (True, False):           # round 4: the G x B samples in ONE rap_sample call (default) vs the reference's loop
+        out = outs[batched] = flow.sample_generations(d, x_1_list=x1s, batch_generations=batched)
+        assert out["generations_in_one_call"] == batched
+        assert torch.equal(out["best_gen_indices"].cpu(), torch.from_numpy(g["avg_best_gen_indices"]))
+        ref = torch.from_numpy(g["avg_rigidity_rmse"])
+        assert ((out["rigidity_rmse"].cpu() - ref).abs() / ref).max().item() < 1e-4       # sampled on the GPU, not from the fixture
+        assert (out["pointclouds_selected"].cpu() - torch.from_numpy(g["avg_pointclouds_selected"])).abs().max().item() < 5e-5
+    a, b = outs[True], outs[False]
+    for ga, gb in zip(a["generations"], b["generations"]):                   # same samples either way (fp32 summation order only)
+        for k in ("end_point_trajectory", "trajectory", "R", "t"):
+            assert ga[k].shape == gb[k].shape and (ga[k] - gb[k]).abs().max().item() < 2e-5, k
+    # final-step criterion (modeling.py:501-504) through both paths
+    fa = flow.sample_generations(d, x_1_list=x1s, use_average_rigidity_rmse=False, batch_generations=True)
+    fb = flow.sample_generations(d, x_1_list=x1s, use_average_rigidity_rmse=False, batch_generations=False)
+    assert torch.equal(fa["best_gen_indices"], fb["best_gen_indices"])
+    assert ((fa["rigidity_rmse"] - fb["rigidity_rmse"]).abs() / fb["rigidity_rmse"]).max().item() < 1e-4
 
 
 # ---------------------------------------------------------------------------------------------
@@ -519,19 +531,44 @@ def test_few_token_split_attention_matches_unsplit(dev):
 
 
 def test_inconsistent_batch_is_reported_and_never_reads_out_of_bounds(dev):
-    """sum(points_per_part) != TP used to give out-of-bounds part offsets.  rap_sample now clamps the part table to TP
-    and rap_check_batch (on by DEFAULT since round 3; validate_inputs=False opts out) names the defect like the reference's
-    split_parts assert does (utils/point_clouds.py:41-44)."""
+    """sum(points_per_part) != TP used to give out-of-bounds part offsets.  rap_sample clamps the part table to TP and
+    rap_check_batch names the defect like the reference's split_parts assert does (utils/point_clouds.py:41-44).  Round 4: the
+    DEFAULT check is deferred (no host sync on the call path): the call returns, its poses and final clouds are NaN, and ValueError
+    is raised by synchronize() / check_pending() / the next sampling call; validate_inputs="eager" raises inside the call like the
+    reference; validate_inputs=False opts out."""
     cfg, sd, model = get_model(2, 0, dev)
     inp = S.make_inputs([[64, 96], [128, 40]], seed=3)
     d = to_dev(inp, dev)
     bad = dict(d); bad["points_per_part"] = d["points_per_part"].clone(); bad["points_per_part"][1, 1] += 50      # 50 points too many
-    strict = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=2, rigidity_forcing=True)      # the default checks
-    assert strict.validate_inputs
+    eager = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=2, rigidity_forcing=True, validate_inputs="eager")
     with pytest.raises(ValueError, match="inconsistent batch"):
-        strict.sample_and_register(bad, x_1=d["x_1"])
-    out = strict.sample_and_register(d, x_1=d["x_1"])                       # the consistent batch passes the check
+        eager.sample_and_register(bad, x_1=d["x_1"])
+    out = eager.sample_and_register(d, x_1=d["x_1"])                        # the consistent batch passes the check
     assert torch.isfinite(out["end_point_trajectory"]).all()
+
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=2, rigidity_forcing=True)         # the default
+    assert flow.validate_inputs == "deferred"
+    res = flow.sample_and_register(bad, x_1=d["x_1"])                       # returns: nothing on the call path reads the flag back
+    with pytest.raises(ValueError, match="inconsistent batch"):
+        flow.synchronize()
+    assert torch.isnan(res["R"]).all() and torch.isnan(res["t"]).all()      # ... and the results cannot be mistaken for poses
+    assert torch.isnan(res["end_point_trajectory"][-1]).all() and torch.isnan(res["trajectory"][-1]).all()
+    flow.synchronize()                                                      # reported once
+    res = flow.sample_and_register(bad, x_1=d["x_1"])
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="earlier call"):                   # the NEXT call reports it too (the verdict has arrived)
+        flow.sample_and_register(d, x_1=d["x_1"])
+    good = flow.sample_and_register(d, x_1=d["x_1"])
+    flow.synchronize()
+    assert torch.equal(good["end_point_trajectory"], out["end_point_trajectory"]) and torch.equal(good["R"], out["R"])
+    # concurrent shards: ONE check for the whole batch, every shard's results poisoned
+    multi = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=2, rigidity_forcing=True, num_streams=2)
+    res = multi.sample_and_register(bad, x_1=d["x_1"])
+    assert len(multi._pending) == 1
+    with pytest.raises(ValueError, match="inconsistent batch"):
+        multi.synchronize()
+    assert torch.isnan(res["R"]).all()
+
     lax = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=2, rigidity_forcing=True, validate_inputs=False)
     out_bad = lax.sample_and_register(bad, x_1=d["x_1"])                    # unchecked: runs on the clamped table, no fault
     torch.cuda.synchronize()
