@@ -20,8 +20,8 @@ Rank 0 prints ONE JSON line (contract in the task description) with two extra ob
                    157.3 TFLOP/s fp32 matrix peak of gfx950;
   cpu_baseline  -- the reference timed on this box's host cores in this run: the LIVE reference (unmodified modules under
                    /root/reference, kind "reference") when the mount exists, else the CPU oracle (restatement pinned to it, kind
-                   "port" -- the GPU box has no mount); a bounded sample: 1 pair, the first 1 and the first 3 of the 20 flow steps
-                   (two points -> a per-step slope and a fixed cost, extrapolated to 20 steps), or all 20 with --cpu-full.
+                   "port" -- the GPU box has no mount); a bounded sample: 1 pair, the first 2 of the 20 flow steps with the time taken at every
+                   step start (-> a per-step slope and a fixed cost, extrapolated to 20 steps), or all 20 with --cpu-full.
   ragged        -- the same path on a RAGGED packed batch in the reference's own regime (rap_amd.synthetic.ragged_regime_parts:
                    samples of 2 / 8 / 64 parts, 200 ... 20 000 points per part, ~262 k points, not a multiple of any tile), in fp32 and
                    bf16, with the same roofline object and the whole-call algorithmic TFLOP/s beside the uniform batch's.
@@ -140,7 +140,7 @@ def call_flops(parts, layers, flow_steps):
 def cpu_baseline(cfg, sd, args, gpu_first_step, full=False):
     """The reference on the host cores of THIS box in THIS run: 1 pair of the workload's geometry.
     With /root/reference mounted: the unmodified reference modules (kind "reference"); otherwise the pinned restatement (kind
-    "port").  Bounded sample: the first 1 and the first 3 flow steps -> per-step slope + fixed cost -> 20-step figure; --cpu-full
+    "port").  Bounded sample: the first 2 flow steps, timed per step -> per-step slope + fixed cost -> 20-step figure; --cpu-full
     times all steps.  Needs no GPU (tests/test_host_logic.py runs it on a tiny configuration)."""
     from oracle import rap_oracle as O
     from oracle import ref_loader
@@ -157,7 +157,7 @@ def cpu_baseline(cfg, sd, args, gpu_first_step, full=False):
     x_t0 = None           # x_t after flow step 0 (what both kinds can hand back)
     ref_first = None
     if live:
-        k = S_ if full else min(3, S_)
+        k = S_ if full else min(2, S_)
         r = ref_loader.reference_time_steps(cfg, sd, inp, S_, rigid, max_steps=None if full else k)
         st = r["step_start"]
         t1 = st[1] - st[0]
@@ -166,15 +166,14 @@ def cpu_baseline(cfg, sd, args, gpu_first_step, full=False):
         if r["result"] is not None:
             ref_first = r["result"]
     else:
-        k = S_ if full else min(3, S_)
-        t0 = time.perf_counter()
-        ref1 = O.sample(sd, cfg, inp, S_, rigid, max_steps=1)
-        t1 = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        refk = O.sample(sd, cfg, inp, S_, rigid, max_steps=k) if k > 1 else ref1
-        tk = time.perf_counter() - t0 if k > 1 else t1
-        x_t0 = ref1["trajectory"][0]
-        ref_first = ref1
+        k = S_ if full else min(2, S_)
+        st = []
+        refk = O.sample(sd, cfg, inp, S_, rigid, max_steps=k, step_hook=lambda: st.append(time.perf_counter()))
+        st.append(time.perf_counter())                  # end of the last timed step (incl. the final pose fit)
+        t1 = st[1] - st[0]
+        tk = st[-1] - st[0]
+        x_t0 = refk["trajectory"][0]
+        ref_first = refk
     if full:
         total, how = tk, f"all {S_} flow steps timed"
         slope = (tk - t1) / max(1, k - 1)
@@ -190,7 +189,7 @@ def cpu_baseline(cfg, sd, args, gpu_first_step, full=False):
            "implementation": ("unmodified reference modules under /root/reference (oracle/ref_loader.py; flash-attn / diffusers stand-ins)"
                               if live else "oracle/rap_oracle.py, the restatement pinned to the reference (/root/reference is not mounted on this box)"),
            "sample": f"1 pair ({args.views}x{args.points} pts) incl. per-step rigidity projection{'' if not full else ' and pose fit'}: {how}",
-           "steps_timed": k, "seconds_first_step": t1, "seconds_measured": (t1 + tk) if (not live and k > 1) else tk,
+           "steps_timed": k, "seconds_first_step": t1, "seconds_measured": tk,
            "seconds_per_flow_step": slope, "seconds_per_pair_all_steps": total, "extrapolated": not full}
     err = None
     if gpu_first_step is not None and x_t0 is not None:
@@ -420,16 +419,20 @@ def main():
             lib.rap_profile_reset(); lib.rap_profile_enable(1)
         t0 = time.perf_counter()
         enqueue = 0.0
+        first_enqueue = None
         for _ in range(steps):
             te = time.perf_counter()
             gathered, last = one_step()
             enqueue += time.perf_counter() - te      # host time to ENQUEUE one sample call (nothing in it synchronises)
+            if first_enqueue is None:
+                first_enqueue = time.perf_counter() - te     # the queue was empty (barrier above): pure enqueue cost of one call
         torch.cuda.synchronize()
         flow.check_pending()                          # deferred input validation: surface it here, outside the enqueue path
         local_elapsed = time.perf_counter() - t0          # this rank's own time, before the closing barrier
         barrier()
         elapsed = time.perf_counter() - t0
         run_mode.host_enqueue_ms = 1e3 * enqueue / steps
+        run_mode.host_first_enqueue_ms = 1e3 * first_enqueue
         run_mode.gather_ms = sum(a.elapsed_time(b) for a, b in ev_pairs[-steps:]) / steps if ev_pairs else 0.0
         run_mode.rank_elapsed = [local_elapsed]
         if distributed:
@@ -498,7 +501,7 @@ def main():
         }
 
     elapsed, prof, last = run_mode(args.dtype, args.steps, args.warmup)
-    host_enqueue_ms = run_mode.host_enqueue_ms
+    host_enqueue_ms, host_first_enqueue_ms = run_mode.host_enqueue_ms, run_mode.host_first_enqueue_ms
     prof_region_s, main_streams = run_mode.prof_region_s, run_mode.streams
     main_bounded = run_mode.bounded_launches
     main_rank_elapsed, main_gather_ms = list(run_mode.rank_elapsed), run_mode.gather_ms
@@ -608,6 +611,9 @@ def main():
         # host time spent INSIDE the sample call: ~3 300 launches at ~2.6 us each while the HIP queue has room (8.5 ms for a
         # single call), the GPU's own pace once the queue is full (the driver's 20-step run: the call blocks on queue slots)
         result["host_call_ms_per_step"] = host_enqueue_ms
+        # ... and of the FIRST timed call, which starts on an empty queue: what one call costs the host when nothing is ahead of it
+        # (no host synchronisation on the call path since round 4: the input check is deferred)
+        result["host_call_ms_first_timed_call"] = host_first_enqueue_ms
         result["rccl_ranks"] = world if distributed else 0        # ranks in the RCCL process group (0: single process, no group)
         result["pairs_total"] = len(parts) * world
         result["achieved_tflops_whole_call"] = uniform_call_flops * world * args.steps / elapsed / 1e12

@@ -312,11 +312,13 @@ def prepare_cu_seqlens(inputs):
 
 @torch.inference_mode()
 def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.float32,
-           max_steps: int | None = None, device=None):
+           max_steps: int | None = None, device=None, step_hook=None):
     """sample_rectified_flow + fit_transformations on the last end-point (modeling.py:356-391).
 
     ``max_steps`` (oracle-only convenience for the bounded CPU baseline): run only the first
     ``max_steps`` of ``num_steps`` flow steps (same dt and time grid).
+
+    ``step_hook`` (bench.py's CPU leg): called with no arguments at the start of every flow step (= every model call).
 
     ``device`` (tests only): run this same restatement on a GPU through PyTorch-ROCm (plain fp32 / fp64 torch ops; attention by
     ``_softmax_attention_chunked``, the 3 x 3 SVDs on the host) as the DEVICE-SIDE CHECKER for the configurations the CPU cannot
@@ -339,6 +341,8 @@ def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.
     call_count = [0]
 
     def fn(x, t):
+        if step_hook is not None:
+            step_hook()
         ts = torch.full((B,), t, dtype=dtype, device=device)                   # modeling.py:674
         is_last_call = (t < 1e-6) or (call_count[0] >= num_steps - 1)          # modeling.py:678
         if is_last_call and captured["features"] is None:                      # modeling.py:680-695

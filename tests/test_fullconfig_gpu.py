@@ -207,8 +207,9 @@ def test_ragged_regime_batch_on_the_padded_fast_path(dev):
     ref = None
     for dtype in ("float32", "bfloat16", "float16"):
         out, _ = _hip(cfg, sd, inp, 2, True, dev, dtype=dtype)
-        for buf in FM._WORKSPACES.values():
-            buf.fill_(0xFF)                                   # NaN in fp32, bf16 and fp16
+        with torch.inference_mode():                          # (the workspace tensors were allocated under inference_mode)
+            for buf in FM._WORKSPACES.values():
+                buf.fill_(0xFF)                               # NaN in fp32, bf16 and fp16
         torch.cuda.synchronize()
         again, _ = _hip(cfg, sd, inp, 2, True, dev, dtype=dtype)
         for k in ("end_point_trajectory", "trajectory", "R", "t"):

@@ -119,7 +119,7 @@ def test_shard_cuts_balance_tokens_at_sample_boundaries():
 def test_bench_cpu_baseline_times_the_live_reference_when_the_mount_exists():
     """bench.py's cpu_baseline leg (north_star: "the reference timed on the host cores of the same box in the
     same run"): with /root/reference mounted it times the UNMODIFIED reference modules (kind "reference"), otherwise the pinned port;
-    two timing points (1 and 3 flow steps) give a per-step slope.  Tiny configuration here (2 layers, 2 x 64 points, 6 steps)."""
+    the first 2 flow steps, timed per step, give a per-step slope.  Tiny configuration here (2 layers, 2 x 64 points, 6 steps)."""
     import types
     import torch
     import bench
@@ -135,7 +135,7 @@ def test_bench_cpu_baseline_times_the_live_reference_when_the_mount_exists():
     finally:
         torch.set_num_threads(nthreads)
     assert base["kind"] == ("reference" if ref_loader.reference_available() else "port")
-    assert base["steps_timed"] == 3 and base["extrapolated"] and not full["extrapolated"] and full["steps_timed"] == 6
+    assert base["steps_timed"] == 2 and base["extrapolated"] and not full["extrapolated"] and full["steps_timed"] == 6
     assert base["value"] > 0 and base["seconds_per_flow_step"] > 0 and base["nproc"] >= base["cores"] >= 1
     assert err is None
     assert base["seconds_per_pair_all_steps"] > 0 and full["seconds_per_pair_all_steps"] > 0       # (tiny sizes: no ratio claim)
