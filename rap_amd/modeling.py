@@ -95,6 +95,43 @@ class RectifiedPointFlow:
         self.num_streams = int(env) if env else num_streams
         self._aux_streams: dict = {}
 
+    # ---- the nn.Module surface the reference's checkpoint loader relies on (sample.py:57-59 -> utils/checkpoint.py:13-61:
+    # `load_checkpoint_for_module(model, ckpt_path)` reads ckpt["state_dict"] -- LightningModule keys, i.e. `flow_model.<name>` for
+    # the velocity network -- and calls `model.load_state_dict(state_dict, strict=False)`; then `model.eval()`) -------------------
+    _PREFIX = "flow_model."
+
+    def state_dict(self) -> dict:
+        return {self._PREFIX + k: v for k, v in self.flow_model.state_dict().items()}
+
+    def load_state_dict(self, state_dict: dict, strict: bool = True):
+        """LightningModule-keyed state dict -> the velocity network.  Keys under ``flow_model.`` go to ``PointCloudDiT``; anything
+        else (``feature_extractor.*`` of a checkpoint trained with the encoder, loss buffers) is reported as unexpected -- an error
+        with ``strict=True``, ignored with ``strict=False`` (what the reference's loader passes).  A bare ``{"state_dict": {...}}``
+        checkpoint dict is unwrapped.  Returns ``(missing_keys, unexpected_keys)`` like ``nn.Module.load_state_dict``."""
+        from .flow_model import _IncompatibleKeys
+        if "state_dict" in state_dict and isinstance(state_dict["state_dict"], dict):
+            state_dict = state_dict["state_dict"]
+        own = {k[len(self._PREFIX):]: v for k, v in state_dict.items() if k.startswith(self._PREFIX)}
+        foreign = [k for k in state_dict if not k.startswith(self._PREFIX)]
+        res = self.flow_model.load_state_dict(own, strict=False)
+        missing = [self._PREFIX + k for k in res.missing_keys]
+        unexpected = foreign + [self._PREFIX + k for k in res.unexpected_keys]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for RectifiedPointFlow: missing {missing[:4]}..., "
+                               f"unexpected {unexpected[:4]}...")
+        return _IncompatibleKeys(missing, unexpected)
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        self.flow_model.to(device)
+        return self
+
+    def cuda(self, device=None):
+        self.flow_model.cuda(device)
+        return self
+
     # modeling.py:203-231 without the boolean-mask compaction (which syncs): empty parts stay in the table as
     # zero-length segments, which every kernel treats as a no-op and which yields the same zero R,t rows.
     @staticmethod
