@@ -142,11 +142,15 @@ def _softmax_attention_chunked(q, k, v, max_score_elems: int = 1 << 28):
     which fused SDPA backend a GPU build of torch would pick.  q, k, v: (H, L, D)."""
     H, L, D = q.shape
     scale = 1.0 / math.sqrt(D)
+    # the softmax scale goes onto q before the product: for D = 64 it is 2^-3, an exact scaling of every product and partial sum,
+    # so (q * scale) k^T == (q k^T) * scale bit for bit -- and the (H, chunk, L) score block is written once instead of twice
+    qs = q * scale
     kt = k.transpose(1, 2)
     out = torch.empty_like(q)
     chunk = max(1, min(L, max_score_elems // max(1, H * L)))
     for a in range(0, L, chunk):
-        p = torch.softmax(torch.matmul(q[:, a:a + chunk], kt) * scale, dim=-1)
+        p = torch.matmul(qs[:, a:a + chunk], kt)
+        p = torch.softmax(p, dim=-1, out=p) if p.is_cuda else torch.softmax(p, dim=-1)
         out[:, a:a + chunk] = torch.matmul(p, v)
     return out
 
