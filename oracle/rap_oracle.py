@@ -149,8 +149,7 @@ def _softmax_attention_chunked(q, k, v, max_score_elems: int = 1 << 28):
     out = torch.empty_like(q)
     chunk = max(1, min(L, max_score_elems // max(1, H * L)))
     for a in range(0, L, chunk):
-        p = torch.matmul(qs[:, a:a + chunk], kt)
-        p = torch.softmax(p, dim=-1, out=p) if p.is_cuda else torch.softmax(p, dim=-1)
+        p = torch.softmax(torch.matmul(qs[:, a:a + chunk], kt), dim=-1)
         out[:, a:a + chunk] = torch.matmul(p, v)
     return out
 
