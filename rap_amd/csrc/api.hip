@@ -135,7 +135,6 @@ extern rap_tuning_t g_rap_attn_h16_variant;   // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_h16_persistent;   // gemm_h16.hip
 extern rap_tuning_t g_rap_attn_h16_dma;          // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_f32_persistent;   // gemm_f32.hip
-extern rap_tuning_t g_rap_gemm_h16_swap_epi;     // gemm_h16.hip
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 // Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
 // fp32 summation order -- 5 split-KV for few-token calls (fp32 attention), 6 split-K for few-row calls (fp32 GEMMs and the 16-bit
@@ -156,7 +155,6 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 11 && (value == 0 || value == 1)) { g_rap_gemm_h16_persistent = value; return RAP_OK; }
   if (key == 12 && (value == 0 || value == 1)) { g_rap_gemm_f32_persistent = value; return RAP_OK; }
   if (key == 13 && (value == 0 || value == 1)) { g_rap_attn_h16_dma = value; return RAP_OK; }
-  if (key == 14 && value >= 0 && value <= 7) { g_rap_gemm_h16_swap_epi = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 

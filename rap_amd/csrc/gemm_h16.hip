@@ -64,7 +64,7 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
         h2[j] = f32x2{acc[i][0][2 * j], acc[i][0][2 * j + 1]} + f32x2{bh, bh};
         g2[j] = f32x2{acc[i][1][2 * j], acc[i][1][2 * j + 1]} + f32x2{bg, bg};
       }
-      if (p.geglu_poly) geglu_pairs_poly<8>(h2, g2, o2); else geglu_pairs<8>(h2, g2, o2);
+      geglu_pairs<8>(h2, g2, o2);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(o2[j], typename H16<DT>::T2));   // one v_cvt_pk for both
@@ -277,118 +277,6 @@ __device__ __forceinline__ void gemm_h16_qknorm_epilogue(const GemmParamsH& p, f
         const typename H16<DT>::T8 o8 = h16_pack8<DT>(x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]);
         if (m < p.M) *reinterpret_cast<uint4*>(plane + (size_t)m * 64 + 32 * j + 16 * t + 8 * hi) = __builtin_bit_cast(uint4, o8);
       }
-    }
-  }
-}
-
-// ---------------- LDS-free epilogues on the SWAPPED product (round 4) ----------------
-// With C^T = W A^T (the weight fragment as the MFMA's A operand) acc[i][j][r] = C[mw + 32 i + l31][nw + 32 j + crow(r, hi)]: a lane owns
-// ONE token row and, of every 32 columns, the four groups of 4 consecutive columns {8 g + 4 hi .. +3}.  One v_permlane32_swap per value
-// pair hands group 2t+1 of the lower half-wave to the upper one and group 2t back, after which a lane holds 8 CONSECUTIVE columns
-// (16 t + 8 hi .. +7) of its row: the 16-bit result leaves as one 16-byte store, the fp16 residual arrives as one 16-byte load, and
-// nothing goes through the LDS -- the transposition slab of gemm_h16_epilogue costs 128 ds_write_b32 + 32 ds_read_b128 per wave and
-// tile, ~4 000 LDS cycles per CU and tile that no MFMA overlaps (the epilogue is 3.6-4.4 us of an 18-21 us tile period,
-// profiles/r03_c13_gemm_ts_persistent.jsonl).  Same arithmetic in the same order as the slab form: (acc + bias) + residual, one rounding.
-// FULL = every row of the tile exists (the persistent kernel: M % 256 == 0): rows are addressed as a wave-uniform base plus ONE 32-bit
-// per-lane byte offset that is formed inside the epilogue (behind an opaque asm, so that hipcc does not hoist sixteen 64-bit per-lane
-// addresses out of the persistent tile loop and spill them); otherwise rows are clamped / masked against M.
-template <int DT, int TM, bool FULL>
-__device__ __forceinline__ void gemm_h16_resid_h16_epilogue_swp(const GemmParamsH& p, f32x16 (&acc)[TM][2], int mw, int nw, int lane) {
-  const int hi = lane >> 5, l31 = lane & 31;
-  u16* C = reinterpret_cast<u16*>(p.C);
-  int lrow = l31;
-  if (FULL) asm volatile("" : "+v"(lrow));
-  const unsigned roff = (unsigned)(lrow * p.ldr + 8 * hi) * 2u, coff = (unsigned)(lrow * p.ldc + 8 * hi) * 2u;
-  const unsigned char* rbase = reinterpret_cast<const unsigned char*>(p.resid_h + (size_t)mw * p.ldr + nw);
-  unsigned char* cbase = reinterpret_cast<unsigned char*>(C + (size_t)mw * p.ldc + nw);
-  // piece (j, t) = columns nw + 32 j + 16 t + 8 hi .. +7 of the lane's row.  Request order = consumption order (vmcnt retires loads
-  // in order): the (L2-hot) bias of all four pieces first, then the residual pieces piece-major, so piece (0, 0) starts when the
-  // first four residual loads have landed and every later piece waits with its own count.
-  float4 bb[2][2][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float* bp = p.bias + nw + 32 * j + 16 * t + 8 * hi;
-      bb[j][t][0] = p.bias ? *reinterpret_cast<const float4*>(bp) : float4{0.f, 0.f, 0.f, 0.f};
-      bb[j][t][1] = p.bias ? *reinterpret_cast<const float4*>(bp + 4) : float4{0.f, 0.f, 0.f, 0.f};
-    }
-  uint4 rr[TM][2][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        int m = mw + 32 * i + l31;
-        m = m < p.M ? m : p.M - 1;
-        if (FULL) rr[i][j][t] = *reinterpret_cast<const uint4*>(rbase + (size_t)((32 * i) * p.ldr + 32 * j + 16 * t) * 2 + roff);
-        else rr[i][j][t] = *reinterpret_cast<const uint4*>(p.resid_h + (size_t)m * p.ldr + nw + 32 * j + 16 * t + 8 * hi);
-      }
-  __builtin_amdgcn_sched_barrier(0);        // all 24 requests are in flight before the first value is touched
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float bl[8] = {bb[j][t][0].x, bb[j][t][0].y, bb[j][t][0].z, bb[j][t][0].w, bb[j][t][1].x, bb[j][t][1].y, bb[j][t][1].z, bb[j][t][1].w};
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = mw + 32 * i + l31;
-        float x[4], y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * t + e]), __float_as_uint(acc[i][j][8 * t + 4 + e]), false, false);
-          x[e] = __uint_as_float(s2[0]); y[e] = __uint_as_float(s2[1]);
-        }
-        float rv[8];
-        h16_unpack8<RAP_DT_F16>(rr[i][j][t], rv);
-        const typename H16<RAP_DT_F16>::T8 o8 = f16_pack8_sat((x[0] + bl[0]) + rv[0], (x[1] + bl[1]) + rv[1], (x[2] + bl[2]) + rv[2], (x[3] + bl[3]) + rv[3],
-                                                             (y[0] + bl[4]) + rv[4], (y[1] + bl[5]) + rv[5], (y[2] + bl[6]) + rv[6], (y[3] + bl[7]) + rv[7]);
-        if (FULL) *reinterpret_cast<uint4*>(cbase + (size_t)((32 * i) * p.ldc + 32 * j + 16 * t) * 2 + coff) = __builtin_bit_cast(uint4, o8);
-        else if (m < p.M) *reinterpret_cast<uint4*>(C + (size_t)m * p.ldc + nw + 32 * j + 16 * t + 8 * hi) = __builtin_bit_cast(uint4, o8);
-      }
-    }
-  }
-}
-
-// GEGLU on the swapped product: value (j = 0) and gate (j = 1) of an output sit in the same register of the same lane, as before; the
-// lane's 16 outputs of a row (columns (nw >> 1) + crow(r, hi)) leave as two 16-byte stores after the same half-wave exchange.
-template <int DT, int TM>
-__device__ __forceinline__ void gemm_h16_geglu_epilogue_swp(const GemmParamsH& p, f32x16 (&acc)[TM][2], int mw, int nw, int lane) {
-  const int hi = lane >> 5, l31 = lane & 31;
-  u16* C = reinterpret_cast<u16*>(p.C);
-  // bias of the lane's own columns: register r <-> column crow(r, hi) = 8 (r >> 2) + 4 hi + (r & 3)
-  f32x2 bh[8], bg[8];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float4 vh = p.bias ? *reinterpret_cast<const float4*>(p.bias + nw + 8 * g + 4 * hi) : float4{0.f, 0.f, 0.f, 0.f};
-    const float4 vg = p.bias ? *reinterpret_cast<const float4*>(p.bias + nw + 32 + 8 * g + 4 * hi) : float4{0.f, 0.f, 0.f, 0.f};
-    bh[2 * g] = f32x2{vh.x, vh.y}; bh[2 * g + 1] = f32x2{vh.z, vh.w};
-    bg[2 * g] = f32x2{vg.x, vg.y}; bg[2 * g + 1] = f32x2{vg.z, vg.w};
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    f32x2 h2[8], g2[8], o2[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      h2[k] = f32x2{acc[i][0][2 * k], acc[i][0][2 * k + 1]} + bh[k];
-      g2[k] = f32x2{acc[i][1][2 * k], acc[i][1][2 * k + 1]} + bg[k];
-    }
-    if (p.geglu_poly) geglu_pairs_poly<8>(h2, g2, o2); else geglu_pairs<8>(h2, g2, o2);
-    const int m = mw + 32 * i + l31;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      // group 2t = registers 8t .. 8t+3 = o2[4t], o2[4t+1]; group 2t+1 = registers 8t+4 .. 8t+7 = o2[4t+2], o2[4t+3]
-      const float gx[4] = {o2[4 * t].x, o2[4 * t].y, o2[4 * t + 1].x, o2[4 * t + 1].y};
-      const float gy[4] = {o2[4 * t + 2].x, o2[4 * t + 2].y, o2[4 * t + 3].x, o2[4 * t + 3].y};
-      float x[4], y[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(gx[e]), __float_as_uint(gy[e]), false, false);
-        x[e] = __uint_as_float(s2[0]); y[e] = __uint_as_float(s2[1]);
-      }
-      const typename H16<DT>::T8 o8 = h16_pack8<DT>(x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]);
-      if (m < p.M) *reinterpret_cast<uint4*>(C + (size_t)m * p.ldc + (nw >> 1) + 16 * t + 8 * hi) = __builtin_bit_cast(uint4, o8);
     }
   }
 }
@@ -648,8 +536,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   // then owns one token row and 16 of every 32 columns, so the row norm of a head is lane-local up to one lane^32 exchange and the
   // 16-bit results leave as 16-byte row pieces without an LDS transpose.  The v tiles keep the normal order (the V^T image wants a
   // lane to own a column).  Wave-uniform choice: a 64-column wave tile is one head of q, k or v.
-  const bool swp = (EPI == EPI_H_QKV_NORM && (n0 + wc * 64) < 2 * p.heads * 64) ||
-                   ((EPI == EPI_H_BIAS_RESID_H16 || EPI == EPI_H_GEGLU) && p.swap_epi);
+  const bool swp = EPI == EPI_H_QKV_NORM && (n0 + wc * 64) < 2 * p.heads * 64;
   // SWP is a compile-time property of the k-loop COPY that runs (round 4, as in the persistent kernel below): as a run-time flag inside
   // the phases the accumulators of the two alternatives are reconciled with register copies at every phase and the kernel spilled
   // (44 bytes of scratch in the <EPI_H_QKV_NORM> instantiations).
@@ -714,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
       PH_BAR
     }
   };
-  if constexpr (EPI == EPI_H_QKV_NORM || EPI == EPI_H_BIAS_RESID_H16 || EPI == EPI_H_GEGLU) {
+  if constexpr (EPI == EPI_H_QKV_NORM) {
     if (swp) k_tiles(std::true_type{}); else k_tiles(std::false_type{});
   } else {
     k_tiles(std::false_type{});
@@ -727,12 +614,6 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   if constexpr (EPI == EPI_H_QKV_NORM) {
     if (swp) gemm_h16_qknorm_epilogue<DT, TM>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
     else gemm_h16_epilogue<EPI_H_QKV, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
-  } else if constexpr (EPI == EPI_H_BIAS_RESID_H16) {
-    if (swp) gemm_h16_resid_h16_epilogue_swp<DT, TM, false>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-    else gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
-  } else if constexpr (EPI == EPI_H_GEGLU) {
-    if (swp) gemm_h16_geglu_epilogue_swp<DT, TM>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-    else gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
   } else {
     gemm_h16_epilogue<EPI, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
   }
@@ -777,10 +658,7 @@ static int launch_ph(hipStream_t stream, const GemmParamsH& p) {
 // epilogue (7.4 with the residual's HBM latency; GEGLU is VALU-bound: the younger wave of each SIMD finishes 2.5 us after the older) +
 // 0.5-0.8 us of turn-around.  Starting every other block half a period late (so that the CUs do not store in lockstep) changes nothing (+-1 %).
 // ---------------------------------------------------------------------------------------------
-// SWE (EPI_H_BIAS_RESID_H16 / EPI_H_GEGLU only): this instantiation runs the swapped product with the LDS-free epilogue (tuning key 14);
-// a compile-time property so that a kernel holds ONE k-loop copy and ONE epilogue (with both in one kernel the fp16-residual
-// instantiation spilled 172 bytes).
-template <int EPI, int DT, bool SWE = false>
+template <int EPI, int DT>
 __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
   typedef typename H16<DT>::T8 T8;
   constexpr int TM = 4;
@@ -894,7 +772,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
     const int vn = v + (int)gridDim.x;
     const bool has_next = vn < total;
     if (has_next) tile_bases(vn, a_nxt, w_nxt, m0n, n0n);
-    const bool swp = (EPI == EPI_H_QKV_NORM && (n0 + wc * 64) < 2 * p.heads * 64) || SWE;
+    const bool swp = EPI == EPI_H_QKV_NORM && (n0 + wc * 64) < 2 * p.heads * 64;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -951,7 +829,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
     if constexpr (EPI == EPI_H_QKV_NORM) {
       if (swp) k_tiles(std::true_type{}); else k_tiles(std::false_type{});
     } else {
-      k_tiles(std::integral_constant<bool, SWE>{});
+      k_tiles(std::false_type{});
     }
     PHP_TS(1)
     if (wr == 0) { PH_BAR }                      // equal barrier counts for both wave rows
@@ -966,10 +844,6 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
       if constexpr (EPI == EPI_H_QKV_NORM) {
         if (swp) gemm_h16_qknorm_epilogue<DT, TM>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
         else gemm_h16_epilogue<EPI_H_QKV, DT, TM>(p, acc, slab, m0 + wr * 128, n0 + wc * 64, lane);
-      } else if constexpr (EPI == EPI_H_BIAS_RESID_H16 && SWE) {
-        gemm_h16_resid_h16_epilogue_swp<DT, TM, true>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
-      } else if constexpr (EPI == EPI_H_GEGLU && SWE) {
-        gemm_h16_geglu_epilogue_swp<DT, TM>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
       } else {
         gemm_h16_epilogue<EPI, DT, TM>(p, acc, slab, m0 + wr * 128, n0 + wc * 64, lane);
       }
@@ -987,10 +861,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
   }
 }
 
-template <int EPI, int DT, bool SWE = false>
+template <int EPI, int DT>
 static int launch_php(hipStream_t stream, const GemmParamsH& p) {
   constexpr int LDS = 4 * 256 * 128 + 32768;
-  auto kern = gemm_h16_php_kernel<EPI, DT, SWE>;
+  auto kern = gemm_h16_php_kernel<EPI, DT>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
     rap_set_last_hip_error((int)hipGetLastError());
     return RAP_ERR_HIP;
@@ -1017,11 +891,7 @@ static int launch_php(hipStream_t stream, const GemmParamsH& p) {
 // 128 x 128 kernel, two blocks per CU.
 // RAP_ABLATION_BUILD only: rap_set_tuning(2, 0) forces the 128 x 128 kernel, (2, 1) the two-stage 256 x 256 kernel.
 rap_tuning_t g_rap_gemm_h16_variant = 14;
-rap_tuning_t g_rap_gemm_h16_persistent = 1;
-// tuning key 14: bit 0 = the fp16-residual GEMMs, bit 1 = the GEGLU GEMM run the swapped product with the LDS-free epilogues above
-// (phase-split kernels only; 0 = the transposition-slab epilogues); bit 2 = GEGLU's Phi by the transcendental-free polynomial
-// (half.h geglu_pairs_poly; 0 = the erfc form).  Default set by measurement.
-rap_tuning_t g_rap_gemm_h16_swap_epi = 7;     // tuning key 11: the persistent phase-split kernel for full-tile shapes (1, default) or one tile per block (0)
+rap_tuning_t g_rap_gemm_h16_persistent = 1;     // tuning key 11: the persistent phase-split kernel for full-tile shapes (1, default) or one tile per block (0)
 
 template <int EPI, int DT, int WM, int WN, int TM, int TN>
 static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
@@ -1132,12 +1002,7 @@ static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
 #endif
   // persistent form when every row tile is full and there are at least two rounds of tiles for a 256-CU part; the one-tile-per-block
   // form for ragged M (it clamps rows) and for few tiles
-  if (big && use_persistent(p)) {
-    if constexpr (EPI == EPI_H_BIAS_RESID_H16 || EPI == EPI_H_GEGLU) {
-      if (p.swap_epi) return launch_php<EPI, DT, true>(stream, p);
-    }
-    return launch_php<EPI, DT>(stream, p);
-  }
+  if (big && use_persistent(p)) return launch_php<EPI, DT>(stream, p);
   // fewer 256 x 256 tiles than CUs (few-token calls): 128 x 128 tiles, two blocks per CU, fill the chip better -- one pair of
   // 2 x 1024 points x 10 steps 26.6 -> 21.6 ms in bf16, 2 x 4096 x 20 steps 102.5 -> 94.0 ms, unchanged from 4 pairs up (r03 call 31)
   if (big && (long)((p.M + 255) / 256) * (p.N / 256) >= 256) return launch_ph<EPI, DT, 0, 1>(stream, p);
@@ -1171,11 +1036,7 @@ static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
   }
 }
 
-int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p_in) {
-  GemmParamsH p = p_in;
-  const int sw = g_rap_gemm_h16_swap_epi;
-  p.geglu_poly = (sw & 4) ? 1 : 0;
-  p.swap_epi = (epilogue == EPI_H_BIAS_RESID_H16 && (sw & 1) && (p.ldc & 7) == 0 && (p.ldr & 7) == 0) || (epilogue == EPI_H_GEGLU && (sw & 2) && (p.ldc & 7) == 0);
+int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p) {
   if (p.M <= 0) return RAP_OK;
   if (p.N % 128 != 0 || p.K % 64 != 0 || p.K <= 0) return RAP_ERR_INVALID;      // K % 64: two 32-wide ring slices / one 64-wide tile
   if ((p.lda & 7) || (p.ldw & 7)) return RAP_ERR_INVALID;

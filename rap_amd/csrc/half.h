@@ -119,35 +119,3 @@ __device__ __forceinline__ void geglu_pairs(const f32x2 (&h)[NP], const f32x2 (&
   for (int i = 0; i < NP; ++i) o[i] = h[i] * (g[i] * q[i]);
 }
 
-// GEGLU with NO transcendental (round 4, 16-bit GEMM epilogues only; tuning key 14 bit 2): the epilogue of the largest GEMM of a layer is
-// VALU-bound, and of the ~128 issue cycles geglu_pairs spends per output pair, 64 are its two v_exp_f32 and two v_rcp_f32 (quarter
-// rate).  Here Phi(g) = 1/2 + xc * Q(s) with xc = clamp(g / sqrt 2, -3.5, 3.5), s = 2 xc^2 / 3.5^2 - 1 in [-1, 1] and Q the degree-11
-// least-squares fit of erf(x) / (2 x) in s at 600 Chebyshev nodes (erf(3.5) = 1 - 7.4e-7): |Phi - Phi_exact| <= 1.7e-6 for every g in
-// fp32 evaluation, three orders of magnitude below one rounding of the 16-bit output it feeds (2^-9 bf16, 2^-12 fp16); the fp32 path
-// keeps the 1.5e-7 erfc form.  14 packed FMAs / multiplies and two v_med3 per pair.
-template <int NP>
-__device__ __forceinline__ void geglu_pairs_poly(const f32x2 (&h)[NP], const f32x2 (&g)[NP], f32x2 (&o)[NP]) {
-  constexpr float Q[12] = {2.0193609343e-01f, -1.0035007483e-01f, 7.3403344014e-02f, -5.7316738324e-02f, 4.3876643258e-02f, -3.2318995527e-02f,
-                           2.3869900106e-02f, -1.5186448232e-02f, 5.9404096164e-03f, -3.4244285419e-03f, 4.4964669270e-03f, -2.0694967289e-03f};
-  f32x2 xc[NP], sv[NP], acc[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const f32x2 x = g[i] * f32x2{0.70710678118654752440f, 0.70710678118654752440f};
-    xc[i] = f32x2{__builtin_amdgcn_fmed3f(x.x, -3.5f, 3.5f), __builtin_amdgcn_fmed3f(x.y, -3.5f, 3.5f)};
-  }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) sv[i] = __builtin_elementwise_fma(xc[i] * xc[i], f32x2{2.0f / 12.25f, 2.0f / 12.25f}, f32x2{-1.0f, -1.0f});
-#pragma unroll
-  for (int i = 0; i < NP; ++i) acc[i] = __builtin_elementwise_fma(sv[i], f32x2{Q[11], Q[11]}, f32x2{Q[10], Q[10]});
-#pragma unroll
-  for (int k = 9; k >= 0; --k) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) acc[i] = __builtin_elementwise_fma(sv[i], acc[i], f32x2{Q[k], Q[k]});
-  }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const f32x2 phi = __builtin_elementwise_fma(xc[i], acc[i], f32x2{0.5f, 0.5f});
-    o[i] = h[i] * (g[i] * phi);
-  }
-}
-

@@ -133,8 +133,6 @@ struct GemmParamsH {
   // gemm_h16_splits() > 1, K is split over that many blocks per 128 x 128 tile (gridDim.y) writing fp32 partial tiles to splitk_ws, and a
   // combine pass forms residual + (bias + partials) in a fixed order (deterministic; differs from the unsplit sum in fp32 rounding only)
   float* splitk_ws = nullptr;
-  int swap_epi = 0;   // set by launch_gemm_h16 (tuning key 14): this launch runs the swapped product with the LDS-free epilogue
-  int geglu_poly = 0; // set by launch_gemm_h16 (tuning key 14 bit 2): GEGLU's Phi by the transcendental-free polynomial
 };
 // 1 = no split; 2 or 4 for GEMMs with K >= 1024 whose 128 x 128 tile grid covers at most a quarter / half of the CUs (tuning key 6)
 int gemm_h16_splits(int M, int N, int K);

@@ -1,7 +1,5 @@
 #!/usr/bin/env python3
-"""Every epilogue of the 16-bit GEMM at the model's shapes (TP = 262144 tokens): the persistent kernel with the transposition-slab
-epilogues (rap_set_tuning key 14 = 0), with the LDS-free swapped-product epilogues (3) and with the transcendental-free GEGLU on top
-(7, round 4); one tile per block (key 11 = 0) for reference."""
+"""Every epilogue of the 16-bit GEMM at the model's shapes (TP = 262144 tokens), persistent kernel on / off (rap_set_tuning key 11)."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,11 +27,11 @@ for name, epi, N, K in (("qkv + qk-norm", 5, 1536, 512), ("out-proj fp16 stream"
         resid = C if epi in (1, 7) else None
         fn = lambda: lib.rap_gemm_h16(dt, epi, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(C), Cw, TP, N, K, _lib.ptr(bias), _lib.ptr(resid), Cw if resid is not None else 0, 0, _lib.ptr(None), 0, st())  # noqa: E731
     row = {"gemm": name, "N": N, "K": K}
-    for tag, k11, k14 in (("slab_epilogue", 1, 0), ("swapped_epilogue", 1, 3), ("swapped_poly_geglu", 1, 7), ("slab_poly_geglu", 1, 4), ("one_tile_per_block", 0, 7)):
-        assert lib.rap_set_tuning(11, k11) == 0 and lib.rap_set_tuning(14, k14) == 0
+    for pz in (1, 0):
+        assert lib.rap_set_tuning(11, pz) == 0
         assert fn() == 0
         t = timeit(lambda: fn(), iters=10, warm=3)
-        row[tag + "_ms"] = round(t * 1e3, 4)
-        row[tag + "_tflops"] = round(2.0 * TP * N * K / t / 1e12, 1)
-    assert lib.rap_set_tuning(11, 1) == 0 and lib.rap_set_tuning(14, 7) == 0
+        row["persistent_ms" if pz else "one_tile_per_block_ms"] = round(t * 1e3, 4)
+        row["persistent_tflops" if pz else "one_tile_per_block_tflops"] = round(2.0 * TP * N * K / t / 1e12, 1)
+    assert lib.rap_set_tuning(11, 1) == 0
     print(json.dumps(row), flush=True)

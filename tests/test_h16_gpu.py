@@ -744,41 +744,3 @@ def test_few_token_split_k_model_path_agrees_with_the_unsplit_one(name, dev):
     assert not torch.isnan(outs[1]).any()
     assert e_on < FWD_REL_BOUND["bfloat16"] and e_off < FWD_REL_BOUND["bfloat16"]
     assert between < FWD_REL_BOUND["bfloat16"]
-
-
-@pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("M", [65536, 3000])
-def test_swapped_product_epilogues_equal_the_slab_epilogues(lib, dev, dt, M):
-    """Round 4 (tuning key 14): the fp16-residual GEMMs and the GEGLU GEMM run the swapped product C^T = W A^T with LDS-free epilogues
-    (a lane owns a row; 16-byte row pieces after one half-wave exchange).  Same MFMA products in the same k order, same epilogue
-    arithmetic in the same order: BIT-identical to the transposition-slab epilogues, on the persistent kernel (M = 65 536) and on the
-    one-tile kernel with a ragged last tile (M = 3 000).  The transcendental-free GEGLU polynomial (bit 2) is a different
-    approximation of the same Phi: within one rounding of the 16-bit output of the erfc form."""
-    g = torch.Generator(device=dev).manual_seed(7 + M)
-    K = 512
-    A = to_h(torch.randn(M, K, device=dev, generator=g), dt)
-    outs = {}
-    try:
-        for key in (0, 3, 7):
-            assert lib.rap_set_tuning(14, key) == 0
-            # fp16-residual GEMM (out-projection shape), in place
-            W = to_h(torch.randn(512, K, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) / K ** 0.5, dt)
-            bias = torch.randn(512, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
-            h = (torch.randn(M, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 3).to(torch.float16)
-            gemm_h(lib, dev, dt, 7, A, W, h, M, 512, K, bias=bias, resid=h)
-            # GEGLU GEMM (ff1 shape, value / gate interleaved rows)
-            W1 = to_h(torch.randn(4096, K, device=dev, generator=torch.Generator(device=dev).manual_seed(4)) / K ** 0.5, dt)
-            b1 = torch.randn(4096, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
-            C1 = torch.empty(M, 2048, device=dev, dtype=TORCH_DT[dt])
-            gemm_h(lib, dev, dt, 3, A, W1, C1, M, 4096, K, bias=b1, ldc=2048)
-            outs[key] = (h.clone(), C1.clone())
-    finally:
-        assert lib.rap_set_tuning(14, 7) == 0
-    assert torch.equal(outs[0][0].view(torch.int16), outs[3][0].view(torch.int16))       # residual epilogue: bit-identical
-    assert torch.equal(outs[0][1].view(torch.int16), outs[3][1].view(torch.int16))        # GEGLU, same Phi: bit-identical
-    assert torch.equal(outs[3][0].view(torch.int16), outs[7][0].view(torch.int16))
-    a = outs[3][1].double(); b = outs[7][1].double()
-    rel = ((a - b).abs() / (a.abs() + 1e-2)).max().item()
-    assert rel < 1.01 * ULP[dt], rel                                                      # polynomial Phi: at most the neighbouring value
-    assert (a != b).double().mean().item() < 0.02                                         # ... and almost everywhere the same value
-
