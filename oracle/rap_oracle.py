@@ -129,10 +129,33 @@ def varlen_attention(qkv: torch.Tensor, cu_seqlens: torch.Tensor) -> torch.Tenso
             continue
         q, k, v = (qkv[a:b, i].transpose(0, 1) for i in range(3))
         if qkv.is_cuda:
-            out[a:b] = _softmax_attention_chunked(q, k, v).transpose(0, 1)
+            out[a:b] = _device_attention(q, k, v).transpose(0, 1)
         else:
             out[a:b] = F.scaled_dot_product_attention(q, k, v).transpose(0, 1)
     return out
+
+
+_DEVICE_SDPA = {"ok": None}
+
+
+def _device_attention(q, k, v):
+    """Attention of the DEVICE-side checker (tests only).  torch's memory-efficient SDPA kernel evaluates fp32 attention without
+    materialising the score matrix -- measured on MI355X (profiles/r04_c2_device_checker_sdpa_probe.jsonl): 88 ms vs 199 ms for one
+    8 x 65 536 x 64 problem, 3.0e-7 vs 2.8e-7 from fp64 -- which halves the time of the full-configuration parity tests.  Used when
+    this torch build has it for the dtype (fp32; the flash backend is 16-bit only), else the explicit chunked form below; either way
+    the device evaluation is pinned to the CPU one by tests/test_fullconfig_gpu.py::test_device_oracle_equals_cpu_oracle."""
+    if _DEVICE_SDPA["ok"] is not False and q.dtype == torch.float32:
+        try:
+            from torch.nn.attention import SDPBackend, sdpa_kernel
+            with sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION]):
+                o = F.scaled_dot_product_attention(q[None], k[None], v[None])[0]
+            _DEVICE_SDPA["ok"] = True
+            return o
+        except (RuntimeError, ImportError):
+            if _DEVICE_SDPA["ok"]:          # worked before: this shape is the problem (e.g. a length the kernel rejects)
+                return _softmax_attention_chunked(q, k, v)
+            _DEVICE_SDPA["ok"] = False
+    return _softmax_attention_chunked(q, k, v)
 
 
 def _softmax_attention_chunked(q, k, v, max_score_elems: int = 1 << 28):
