@@ -387,6 +387,7 @@ int rap_profile_enable(int on);
  *          its XCD's tiles; full-tile shapes only)
  *   key 12 persistent fp32 GEMM (same, 256 x 256 kernel)  {1 (default), 0 = one tile per block}              fp32 path
  *   key 13 16-bit attention: K / V^T tiles by LDS-DMA      {1 (default), 0 = staged through registers}       16-bit path
+ *   key 15 attention work lists of rap_sample / forward    {1 (default): longest segment first, 0: segment order}   both precisions
  * Any other key returns RAP_ERR_INVALID.  (Keys 0-4 selected among the kernel variants of the round-1/2 experiments; those variants
  * are no longer in the tree, and what is left of the switch exists only in a library built with -DRAP_ABLATION_BUILD.) */
 int rap_set_tuning(int32_t key, int32_t value);

@@ -135,11 +135,12 @@ extern rap_tuning_t g_rap_attn_h16_variant;   // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_h16_persistent;   // gemm_h16.hip
 extern rap_tuning_t g_rap_attn_h16_dma;          // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_f32_persistent;   // gemm_f32.hip
+rap_tuning_t g_rap_attn_lpt = 1;               // tuning key 15: attention work lists longest-segment-first (1, default) or in segment order (0)
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 // Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
 // fp32 summation order -- 5 split-KV for few-token calls (fp32 attention), 6 split-K for few-row calls (fp32 GEMMs and the 16-bit
 // residual GEMMs), 7 fused qk-norm, 9 GEGLU's Phi by the
-// 1.5e-7 erfc polynomial (1) or erff (0), 11 / 12 persistent 16-bit / fp32 GEMM.  Keys 0-4 (kernel-variant A/B of the round-1/2 experiments) exist
+// 1.5e-7 erfc polynomial (1) or erff (0), 11 / 12 persistent 16-bit / fp32 GEMM, 15 the order of the attention work lists (identical results).  Keys 0-4 (kernel-variant A/B of the round-1/2 experiments) exist
 // only in a library built with -DRAP_ABLATION_BUILD; the shipped library refuses them.
 extern "C" int rap_set_tuning(int32_t key, int32_t value) {
 #ifdef RAP_ABLATION_BUILD
@@ -155,6 +156,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 11 && (value == 0 || value == 1)) { g_rap_gemm_h16_persistent = value; return RAP_OK; }
   if (key == 12 && (value == 0 || value == 1)) { g_rap_gemm_f32_persistent = value; return RAP_OK; }
   if (key == 13 && (value == 0 || value == 1)) { g_rap_attn_h16_dma = value; return RAP_OK; }
+  if (key == 15 && (value == 0 || value == 1)) { g_rap_attn_lpt = value; return RAP_OK; }
   return RAP_ERR_INVALID;
 }
 
@@ -446,8 +448,9 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
   int rc;
   if ((rc = launch_token_sample(stream, cu_batch, B, w.token_sample))) return rc;
   const int bq = m->dtype == RAP_DT_F32 ? 0 : attention_h16_block_queries(m->dtype);
-  if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch, bq, w.attn_sort))) return rc;
-  if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part, bq, w.attn_sort))) return rc;
+  int32_t* sort_ws = g_rap_attn_lpt ? w.attn_sort : nullptr;
+  if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch, bq, sort_ws))) return rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part, bq, sort_ws))) return rc;
   // Filler rows TP .. TQ-1 (TQ = align_up(TP, 256), see carve_workspace): every value a layer kernel reads there has to be FINITE,
   // because the 16-bit attention's V^T image is blocked by 64 tokens and a masked key still multiplies its V column by p = 0
   // (0 x NaN = NaN).  Zero the filler rows of the four buffers no kernel writes beyond row TP -- the step-invariant embedding

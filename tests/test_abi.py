@@ -112,7 +112,7 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
     # production switches accept {0, 1} only
     for key in (0, 1, 2, 3, 4, 8, 10, 14, -1):
         assert lib.rap_set_tuning(key, 1) == -1 and lib.rap_set_tuning(key, 0) == -1, key
-    for key in (5, 6, 7, 9, 11, 12, 13):
+    for key in (5, 6, 7, 9, 11, 12, 13, 15):
         assert lib.rap_set_tuning(key, 2) == -1 and lib.rap_set_tuning(key, 1) == 0, key
     assert lib.rap_model_bounded_attention_launches(N) < 0
 

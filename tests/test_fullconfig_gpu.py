@@ -2,8 +2,8 @@
 
 The CPU reference cannot produce these cases in test time (one 2 x 4096 pair costs 854 s of CPU, two steps of configs[4] 4 185 s), so
 the checker here is the SAME restatement the CPU tests pin to the unmodified reference (`oracle/rap_oracle.py`), evaluated on the
-MI355X through PyTorch-ROCm in fp32 (`O.sample(..., device="cuda")`: plain torch ops, attention as explicit matmul + softmax in
-query chunks, the 3 x 3 SVDs on the host LAPACK).  The chain is closed by `test_device_oracle_equals_cpu_oracle`:
+MI355X through PyTorch-ROCm in fp32 (`O.sample(..., device="cuda")`: plain torch ops, attention by torch's fp32 memory-efficient
+SDPA kernel -- or explicit matmul + softmax in query chunks where a build lacks it -- the 3 x 3 SVDs on the host LAPACK).  The chain is closed by `test_device_oracle_equals_cpu_oracle`:
 
     unmodified reference (CPU)  ==  oracle on CPU  (tests/test_oracle.py, <= 5e-6, run in the build container + golden fixtures)
     oracle on CPU               ==  oracle on the GPU   (here, <= 5e-6, same seeded inputs as the golden l2_ragged_rigid)
@@ -197,7 +197,8 @@ def test_ragged_regime_batch_on_the_padded_fast_path(dev):
     uniform one.  A ragged reference-regime batch (~70 k points in samples of 2 / 8 / 64 parts, not a multiple of 256):
     (1) fp32 equals the device-side checker at the stated tolerances; (2) the filler rows never leak: with the WHOLE workspace
     pre-filled with NaN bit patterns the results are bit-identical, in fp32 and in both 16-bit modes (the 16-bit attention multiplies
-    masked keys by p = 0, so a non-finite filler V column would poison real rows); (3) the work list is longest-segment-first."""
+    masked keys by p = 0, so a non-finite filler V column would poison real rows); (3) the attention work lists are emitted
+    longest-segment-first (tests/test_kernels_gpu.py checks the order itself): switching that off changes no bit of the results."""
     from rap_amd import flow_model as FM
     cfg, sd = _weights(2)
     parts = S.ragged_regime_parts(70000, seed=11)
@@ -215,6 +216,16 @@ def test_ragged_regime_batch_on_the_padded_fast_path(dev):
         for k in ("end_point_trajectory", "trajectory", "R", "t"):
             assert torch.isfinite(again[k]).all(), (dtype, k)
             assert torch.equal(out[k], again[k]), (dtype, k)
+        # (3) the ORDER of the attention work lists (tuning key 15) is not observable in the results
+        from rap_amd import _lib
+        lib = _lib.load()
+        try:
+            assert lib.rap_set_tuning(15, 0) == 0
+            unsorted, _ = _hip(cfg, sd, inp, 2, True, dev, dtype=dtype)
+        finally:
+            assert lib.rap_set_tuning(15, 1) == 0
+        for k in ("end_point_trajectory", "trajectory", "R", "t"):
+            assert torch.equal(out[k], unsorted[k]), (dtype, k)
         if dtype == "float32":
             ref, _ = _checker(cfg, sd, inp, 2, True, dev)
             e = _errors(out, ref, inp["cu_seqlens"], inp["points_per_part"])
