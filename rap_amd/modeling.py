@@ -359,12 +359,7 @@ class RectifiedPointFlow:
                        ppp=ppp.repeat(G, 1),
                        cu_batch=torch.cat([(cu[:-1][None, :] + offs).reshape(-1), cu.new_full((1,), G * TP)]).contiguous(),
                        flag=self._validate(d))                       # the G copies are consistent iff the batch is
-            n_streams = self.num_streams
-            try:
-                self.num_streams = 1          # the stacked call fills the chip by itself; shards would only cut it up again
-                o = self._sample_shard(big, x_1, False)
-            finally:
-                self.num_streams = n_streams
+            o = self._sample_shard(big, x_1, False)   # one stream: the stacked call fills the chip; shards would only cut it up again
             ep, tr = o["end_point_trajectory"], o["trajectory"]
             Rg, tg = o["R"].view(G, B, P, 3, 3), o["t"].view(G, B, P, 3)
             gens = [{"end_point_trajectory": ep[:, g * TP:(g + 1) * TP], "trajectory": tr[:, g * TP:(g + 1) * TP],
