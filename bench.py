@@ -67,7 +67,7 @@ SHIPPED_ATTENTION_SYMBOL = {
 }
 
 
-def pmc_traffic(dtype, symbol):
+def pmc_traffic(dtype, symbol, section="kernels"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside this
     process; the passes are separate runs, scripts/pmc_passes.sh, summarised in profiles/pmc_traffic.json per kernel SYMBOL).
     Returned only when the passes measured the instantiation this run timed; otherwise (None, reason)."""
@@ -75,8 +75,8 @@ def pmc_traffic(dtype, symbol):
     try:
         with open(path) as f:
             j = json.load(f)
-        for sym, k in j["kernels"].items():
-            if sym == symbol:
+        for sym, k in j.get(section, {}).items():
+            if sym == symbol and isinstance(k, dict):
                 return k["hbm_bytes_per_launch"], f"{j['source']}; measured on: {k['measured_on']}"
         return None, f"no PMC pass for {symbol} in profiles/pmc_traffic.json"
     except (OSError, KeyError, ValueError):
@@ -473,9 +473,12 @@ def main():
         achieved = flops / secs / 1e12
         elem = 4 if dtype == "float32" else 2
         symbol = SHIPPED_ATTENTION_SYMBOL[(dtype, bool(bounded))]
-        traffic, source = pmc_traffic(dtype, symbol)
-        if tokens != 32 * 2 * 4096 or any(len(x) != 2 or x[0] != 4096 or x[1] != 4096 for x in parts):
-            traffic, source = None, "the committed PMC passes measured the uniform configs[1] shape only"
+        if tokens == 32 * 2 * 4096 and all(len(x) == 2 and x[0] == 4096 and x[1] == 4096 for x in parts):
+            traffic, source = pmc_traffic(dtype, symbol)
+        elif rank == 0 and parts == S.ragged_regime_parts(262144, seed=4321):
+            traffic, source = pmc_traffic(dtype, symbol, section="ragged_kernels")
+        else:
+            traffic, source = None, "the committed PMC passes measured the uniform configs[1] shape and the default ragged batch only"
         return {
             "kernel": "attention_f32_kernel" if dtype == "float32" else "attention_h16_kernel", "kernel_symbol": symbol,
             "softmax": "bounded, offset-free (every logit bound <= 40)" if bounded and dtype != "float16" else "online (running maximum)",
