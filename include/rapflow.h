@@ -82,9 +82,11 @@ int rap_model_residual_dtype(const rap_model* m);
 
 /* Bytes of caller-provided workspace for one call on a batch of TP points, B samples, `nseg_part`
  * part segments (B*P for rap_sample, VP for rap_dit_forward) and `rows` adaLN rows
- * (num_steps for rap_sample, B for rap_dit_forward).  Depends on the model's compute / residual dtype and, for few-token calls in
- * the 16-bit modes, on tuning key 6 (the split-K planes of the feed-forward GEMM): query it in the state the call will run in -- a
- * call whose workspace is too small for the current state returns -2, it never overruns. */
+ * (num_steps for rap_sample, B for rap_dit_forward).  Depends on the model's compute / residual dtype (query it in the state the call
+ * will run in; the setters and the enqueueing entry points serialise on a per-model mutex) and on nothing else: token-row buffers are
+ * carved at align_up(TP, 256) rows (the layer kernels run over the padded rows, so any TP takes the persistent 256-row-tile GEMMs),
+ * and the split-K planes of few-token 16-bit calls are reserved by shape, whatever tuning key 6 says.  A call whose workspace is too
+ * small returns -2, it never overruns. */
 size_t rap_workspace_bytes(const rap_model* m, int64_t TP, int32_t B, int32_t nseg_part, int32_t rows);
 
 /* Replaces PointCloudDiT.forward (reference flow_model/point_cloud_dit.py:141-191), called from
