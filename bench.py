@@ -379,7 +379,7 @@ def main():
             return sd
         return {k: (v * scale if k.endswith("q_norm.gamma") or k.endswith("k_norm.gamma") else v) for k, v in sd.items()}
 
-    def run_mode(dtype, steps, warmup, gamma_scale=1.0, data=data, x_1=x_1):
+    def run_mode(dtype, steps, warmup, gamma_scale=1.0, data=data, x_1=x_1, idle_probe=False):
         """W untimed + K timed sample calls with the transformer blocks in `dtype`; returns (elapsed, prof, last, flow)."""
         model = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
                                       num_heads=cfg["num_heads"], local_feat_dim=cfg["local_feat_dim"],
@@ -454,6 +454,15 @@ def main():
         if profile:
             lib.rap_profile_enable(0)
             _lib.check(lib.rap_profile_collect(prof_ms, prof_n), "rap_profile_collect")
+        run_mode.host_idle_unprofiled_ms = None
+        if idle_probe and not distributed:
+            # one extra UN-profiled call on an idle device, outside the timed region: what a call costs the host when the HIP queue is
+            # empty and no event records ride along (~3 300 launches; the call path has no synchronisation)
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            one_step()
+            run_mode.host_idle_unprofiled_ms = 1e3 * (time.perf_counter() - tq)
+            torch.cuda.synchronize()
         if distributed:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -503,8 +512,9 @@ def main():
                              f"{run_mode.streams} streams, where a kernel's event-to-event time includes the other shard's kernels)",
         }
 
-    elapsed, prof, last = run_mode(args.dtype, args.steps, args.warmup)
+    elapsed, prof, last = run_mode(args.dtype, args.steps, args.warmup, idle_probe=True)
     host_enqueue_ms, host_first_enqueue_ms = run_mode.host_enqueue_ms, run_mode.host_first_enqueue_ms
+    host_idle_unprofiled_ms = run_mode.host_idle_unprofiled_ms
     prof_region_s, main_streams = run_mode.prof_region_s, run_mode.streams
     main_bounded = run_mode.bounded_launches
     main_rank_elapsed, main_gather_ms = list(run_mode.rank_elapsed), run_mode.gather_ms
@@ -617,6 +627,8 @@ def main():
         # ... and of the FIRST timed call, which starts on an empty queue: what one call costs the host when nothing is ahead of it
         # (no host synchronisation on the call path since round 4: the input check is deferred)
         result["host_call_ms_first_timed_call"] = host_first_enqueue_ms
+        if host_idle_unprofiled_ms is not None:
+            result["host_call_ms_idle_queue_unprofiled"] = host_idle_unprofiled_ms
         result["rccl_ranks"] = world if distributed else 0        # ranks in the RCCL process group (0: single process, no group)
         result["pairs_total"] = len(parts) * world
         result["achieved_tflops_whole_call"] = uniform_call_flops * world * args.steps / elapsed / 1e12
