@@ -101,6 +101,7 @@ class PointCloudDiT:
         self._spec = weight_spec(self.cfg)
         self._sd: dict[str, torch.Tensor] | None = None
         self._handle = ctypes.c_void_p(0)
+        self._generation = 0          # bumped whenever the native model is released: captured graphs of an older one must not be replayed
         self._device: torch.device | None = None
         self._desc = _lib.ModelDesc(embed_dim, num_layers, num_heads, local_feat_dim)
         lib = _lib.load()
@@ -156,6 +157,7 @@ class PointCloudDiT:
             _lib.load().rap_model_destroy(self._handle)
             self._handle = ctypes.c_void_p(0)
             self._device = None
+            self._generation += 1
 
     def __del__(self):
         try:

@@ -50,7 +50,7 @@ class RectifiedPointFlow:
     def __init__(self, flow_model: PointCloudDiT = None, inference_sampling_steps: int = 20,
                  inference_sampler: str = "euler", n_generations: int = 1, rigidity_forcing: bool = False,
                  return_end_point_trajectory: bool = True, encoder_on: bool = False, validate_inputs: bool | None = None,
-                 num_streams: int | None = None, **_ignored):
+                 num_streams: int | None = None, graph_replay: bool | None = None, **_ignored):
         if flow_model is None:
             raise ValueError("flow_model is required")            # modeling.py:80-81
         if encoder_on:
@@ -94,6 +94,18 @@ class RectifiedPointFlow:
         env = os.environ.get("RAP_NUM_STREAMS")
         self.num_streams = int(env) if env else num_streams
         self._aux_streams: dict = {}
+        # HIP-graph replay (opt-in, round 4; RAP_GRAPH_REPLAY=1): a sampling call is ~2 900 kernel launches.  Enqueued one by one they
+        # cost the host 8-9 ms at demo size and, at full size, 0.2 s (bf16) to 1.6 s (fp32) because the call is a few hundred commands
+        # longer than the HIP queue and the host has to follow the GPU; replayed as ONE captured graph the same call costs the host
+        # ~1 ms at every size (profiles/r04_c10_graph_host_time.jsonl), with identical results (the call never synchronises or
+        # allocates inside the library, so it captures as it is).  One graph per call signature -- device, (B, P, TP), steps, rigidity
+        # forcing, arithmetic -- holding static input / output buffers and its own workspace: meant for serving loops whose batches
+        # repeat a geometry (the segment tables and work lists are rebuilt on the device inside the graph, so the part sizes may differ
+        # from call to call as long as B, P and the point count do not).  A new signature costs one eager call plus the capture;
+        # the `graph_cache` most recent ones are kept.  Results are returned as copies (the static buffers belong to the graph).
+        self.graph_replay = (os.environ.get("RAP_GRAPH_REPLAY", "0") == "1") if graph_replay is None else bool(graph_replay)
+        self.graph_cache = 4
+        self._graphs: dict = {}
 
     # ---- the nn.Module surface the reference's checkpoint loader relies on (sample.py:57-59 -> utils/checkpoint.py:13-61:
     # `load_checkpoint_for_module(model, ckpt_path)` reads ckpt["state_dict"] -- LightningModule keys, i.e. `flow_model.<name>` for
@@ -164,6 +176,8 @@ class RectifiedPointFlow:
         B = d["ppp"].shape[0]
         n = min(self._resolved_streams(), B)
         d["flag"] = self._validate(d)             # once for the whole batch, before any shard is forked
+        if self.graph_replay and not torch.cuda.is_current_stream_capturing():
+            return self._sample_graph(d, x_1, return_transformer_features)
         if n <= 1:
             return self._sample_shard(d, x_1, return_transformer_features)
         cond = d["cond"]
@@ -271,6 +285,50 @@ class RectifiedPointFlow:
         """Wait for the device and surface deferred validation errors (the natural place for a caller that is about to read results)."""
         torch.cuda.synchronize()
         self.check_pending(block=True)
+
+    def _sample_graph(self, d: dict, x_1: torch.Tensor | None, return_transformer_features: bool) -> dict:
+        """One sampling call as a replay of a captured HIP graph (see ``graph_replay``).  Validation stays outside the graph (the
+        flag kernel before, the poison kernels after: a capture cannot carry the deferred read-back)."""
+        cond = d["cond"]
+        device = cond.device
+        TP = cond.shape[0]
+        B, P = d["ppp"].shape
+        S = int(self.inference_sampling_steps)
+        model = self.flow_model
+        model._activate(device)
+        lib = _lib.load()
+        key = (device.index, B, P, TP, S, bool(self.rigidity_forcing), lib.rap_model_compute_dtype(model._handle),
+               lib.rap_model_residual_dtype(model._handle), bool(return_transformer_features), id(model), model._generation)
+        x_1 = torch.randn_like(cond) if x_1 is None else _f32c(x_1.to(device))    # modeling.py:664 (outside the graph: fresh noise per call)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static = {k: d[k].clone() for k in ("cond", "feats", "scales", "anchor", "ppp", "cu_batch")}
+            static["flag"] = None
+            sx = x_1.clone()
+            self._sample_shard(static, sx, return_transformer_features)      # eager warm-up: weight copies, attributes, allocator
+            torch.cuda.current_stream(device).synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._sample_shard(static, sx, return_transformer_features)
+            entry = (graph, static, sx, out)
+            while len(self._graphs) >= max(1, int(self.graph_cache)):
+                self._graphs.pop(next(iter(self._graphs)))                    # oldest signature first
+            self._graphs[key] = entry
+        else:
+            self._graphs[key] = self._graphs.pop(key)                         # most recently used last
+        graph, static, sx, out = entry
+        for k in ("cond", "feats", "scales", "anchor", "ppp", "cu_batch"):
+            static[k].copy_(d[k])
+        sx.copy_(x_1)
+        graph.replay()
+        res = {k: v.clone() for k, v in out.items()}
+        flag = d.get("flag")
+        if flag is not None:
+            stream = _lib.current_stream(device)
+            with torch.cuda.device(device):
+                for buf in (res["R"], res["t"], res["end_point_trajectory"][S - 1], res["trajectory"][S - 1]):
+                    _lib.check(lib.rap_poison_on_flag(_lib.ptr(flag), _lib.ptr(buf), buf.numel(), stream), "rap_poison_on_flag")
+        return res
 
     def _sample_shard(self, d: dict, x_1: torch.Tensor | None, return_transformer_features: bool) -> dict:
         """rap_sample on the current stream for one (shard of a) prepared batch."""

@@ -625,3 +625,46 @@ def test_concurrent_batch_shards_equal_the_single_stream_call(dev, n_streams):
     # and the next call on the caller's stream sees the joined result (stream order is preserved for the caller)
     again = many.sample_and_register(d, x_1=d["x_1"])
     assert (again["R"] - ref["R"]).abs().max().item() < 2e-5
+
+
+def test_graph_replay_mode_equals_the_eager_call(dev):
+    """Round 4: RectifiedPointFlow(graph_replay=True) replays one captured HIP graph per call signature (device, B, P, TP, steps,
+    rigidity, arithmetic) instead of enqueueing ~2 900 launches -- ~1 ms of host time per call at every size.  Results are those of the
+    eager call bit for bit: for new clouds / features / noise of the same geometry, for a DIFFERENT split of the same point count into
+    parts (the segment tables and work lists are rebuilt on the device inside the graph), with transformer features, after the model's
+    weights were reloaded (a stale graph must not be replayed), and the deferred input validation still reports a malformed batch."""
+    cfg, sd, model = get_model(2, 3, dev)
+    eager = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=4, rigidity_forcing=True)
+    fast = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=4, rigidity_forcing=True, graph_replay=True)
+    a = to_dev(S.make_inputs([[200, 312], [256, 256]], seed=1), dev)
+    b = to_dev(S.make_inputs([[200, 312], [256, 256]], seed=2), dev)       # same geometry, different clouds / features / noise
+    c = to_dev(S.make_inputs([[100, 412], [500, 12]], seed=3), dev)        # same B, P and point count, different part sizes
+    for src in (a, b, c, a):
+        want = eager.sample_and_register(src, x_1=src["x_1"], return_transformer_features=True)
+        got = fast.sample_and_register(src, x_1=src["x_1"], return_transformer_features=True)
+        for k in ("end_point_trajectory", "trajectory", "R", "t", "transformer_features"):
+            assert torch.equal(got[k], want[k]), k
+    assert len(fast._graphs) == 1                                           # one signature, one graph
+    keep = fast.sample_and_register(a, x_1=a["x_1"])                        # results are copies: a later replay must not change them
+    snapshot = {k: v.clone() for k, v in keep.items()}
+    fast.sample_and_register(b, x_1=b["x_1"])
+    for k in snapshot:
+        assert torch.equal(keep[k], snapshot[k]), k
+    # another signature (other point count) gets its own graph; the cache is bounded
+    fast.graph_cache = 2
+    for n in (300, 310, 320):
+        e = to_dev(S.make_inputs([[n, 100]], seed=n), dev)
+        assert torch.equal(fast.sample_and_register(e, x_1=e["x_1"])["R"], eager.sample_and_register(e, x_1=e["x_1"])["R"])
+    assert len(fast._graphs) == 2
+    # reloaded weights: new native model, the graphs of the old one are not replayed
+    sd2 = S.make_weights(cfg, 11)
+    model.load_state_dict(sd2); model.to(dev)
+    want = eager.sample_and_register(a, x_1=a["x_1"]); got = fast.sample_and_register(a, x_1=a["x_1"])
+    assert torch.equal(got["end_point_trajectory"], want["end_point_trajectory"]) and not torch.equal(got["R"], snapshot["R"])
+    # deferred validation around the replay
+    bad = dict(a); bad["points_per_part"] = a["points_per_part"].clone(); bad["points_per_part"][1, 1] += 50
+    res = fast.sample_and_register(bad, x_1=a["x_1"])
+    with pytest.raises(ValueError, match="inconsistent batch"):
+        fast.synchronize()
+    assert torch.isnan(res["R"]).all()
+    model.load_state_dict(sd); model.to(dev)                                # leave the shared test model as it was
