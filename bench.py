@@ -543,6 +543,36 @@ def main():
             secondary["deviation_from_reference_golden"] = {k: gp2[k] for k in ("final_cloud_max_abs", "R_frob_max", "t_max_abs")}
         del l2
 
+    # ---- opt-in HIP-graph replay of the same call (bf16, a few calls): what a call costs the HOST when it is one graph launch
+    graph_leg = None
+    if world == 1 and args.workload == "uniform" and args.dtype == "float32" and not args.no_secondary:
+        mg = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"], num_heads=cfg["num_heads"],
+                                   local_feat_dim=cfg["local_feat_dim"], attn_dtype="bfloat16", compute_dtype="bfloat16",
+                                   residual_dtype=args.residual_dtype)
+        mg.load_state_dict(sd); mg.to(dev)
+        kw = dict(flow_model=mg, inference_sampling_steps=args.flow_steps, rigidity_forcing=bool(args.rigidity))
+        fg, fe = rap_amd.RectifiedPointFlow(graph_replay=True, **kw), rap_amd.RectifiedPointFlow(**kw)
+        fg.sample_and_register(data, x_1=x_1)                    # eager warm-up + capture
+        torch.cuda.synchronize()
+        n_g, host = 3, []
+        t0 = time.perf_counter()
+        for _ in range(n_g):
+            te = time.perf_counter()
+            og = fg.sample_and_register(data, x_1=x_1)
+            host.append(1e3 * (time.perf_counter() - te))
+        torch.cuda.synchronize()
+        eg = time.perf_counter() - t0
+        fg.check_pending()
+        te = time.perf_counter()
+        oe = fe.sample_and_register(data, x_1=x_1)
+        eager_host = 1e3 * (time.perf_counter() - te)
+        torch.cuda.synchronize()
+        graph_leg = {"what": "RectifiedPointFlow(graph_replay=True): the same batch in bf16, each call = input copies + ONE graph launch + result copies",
+                     "calls": n_g, "points_per_s": pts_per_rank * n_g / eg, "ms_per_step": 1e3 * eg / n_g,
+                     "host_call_ms": host, "eager_host_call_ms_idle_queue": eager_host,
+                     "bit_identical_to_eager": bool(all(torch.equal(og[k], oe[k]) for k in ("end_point_trajectory", "trajectory", "R", "t")))}
+        del mg, fg, fe, og, oe
+
     # ---- the RAGGED reference-regime batch through the same path: fp32 (1 warm-up + 1 timed call) and bf16
     ragged = None
     uniform_call_flops = call_flops(parts, args.layers, args.flow_steps)
@@ -646,6 +676,8 @@ def main():
             result["reduced_precision"] = secondary
         if online:
             result["roofline_online_softmax"] = online
+        if graph_leg:
+            result["graph_replay"] = graph_leg
         if ragged:
             for tag in ("f32", "bf16"):
                 if tag in ragged:
