@@ -20,6 +20,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   run f32_kernel_level $c python "$GRAFT_REPO_ROOT/scripts/kernel_bench.py" --only attention --pmc --bounded 2
   run bf16_kernel_level $c python "$GRAFT_REPO_ROOT/scripts/kernel_bench.py" --dtype bfloat16 --only attention --pmc --bounded 2
   run f16_kernel_level $c python "$GRAFT_REPO_ROOT/scripts/kernel_bench.py" --dtype float16 --only attention --pmc --bounded 0
-  run bf16_model_path $c python "$GRAFT_REPO_ROOT/bench.py" --dtype bfloat16 --steps 1 --warmup 0 --flow-steps 1 --no-cpu-baseline --no-secondary --no-profile --gamma-scale 0
+  run bf16_model_path $c python "$GRAFT_REPO_ROOT/bench.py" --dtype bfloat16 --steps 1 --warmup 0 --flow-steps 1 --no-cpu-baseline --no-secondary --no-ragged --no-profile --gamma-scale 0
 done
 cat "$OUT/pmc_traffic.txt"
