@@ -512,7 +512,7 @@ def main():
                              f"{run_mode.streams} streams, where a kernel's event-to-event time includes the other shard's kernels)",
         }
 
-    elapsed, prof, last = run_mode(args.dtype, args.steps, args.warmup, idle_probe=True)
+    elapsed, prof, last = run_mode(args.dtype, args.steps, args.warmup, idle_probe=not args.no_profile)     # (--no-profile: profiler-driven runs want exactly K calls)
     host_enqueue_ms, host_first_enqueue_ms = run_mode.host_enqueue_ms, run_mode.host_first_enqueue_ms
     host_idle_unprofiled_ms = run_mode.host_idle_unprofiled_ms
     prof_region_s, main_streams = run_mode.prof_region_s, run_mode.streams
