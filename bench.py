@@ -223,13 +223,14 @@ def device_checker_last_pair(cfg, sd, args, last, inp_cpu, dev):
             "per_step_max_abs": {"max": float(per_step.max()), "first": float(per_step[0]), "last": float(per_step[-1])}}
 
 
-def golden_parity(args, last, data):
-    """Pair 0 of the batch vs the all-step fixture the unmodified reference produced for exactly that pair (seed 1234, rap_12,
-    20 steps; oracle/make_golden.py --headline-only).  None when the configuration has no fixture."""
+def golden_parity(args, last, data, fixture=None):
+    """Pair 0 of THIS RANK's batch vs the all-step fixture the unmodified reference produced for exactly that pair (rank 0: seed 1234,
+    `headline_c1_*`; rank 1 of a multi-GPU job with 32 pairs per rank: seed 1234 + 32, `headline_c2_rank1`; rap_12, 20 steps;
+    oracle/make_golden.py --headline-only).  None when the configuration has no fixture."""
     import numpy as np
     if (args.views, args.points, args.flow_steps, args.layers) != (2, 4096, 20, 12):
         return None
-    path = os.path.join(ROOT, "tests", "golden", f"headline_c1_{'rigid' if args.rigidity else 'free'}.npz")
+    path = os.path.join(ROOT, "tests", "golden", (fixture or f"headline_c1_{'rigid' if args.rigidity else 'free'}") + ".npz")
     if not os.path.exists(path):
         return None
     g = np.load(path)
@@ -520,6 +521,26 @@ def main():
     main_rank_elapsed, main_gather_ms = list(run_mode.rank_elapsed), run_mode.gather_ms
     if main_bounded != 2 * args.layers:
         raise SystemExit(f"seeded weights: {main_bounded} of {2 * args.layers} attention launches bounded -- the headline expects all")
+    # multi-GPU runs: the first pair of RANK 1 (seed 1234 + 32) has a fixture of the unmodified reference too -- parity evidence from a
+    # rank that is not rank 0, gathered with one tiny collective every rank takes part in (the condition depends on the arguments only)
+    rank1_parity = None
+    if distributed and args.dtype == "float32" and args.workload == "uniform" and args.batch == 32 and args.rigidity:
+        vals = torch.full((4,), float("nan"), dtype=torch.float64, device=dev)
+        if rank == 1:
+            try:
+                g1 = golden_parity(args, last, data, fixture="headline_c2_rank1")
+                if g1:
+                    vals = torch.tensor([g1["final_cloud_max_abs"], g1["R_frob_max"], g1["t_max_abs"], g1["per_step_max_abs"]["max"]],
+                                        dtype=torch.float64, device=dev)
+            except Exception:      # never let the evidence leg take the job down (the collective below still runs)
+                pass
+        allv = torch.zeros(4 * world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allv, vals)
+        r1 = allv[4:8].tolist() if world > 1 else [float("nan")] * 4        # (a forced 1-rank group exercises the collective only)
+        if all(x == x for x in r1):
+            rank1_parity = {"fixture": "tests/golden/headline_c2_rank1.npz", "source": "unmodified reference modules, fp32 CPU, all 20 flow steps; "
+                            "computed ON rank 1 for the first pair it owns (input seed 1234 + 32)",
+                            "final_cloud_max_abs": r1[0], "R_frob_max": r1[1], "t_max_abs": r1[2], "per_step_max_abs_max": r1[3]}
     secondary = None
     if args.dtype == "float32" and not args.no_secondary:
         # the same workload with bf16 MFMA blocks (BASELINE configs[2]'s per-GPU shard), reported beside the fp32 headline
@@ -705,6 +726,8 @@ def main():
         gp = golden_parity(args, last, data) if (args.dtype == "float32" and args.workload == "uniform") else None
         if gp:
             result["parity_vs_reference_golden"] = gp
+        if rank1_parity:
+            result["parity_vs_reference_golden_rank1"] = rank1_parity
         if args.dtype == "float32" and args.workload == "uniform" and world == 1 and not args.no_cpu_baseline:
             result["parity_vs_device_checker_last_pair"] = device_checker_last_pair(cfg, sd, args, last, inp, dev)
         print(json.dumps(result), file=json_out, flush=True)

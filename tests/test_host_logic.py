@@ -176,3 +176,24 @@ def test_lightning_keyed_checkpoint_loads_through_the_flow_module():
     assert set(flow.load_state_dict(part, strict=False).missing_keys) == {"flow_model." + k for k in sd if "final_mlp" in k}
     assert set(flow.state_dict()) == {"flow_model." + k for k in sd}
     assert flow.eval() is flow
+
+
+def test_bench_golden_parity_accepts_the_rank1_fixture():
+    """bench.py's multi-GPU runs compare the first pair of RANK 1 with `headline_c2_rank1` (the unmodified reference's all-step result
+    for input seed 1234 + 32) on that rank and gather four numbers: the comparison function itself, fed the fixture's own content."""
+    import types
+    import numpy as np
+    import torch
+    import bench
+    args = types.SimpleNamespace(views=2, points=4096, flow_steps=20, layers=12, rigidity=1)
+    for name in ("headline_c2_rank1", None):
+        g = np.load(os.path.join(ROOT, "tests", "golden", (name or "headline_c1_rigid") + ".npz"))
+        st = int(g["stride"])
+        ep = torch.zeros(20, 8192, 3); tr = torch.zeros(20, 8192, 3)
+        ep[:, ::st] = torch.from_numpy(g["end_point_strided"]); tr[:, ::st] = torch.from_numpy(g["x_t_strided"])
+        ep[-1] = torch.from_numpy(g["final_end_point"]); tr[-1] = torch.from_numpy(g["final_x_t"])
+        last = {"end_point_trajectory": ep, "trajectory": tr, "R": torch.from_numpy(g["R"]), "t": torch.from_numpy(g["t"])}
+        r = bench.golden_parity(args, last, None, fixture=name)
+        assert r["fixture"].endswith((name or "headline_c1_rigid") + ".npz")
+        assert r["final_cloud_max_abs"] == 0 and r["R_frob_max"] == 0 and r["t_max_abs"] == 0 and r["per_step_max_abs"]["max"] == 0
+    assert bench.golden_parity(types.SimpleNamespace(views=8, points=2048, flow_steps=30, layers=12, rigidity=1), last, None) is None
