@@ -26,8 +26,9 @@ extern "C" {
 
 /* ABI version of this header.  rap_version() returns the value the LIBRARY was built with; a caller compiled against another
  * value must not use the library (round 4, version 4: rap_spinnet_describe gained `flags` and three entry points were removed in
- * round 3 without a bump; the fp16-residual epilogue of rap_gemm_h16 moved from 6 to 7 and 6 is refused; rap_poison_on_flag is new). */
-#define RAPFLOW_ABI_VERSION 4
+ * round 3 without a bump; the fp16-residual epilogue of rap_gemm_h16 moved from 6 to 7 and 6 is refused; rap_poison_on_flag is new;
+ * round 5, version 5: compute dtype 3 (split precision) and the rap_x2_* entry points are new, nothing was removed or re-numbered). */
+#define RAPFLOW_ABI_VERSION 5
 
 typedef struct rap_model rap_model;
 
@@ -59,7 +60,15 @@ void rap_model_destroy(rap_model* m);
 
 /* Arithmetic type of the transformer blocks (qkv / out / feed-forward GEMMs and attention) for subsequent calls on `m`:
  * 0 = fp32 (default; exact-fp32 MFMA, the parity configuration of BASELINE configs[1]),
- * 1 = bf16 MFMA (BASELINE configs[2], [4]), 2 = fp16 MFMA.  Replaces the autocast context the reference runs its
+ * 1 = bf16 MFMA (BASELINE configs[2], [4]), 2 = fp16 MFMA,
+ * 3 = SPLIT PRECISION ("float32x2", round 5): fp32-ACCURATE results from the fp16 matrix pipe.  Every operand of the block GEMMs and of
+ *     both attention products is carried as an fp16 head + an fp16 tail (x = hi + lo, 22 significand bits; weights additionally scaled by
+ *     a per-tensor power of two so that their tails are normal numbers) and each contraction keeps hi*hi + hi*lo + lo*hi in the MFMA's
+ *     fp32 accumulators -- 3 x 32 matrix-pipe cycles per 16 contraction steps instead of 8 x 64 for the fp32-input MFMA.  Residual stream,
+ *     LayerNorm, qk-norm, softmax state, GEGLU, embedding, head, Euler and Procrustes are fp32 exactly as in mode 0; results sit at
+ *     mode 0's distance from an fp64 evaluation.  Operands are clipped to the fp16 range (|x| <= 65504), the range
+ *     of the reference's own shipped fp16 inference.  The residual-dtype switch below is ignored in this mode.
+ * Modes 1 / 2 replace the autocast context the reference runs its
  * GPU inference under (Lightning precision "16-mixed", config/trainer/infer.yaml:6; attn_dtype, layer.py:106-128).
  * Residual stream, LayerNorm, softmax, accumulation, embedding, final_mlp, Euler and Procrustes stay fp32
  * (final_mlp is fp32 in the reference too, point_cloud_dit.py:183-184).  The first call per dtype allocates and
@@ -330,6 +339,30 @@ int rap_layernorm_affine_h16(int32_t dtype, const float* x, uint16_t* out, int64
 int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t heads, const float* gamma_q, const float* gamma_k,
                    void* stream);
 
+/* ---- split-precision kernel-level entry points (compute dtype 3, round 5) ----
+ * PAIRED layout of a split fp32 matrix (rows, K): (rows, 2K) fp16; logical column k sits at physical column 64 (k >> 5) + (k & 31) as
+ * its fp16 head, and 32 columns further as its fp16 tail -- every 32-column chunk is one 128-byte line [32 heads | 32 tails].  K % 32 == 0.
+ * rap_x2_pack:   dst = split(src * scale)  (src fp32 (rows, cols), row stride ld_src; scale a power of two for weights, 1 otherwise).
+ * rap_x2_unpack: dst fp32 (rows, cols) = (head + tail) * inv_scale.
+ * rap_x2_gemm:   C = A (M,K) W(N,K)^T from paired A (M, lda) and W (N, ldw), K_physical = 2 K (>= 128, % 64 == 0), N % 256 == 0; the accumulators are
+ *   multiplied by acc_scale (the inverse of the weight planes' scale) before the epilogue:
+ *     1  C fp32 (M,N) = resid + acc + bias (resid may be NULL / alias C);
+ *     3  GEGLU on value/gate-interleaved W: C paired (M, ldc >= N) holds the N/2 outputs (h + bh) * gelu_erf(g + bg);
+ *     5  QKV projection with MultiHeadRMSNorm fused (N = 3 * heads * 64): q, k -> C paired [2][heads][2 chunks][M][64 physical] (chunk c =
+ *        head dims 32c .. 32c+31; q multiplied by q_mul, k by 8 as in rap_gemm_h16_qkvnorm), v -> vt paired
+ *        [heads][vt_nblk][2 chunks][64 d][64 physical]: token t sits in block t >> 6, chunk (t >> 5) & 1, at in-chunk position
+ *        p = (t & 19) | ((t & 4) << 1) | ((t & 8) >> 1) as head (column p) and tail (column 32 + p); vt_nblk * 64 >= M rounded up to 256.
+ * rap_x2_attention: flash_attn_varlen_qkvpacked_func on those planes (online softmax in fp32): out paired (TP, 2 * heads * 64).
+ *   ws >= rap_attention_workspace_bytes(TP, nseg).
+ * LayerNorm with paired output: rap_layernorm_mod_h16 / rap_layernorm_affine_h16 with dtype 3 (out is (TP, 2 d)). */
+int rap_x2_pack(const float* src, int64_t ld_src, int64_t rows, int32_t cols, float scale, uint16_t* dst, void* stream);
+int rap_x2_unpack(const uint16_t* src, int64_t rows, int32_t cols, float inv_scale, float* dst, void* stream);
+int rap_x2_gemm(int32_t epilogue, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, void* C, int32_t ldc, int32_t M, int32_t N,
+                int32_t K_physical, const float* bias, const float* resid, int32_t ldr, float acc_scale, int32_t heads, const float* gamma_q,
+                const float* gamma_k, float q_mul, uint16_t* vt, int32_t vt_nblk, void* stream);
+int rap_x2_attention(const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk, const int32_t* cu_seqlens, int32_t nseg, uint16_t* out,
+                     int64_t TP, int32_t heads, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- input side of the boundary: raw multi-part scans -> the packed batch rap_sample consumes ----
  * Replaces, in their evaluation-split form (no augmentation), PointCloudDataset._transform
  * (rectified_point_flow/data/dataset.py:733-900) and variable_collate_fn (data/datamodule.py:169-198) for a whole batch, on the
@@ -378,8 +411,11 @@ int rap_poison_on_flag(const int32_t* flag, float* buf, int64_t n, void* stream)
  * When enabled, every attention and layer-GEMM launch inside rap_dit_forward / rap_sample is bracketed by two
  * hipEvents recorded on the launch stream.  rap_profile_collect synchronises on them and returns, per class
  * (0 attention per part, 1 attention per sample, 2 layer GEMMs), the summed milliseconds and the launch count
- * into HOST arrays of 3 entries.  Not thread-safe; off by default. */
+ * into HOST arrays of 3 entries.  rap_profile_collect_ex (round 5) takes n_classes entries and also reports the HBM-bound ring:
+ * 3 LayerNorm, 4 posenc(x_t), 5 Euler update, 6 Procrustes moments + solve, 7 rigid apply / blend (8 classes in all).
+ * Off by default; the state is process-global behind a mutex (safe to call from several threads, the figures are per process). */
 int rap_profile_enable(int on);
+int rap_profile_collect_ex(float* h_ms_out, int64_t* h_count_out, int32_t n_classes);
 /* Production switches between two SHIPPED code paths that compute the same function (process-global, atomic; not per model):
  *   key 5  split-KV attention for few-token calls        {0 off, 1 on (default)}       fp32 path
  *   key 6  split-K of the bias + residual GEMM, few rows  {0 off, 1 on (default)}       both precisions (16-bit: K >= 1024, i.e. ff2)

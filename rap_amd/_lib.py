@@ -13,9 +13,10 @@ from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librapflow.so")
 
-ABI_VERSION = 4        # RAPFLOW_ABI_VERSION of include/rapflow.h this binding was written against
+ABI_VERSION = 5        # RAPFLOW_ABI_VERSION of include/rapflow.h this binding was written against
 EPI_H_BIAS_RESID_H16 = 7   # rap_gemm_h16's fp16-residual epilogue (6 before ABI version 4; 6 is refused now)
-DTYPES = {"float32": 0, "fp32": 0, "bfloat16": 1, "bf16": 1, "float16": 2, "fp16": 2}
+# "float32x2" (round 5): split precision -- fp32-ACCURATE transformer blocks on the fp16 matrix pipe (include/rapflow.h, compute dtype 3)
+DTYPES = {"float32": 0, "fp32": 0, "bfloat16": 1, "bf16": 1, "float16": 2, "fp16": 2, "float32x2": 3, "f32x2": 3}
 
 ERRORS = {-1: "invalid argument", -2: "workspace too small", -3: "HIP runtime error", -4: "allocation failure"}
 
@@ -106,10 +107,16 @@ SIGNATURES = {
     "rap_layernorm_mod_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P]),
     "rap_layernorm_affine_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, _P, _P]),
     "rap_qknorm_h16": (c_int32, [c_int32, _P, c_int64, c_int32, _P, _P, _P]),
+    "rap_x2_pack": (c_int32, [_P, c_int64, c_int64, c_int32, c_float, _P, _P]),
+    "rap_x2_unpack": (c_int32, [_P, c_int64, c_int32, c_float, _P, _P]),
+    "rap_x2_gemm": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, c_float, c_int32,
+                              _P, _P, c_float, _P, c_int32, _P]),
+    "rap_x2_attention": (c_int32, [_P, _P, c_int32, _P, c_int32, _P, c_int64, c_int32, _P, c_size_t, _P]),
     "rap_set_tuning": (c_int32, [c_int32, c_int32]),
     "rap_profile_enable": (c_int32, [c_int32]),
     "rap_profile_reset": (c_int32, []),
     "rap_profile_collect": (c_int32, [_P, _P]),
+    "rap_profile_collect_ex": (c_int32, [_P, _P, c_int32]),
 }
 
 _lib = None

@@ -16,15 +16,20 @@ void rap_set_last_hip_error(int e) { g_last_hip_error = e; }
 // optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 // Off by default; when on, every attention / GEMM launch of forward_step is bracketed by two events.
 // ---------------------------------------------------------------------------------------------
-#define RAP_PROF_CLASSES 3   // 0 = attention per part, 1 = attention per sample, 2 = GEMM
+// classes: 0 = attention per part, 1 = attention per sample, 2 = layer GEMMs (the MFMA-bound kernels), and since round 5 the HBM-bound
+// ring: 3 = LayerNorm, 4 = posenc(x_t), 5 = Euler update, 6 = Procrustes moments + solve, 7 = rigid apply / blend
+#define RAP_PROF_CLASSES 8
 struct ProfRec { hipEvent_t a, b; int cls; };
-static bool g_prof_on = false;
+// process-global state behind one mutex (round 5: the enable flag was a plain bool and the vectors unsynchronised): two
+// threads enqueueing on two models may record concurrently; the flag is an atomic so that the off path costs one relaxed load
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
 static size_t g_prof_pool_used = 0;
 static const size_t RAP_PROF_MAX_EVENTS = 1u << 19;   // 20 sample calls of rap_12 at 20 flow steps = 38 400 scopes = 76 800 events (r01: 32768 truncated the log)
 
-static hipEvent_t prof_event() {
+static hipEvent_t prof_event() {      // caller holds g_prof_mu
   if (g_prof_pool_used < g_prof_pool.size()) return g_prof_pool[g_prof_pool_used++];
   if (g_prof_pool.size() >= RAP_PROF_MAX_EVENTS) return nullptr;
   hipEvent_t e = nullptr;
@@ -36,21 +41,27 @@ static hipEvent_t prof_event() {
 struct ProfScope {
   hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int cls;
   ProfScope(hipStream_t s_, int cls_) : s(s_), cls(cls_) {
-    if (!g_prof_on) return;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     a = prof_event(); b = prof_event();
     if (a && b) (void)hipEventRecord(a, s); else a = b = nullptr;
   }
   ~ProfScope() {
-    if (a && b) { (void)hipEventRecord(b, s); g_prof_recs.push_back({a, b, cls}); }
+    if (a && b) {
+      std::lock_guard<std::mutex> lock(g_prof_mu);
+      (void)hipEventRecord(b, s); g_prof_recs.push_back({a, b, cls});
+    }
   }
 };
-extern "C" int rap_profile_enable(int on) { g_prof_on = on != 0; return RAP_OK; }
-extern "C" int rap_profile_reset(void) { g_prof_recs.clear(); g_prof_pool_used = 0; return RAP_OK; }
-// Synchronises on the recorded events.  ms_out / count_out have RAP_PROF_CLASSES (3) entries.
-extern "C" int rap_profile_collect(float* h_ms_out, int64_t* h_count_out) {
-  if (!h_ms_out || !h_count_out) return RAP_ERR_INVALID;
-  for (int c = 0; c < RAP_PROF_CLASSES; ++c) { h_ms_out[c] = 0.f; h_count_out[c] = 0; }
+extern "C" int rap_profile_enable(int on) { g_prof_on.store(on != 0); return RAP_OK; }
+extern "C" int rap_profile_reset(void) { std::lock_guard<std::mutex> lock(g_prof_mu); g_prof_recs.clear(); g_prof_pool_used = 0; return RAP_OK; }
+// Synchronises on the recorded events.  h_ms_out / h_count_out have n_classes entries (classes >= n_classes are dropped).
+extern "C" int rap_profile_collect_ex(float* h_ms_out, int64_t* h_count_out, int32_t n_classes) {
+  if (!h_ms_out || !h_count_out || n_classes <= 0) return RAP_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  for (int c = 0; c < n_classes; ++c) { h_ms_out[c] = 0.f; h_count_out[c] = 0; }
   for (const ProfRec& r : g_prof_recs) {
+    if (r.cls >= n_classes) continue;
     if (hipEventSynchronize(r.b) != hipSuccess) return RAP_ERR_HIP;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return RAP_ERR_HIP;
@@ -58,6 +69,8 @@ extern "C" int rap_profile_collect(float* h_ms_out, int64_t* h_count_out) {
   }
   return RAP_OK;
 }
+// the three MFMA-bound classes (ABI <= 4 form)
+extern "C" int rap_profile_collect(float* h_ms_out, int64_t* h_count_out) { return rap_profile_collect_ex(h_ms_out, h_count_out, 3); }
 
 // ---------------------------------------------------------------------------------------------
 // model
@@ -82,6 +95,8 @@ struct LayerWH {
   const u16* Wout[2];
   const u16* Wff1p;   // value/gate interleaved, as the fp32 packing
   const u16* Wff2;
+  // split precision (RAP_DT_F32X2): the planes hold w * 2^e per tensor; s_* = 2^-e, the factor the epilogue applies to the accumulators
+  float s_qkv[2] = {1.f, 1.f}, s_out[2] = {1.f, 1.f}, s_ff1 = 1.f, s_ff2 = 1.f;
 };
 struct HalfWeights {
   u16* blob = nullptr;
@@ -94,7 +109,7 @@ struct rap_model {
   int d, L, H, F, E;
   int dtype = RAP_DT_F32;     // arithmetic type of the transformer blocks (rap_model_set_compute_dtype)
   int resid_dtype = RAP_DT_F32;   // storage type of the residual stream in the 16-bit modes (rap_model_set_residual_dtype): fp32 or fp16
-  HalfWeights half[3];        // indexed by dtype (slot 0 unused)
+  HalfWeights half[4];        // indexed by dtype (slot 0 unused; 3 = the paired head / tail planes of the split-precision mode)
   float* logit_bound = nullptr;   // (L, 2, H) per-head bounds on q.k/8 after qk-norm; null until a 16-bit dtype is selected
   // bounded[2 * layer + branch]: every head of THAT attention has a bound <= RAP_MAX_LOGIT_BOUND, so that launch may use the
   // bounded (offset-free) softmax kernel; the others take the online-softmax kernel.  Decided per launch since round 3 (VERDICT
@@ -135,6 +150,7 @@ extern rap_tuning_t g_rap_attn_h16_variant;   // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_h16_persistent;   // gemm_h16.hip
 extern rap_tuning_t g_rap_attn_h16_dma;          // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_f32_persistent;   // gemm_f32.hip
+extern rap_tuning_t g_rap_attn_x2_wpe;           // attn_x2.hip
 rap_tuning_t g_rap_attn_lpt = 1;               // tuning key 15: attention work lists longest-segment-first (1, default) or in segment order (0)
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 // Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
@@ -157,6 +173,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 12 && (value == 0 || value == 1)) { g_rap_gemm_f32_persistent = value; return RAP_OK; }
   if (key == 13 && (value == 0 || value == 1)) { g_rap_attn_h16_dma = value; return RAP_OK; }
   if (key == 15 && (value == 0 || value == 1)) { g_rap_attn_lpt = value; return RAP_OK; }
+  if (key == 16 && (value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: 1 / 2 blocks per CU
   return RAP_ERR_INVALID;
 }
 
@@ -270,7 +287,7 @@ extern "C" void rap_model_destroy(rap_model* m) {
   if (!m) return;
   if (m->raw) (void)hipFree(m->raw);
   if (m->derived) (void)hipFree(m->derived);
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 4; ++i)
     if (m->half[i].blob) (void)hipFree(m->half[i].blob);
   if (m->logit_bound) (void)hipFree(m->logit_bound);
   delete m;
@@ -299,12 +316,71 @@ static int ensure_logit_bounds(rap_model* m, hipStream_t stream) {
   return RAP_OK;
 }
 
+// Split precision: paired fp16 head / tail planes of the six GEMM weights of every layer, each tensor multiplied by a power of two
+// chosen from its largest magnitude (x2_pack.hip).  Model configuration may synchronise (as model creation does for the logit bounds).
+static int build_x2_weights(rap_model* m, hipStream_t stream) {
+  HalfWeights& hw = m->half[RAP_DT_F32X2];
+  const size_t d = m->d, L = m->L;
+  const size_t per_layer = 2 * (2 * (3 * d * d + d * d) + 8 * d * d + 4 * d * d);      // twice the 16-bit copy: heads and tails
+  const int nt = (int)(6 * L);
+  float* d_max = nullptr;
+  if (hipMalloc((void**)&d_max, (size_t)nt * sizeof(float)) != hipSuccess) return RAP_ERR_ALLOC;
+  if (hipMalloc((void**)&hw.blob, per_layer * L * sizeof(u16)) != hipSuccess) { hw.blob = nullptr; (void)hipFree(d_max); return RAP_ERR_ALLOC; }
+  int rc = RAP_OK;
+  auto fail = [&](int code) { (void)hipFree(hw.blob); hw.blob = nullptr; hw.layers.clear(); (void)hipFree(d_max); return code; };
+  if (hipMemsetAsync(d_max, 0, (size_t)nt * sizeof(float), stream) != hipSuccess) return fail(RAP_ERR_HIP);
+  struct Item { const float* src; size_t rows, cols; };
+  std::vector<Item> items;
+  for (size_t i = 0; i < L; ++i) {
+    const LayerW& lw = m->layers[i];
+    for (int a = 0; a < 2; ++a) { items.push_back({lw.Wqkv[a], 3 * d, d}); items.push_back({lw.Wout[a], d, d}); }
+    items.push_back({lw.Wff1p, 8 * d, d});
+    items.push_back({lw.Wff2, d, 4 * d});
+  }
+  for (int k = 0; k < nt && rc == RAP_OK; ++k) rc = launch_max_abs(stream, items[k].src, items[k].rows * items[k].cols, d_max + k);
+  if (rc) return fail(rc);
+  std::vector<float> hmax(nt);
+  if (hipMemcpyAsync(hmax.data(), d_max, (size_t)nt * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess) return fail(RAP_ERR_HIP);
+  if (hipStreamSynchronize(stream) != hipSuccess) return fail(RAP_ERR_HIP);
+  u16* q = hw.blob;
+  std::vector<const u16*> planes(nt);
+  std::vector<float> inv(nt);
+  for (int k = 0; k < nt && rc == RAP_OK; ++k) {
+    // largest magnitude * 2^e in (2^11, 2^12]; an all-zero (or non-finite) tensor keeps e = 0
+    int e = 0;
+    if (hmax[k] > 0.f && hmax[k] < 3.0e38f) { int ex; (void)frexpf(hmax[k], &ex); e = 12 - ex; }
+    e = e > 60 ? 60 : e < -60 ? -60 : e;
+    inv[k] = ldexpf(1.0f, -e);
+    planes[k] = q;
+    rc = launch_x2_pack(stream, items[k].src, (long)items[k].cols, (long)items[k].rows, (int)items[k].cols, ldexpf(1.0f, e), q);
+    q += 2 * items[k].rows * items[k].cols;
+  }
+  if (rc) return fail(rc);
+  hw.layers.resize(L);
+  for (size_t i = 0; i < L; ++i) {
+    LayerWH& lh = hw.layers[i];
+    const int k0 = (int)(6 * i);
+    for (int a = 0; a < 2; ++a) {
+      lh.Wqkv[a] = planes[k0 + 2 * a]; lh.s_qkv[a] = inv[k0 + 2 * a];
+      lh.Wout[a] = planes[k0 + 2 * a + 1]; lh.s_out[a] = inv[k0 + 2 * a + 1];
+    }
+    lh.Wff1p = planes[k0 + 4]; lh.s_ff1 = inv[k0 + 4];
+    lh.Wff2 = planes[k0 + 5]; lh.s_ff2 = inv[k0 + 5];
+  }
+  (void)hipFree(d_max);
+  return RAP_OK;
+}
+
 extern "C" int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* stream_) {
   if (!m) return RAP_ERR_INVALID;
   std::lock_guard<std::mutex> lock(m->cfg_mu);
   if (dtype == RAP_DT_F32) { m->dtype = dtype; return RAP_OK; }
-  if (dtype != RAP_DT_BF16 && dtype != RAP_DT_F16) return RAP_ERR_INVALID;
+  if (dtype != RAP_DT_BF16 && dtype != RAP_DT_F16 && dtype != RAP_DT_F32X2) return RAP_ERR_INVALID;
   HalfWeights& hw = m->half[dtype];
+  if (!hw.blob && dtype == RAP_DT_F32X2) {
+    const int rcx = build_x2_weights(m, (hipStream_t)stream_);
+    if (rcx) return rcx;
+  }
   if (!hw.blob) {
     hipStream_t stream = (hipStream_t)stream_;
     const size_t d = m->d, L = m->L;
@@ -359,6 +435,7 @@ struct Workspace {
   int rows;                             // TQ = align_up(TP, 256): rows of every token-row buffer
   double* proc_partials;
   int32_t *token_sample, *part_offsets, *attn_sort;
+  int32_t *cu_batch_s, *cu_part_s;      // sanitised copies of the caller's segment tables (clamped to [0, TP], non-decreasing)
   AttnWorkItem *items_batch, *items_part;
   int max_items_batch, max_items_part;
   size_t total;
@@ -376,7 +453,8 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   const size_t T = align_up((size_t)TP, 256);
   w.rows = (int)T;
   w.base = (float*)take(T * d * 4);
-  const bool h16 = m->dtype != RAP_DT_F32 && m->resid_dtype == RAP_DT_F16;
+  const bool x2 = m->dtype == RAP_DT_F32X2;    // split precision: fp32 residual stream, every 16-bit activation buffer holds heads AND tails
+  const bool h16 = m->dtype != RAP_DT_F32 && !x2 && m->resid_dtype == RAP_DT_F16;
   w.h = h16 ? nullptr : (float*)take(T * d * 4);
   w.h16 = h16 ? (u16*)take(T * d * 2) : nullptr;
   w.xn = w.qkv = w.att = w.ffmid = nullptr;
@@ -390,18 +468,19 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
     w.ffmid = (float*)take(T * 4 * d * 4);     // also the static feature matrix (TP,128) during prepare
     w.hid1 = w.xn; w.hid2 = w.att; w.astatic = w.ffmid;
   } else {
+    const size_t pl = x2 ? 2 : 1;              // planes per value
     w.vt_nblk = (int)(T / 64);                 // V^T image: whole 64-token blocks over the padded rows
-    w.xnh = (u16*)take(T * d * 2);
-    w.qkh = (u16*)take(T * 2 * d * 2);         // q,k [2][H][T][64]
-    w.vth = (u16*)take((size_t)w.vt_nblk * 64 * d * 2);   // [H][vt_nblk][64][64]
-    w.atth = (u16*)take(T * d * 2);
-    w.ffmidh = (u16*)take(T * 4 * d * 2);      // 8*T*d bytes: also hosts the fp32 head hidden layers / static features
+    w.xnh = (u16*)take(T * d * 2 * pl);
+    w.qkh = (u16*)take(T * 2 * d * 2 * pl);    // q,k [2][H][T][64]   (x2: [2][H][2 chunks][T][64 physical])
+    w.vth = (u16*)take((size_t)w.vt_nblk * 64 * d * 2 * pl);   // [H][vt_nblk][64][64]   (x2: [H][vt_nblk][2 chunks][64][64 physical])
+    w.atth = (u16*)take(T * d * 2 * pl);
+    w.ffmidh = (u16*)take(T * 4 * d * 2 * pl); // >= 8*T*d bytes: also hosts the fp32 head hidden layers / static features
     w.hid1 = (float*)w.ffmidh;                 // (T,d) fp32   = 4*T*d bytes
     w.hid2 = w.hid1 + T * d;                   // (T,d/2) fp32 = 2*T*d bytes
     w.astatic = (float*)w.ffmidh;
     // ff2: the one layer GEMM with K >= 1024.  Reserved by SHAPE alone (tuning key 6 only gates the launch), so that the size
     // rap_workspace_bytes reports cannot change between the query and the call
-    const int splits = gemm_h16_splits_by_shape((int)T, (int)d, (int)(4 * d));
+    const int splits = x2 ? 1 : gemm_h16_splits_by_shape((int)T, (int)d, (int)(4 * d));     // (the split-precision GEMMs have no split-K form)
     if (splits > 1) w.splitk_h = (float*)take((size_t)splits * T * d * 4);
   }
   w.ax = (float*)take(T * 64 * 4);
@@ -412,6 +491,8 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   w.tgrid = (float*)take((size_t)rows * 4);
   w.token_sample = (int32_t*)take(T * 4);
   w.part_offsets = (int32_t*)take(((size_t)nseg_part + 1) * 4);
+  w.cu_batch_s = (int32_t*)take(((size_t)B + 1) * 4);
+  w.cu_part_s = (int32_t*)take(((size_t)nseg_part + 1) * 4);
   w.max_items_batch = (int)(TP / RAP_ATTN_BQ) + B + 1;
   w.max_items_part = (int)(TP / RAP_ATTN_BQ) + nseg_part + 1;
   w.items_batch = (AttnWorkItem*)take((size_t)w.max_items_batch * sizeof(AttnWorkItem));
@@ -446,8 +527,15 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
                           const float* scales, const uint8_t* anchor, const int32_t* cu_batch, const int32_t* cu_part,
                           int B, int nseg_part, int TP) {
   int rc;
+  // the caller's tables are only ever read through sanitised copies: every index derived from them stays inside [0, TP]
+  if ((rc = launch_sanitize_cu(stream, cu_batch, B + 1, TP, w.cu_batch_s))) return rc;
+  cu_batch = w.cu_batch_s;
+  if (cu_part != w.part_offsets) {          // rap_dit_forward: the caller's part table (rap_sample builds its own, clamped, from points_per_part)
+    if ((rc = launch_sanitize_cu(stream, cu_part, nseg_part + 1, TP, w.cu_part_s))) return rc;
+    cu_part = w.cu_part_s;
+  }
   if ((rc = launch_token_sample(stream, cu_batch, B, w.token_sample))) return rc;
-  const int bq = m->dtype == RAP_DT_F32 ? 0 : attention_h16_block_queries(m->dtype);
+  const int bq = m->dtype == RAP_DT_F32 ? 0 : m->dtype == RAP_DT_F32X2 ? 256 : attention_h16_block_queries(m->dtype);
   int32_t* sort_ws = g_rap_attn_lpt ? w.attn_sort : nullptr;
   if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch, bq, sort_ws))) return rc;
   if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part, bq, sort_ws))) return rc;
@@ -461,7 +549,7 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
   if ((rc = zero_rows(stream, w.ax, 64 * 4, TP, TQ))) return rc;
   if ((rc = zero_rows(stream, w.token_sample, 4, TP, TQ))) return rc;
   if (m->dtype == RAP_DT_F32) { if ((rc = zero_rows(stream, w.att, (size_t)d * 4, TP, TQ))) return rc; }
-  else if ((rc = zero_rows(stream, w.atth, (size_t)d * 2, TP, TQ))) return rc;
+  else if ((rc = zero_rows(stream, w.atth, (size_t)d * 2 * (m->dtype == RAP_DT_F32X2 ? 2 : 1), TP, TQ))) return rc;
   // base = [PE63(cond) | PE21(scale) | feat | 0] Wstatic^T + emb bias + anchor embedding   (embedding.py:155-179,
   // point_cloud_dit.py:119-139) -- everything in the embedding that does not depend on x_t.
   float* astatic = w.astatic;
@@ -478,7 +566,8 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
   const int d = m->d, H = m->H;
   int rc;
   // embed = PE63(x_t) Wx^T + base
-  if ((rc = launch_posenc_x(stream, x_t, w.ax, TP_valid))) return rc;
+  { ProfScope ps(stream, 4); rc = launch_posenc_x(stream, x_t, w.ax, TP_valid); }
+  if (rc) return rc;
   // From here to the head every kernel runs over TQ = align_up(TP, 256) rows of the workspace (filler rows: prepare_static):
   // the GEMMs see M % 256 == 0 whatever the batch, i.e. the persistent 256 x 256 kernels; the attention launches take TQ as the
   // row count of the head-major planes and their work lists (true segment ends) for everything else.
@@ -497,12 +586,53 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
   const int epi_resid = w.h16 ? EPI_H_BIAS_RESID_H16 : EPI_H_BIAS_RESID_F32;
   for (int i = 0; i < m->L; ++i) {
     const LayerW& lw = m->layers[i];
+    if (dt == RAP_DT_F32X2) {
+      // ---- split-precision block (round 5): fp32-accurate products on the fp16 matrix pipe.  Same kernel sequence as the 16-bit
+      // block below on paired head / tail operands (physical K = 2 d resp. 8 d), fp32 residual stream, qk-norm always fused,
+      // online softmax (probabilities must fit fp16).
+      const LayerWH& lh = m->half[dt].layers[i];
+      for (int a = 0; a < 2; ++a) {
+        const int j = 2 * i + a;
+        { ProfScope ps(stream, 3); rc = launch_layernorm_mod_h16(stream, dt, w.h, 0, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row); }
+        if (rc) return rc;
+        GemmParamsH g{};
+        g.A = w.xnh; g.lda = 2 * d; g.W = lh.Wqkv[a]; g.ldw = 2 * d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = 2 * d; g.heads = H;
+        g.vt = w.vth; g.vt_nblk = w.vt_nblk; g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; g.q_mul = 8.0f; g.acc_scale = lh.s_qkv[a];
+        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV_NORM, g); }
+        if (rc) return rc;
+        {
+          ProfScope ps(stream, a);
+          rc = launch_attention_x2(stream, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch,
+                                   a == 0 ? w.max_items_part : w.max_items_batch);
+        }
+        if (rc) return rc;
+        GemmParamsH o{};
+        o.A = w.atth; o.lda = 2 * d; o.W = lh.Wout[a]; o.ldw = 2 * d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = 2 * d;
+        o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d; o.acc_scale = lh.s_out[a];
+        { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, o); }
+        if (rc) return rc;
+      }
+      { ProfScope ps(stream, 3); rc = launch_layernorm_affine_h16(stream, dt, w.h, 0, w.xnh, TP, d, lw.ffn_g, lw.ffn_b); }
+      if (rc) return rc;
+      GemmParamsH f1{};
+      f1.A = w.xnh; f1.lda = 2 * d; f1.W = lh.Wff1p; f1.ldw = 2 * d; f1.C = w.ffmidh; f1.ldc = 8 * d; f1.M = TP; f1.N = 8 * d; f1.K = 2 * d;
+      f1.bias = lw.bff1p; f1.acc_scale = lh.s_ff1;
+      { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_GEGLU, f1); }
+      if (rc) return rc;
+      GemmParamsH f2{};
+      f2.A = w.ffmidh; f2.lda = 8 * d; f2.W = lh.Wff2; f2.ldw = 8 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 8 * d;
+      f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d; f2.acc_scale = lh.s_ff2;
+      { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, f2); }
+      if (rc) return rc;
+      continue;
+    }
     if (dt != RAP_DT_F32) {
       // ---- reduced-precision block: 16-bit MFMA operands, fp32 accumulate, fp32 residual stream / LN / softmax
       const LayerWH& lh = m->half[dt].layers[i];
       for (int a = 0; a < 2; ++a) {
         const int j = 2 * i + a;
-        if ((rc = launch_layernorm_mod_h16(stream, dt, hres, hres_f16, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
+        { ProfScope ps(stream, 3); rc = launch_layernorm_mod_h16(stream, dt, hres, hres_f16, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row); }
+        if (rc) return rc;
         GemmParamsH g{};
         g.A = w.xnh; g.lda = d; g.W = lh.Wqkv[a]; g.ldw = d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
         g.vt = w.vth; g.vt_nblk = w.vt_nblk;
@@ -536,7 +666,8 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, epi_resid, o); }
         if (rc) return rc;
       }
-      if ((rc = launch_layernorm_affine_h16(stream, dt, hres, hres_f16, w.xnh, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
+      { ProfScope ps(stream, 3); rc = launch_layernorm_affine_h16(stream, dt, hres, hres_f16, w.xnh, TP, d, lw.ffn_g, lw.ffn_b); }
+      if (rc) return rc;
       GemmParamsH f1{};
       f1.A = w.xnh; f1.lda = d; f1.W = lh.Wff1p; f1.ldw = d; f1.C = w.ffmidh; f1.ldc = 4 * d; f1.M = TP; f1.N = 8 * d; f1.K = d;
       f1.bias = lw.bff1p;
@@ -553,7 +684,8 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
     }
     for (int a = 0; a < 2; ++a) {   // a = 0: per-part attention, a = 1: per-sample attention (layer.py:152-160)
       const int j = 2 * i + a;
-      if ((rc = launch_layernorm_mod(stream, w.h, w.xn, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row))) return rc;
+      { ProfScope ps(stream, 3); rc = launch_layernorm_mod(stream, w.h, w.xn, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row); }
+      if (rc) return rc;
       GemmParams g{};
       g.A = w.xn; g.lda = d; g.W = lw.Wqkv[a]; g.ldw = d; g.C = w.qkv; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
       const bool fuse_qk = g_rap_fuse_qknorm != 0;
@@ -579,7 +711,8 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_BIAS_RESID, o); }
       if (rc) return rc;
     }
-    if ((rc = launch_layernorm_affine(stream, w.h, w.xn, TP, d, lw.ffn_g, lw.ffn_b))) return rc;
+    { ProfScope ps(stream, 3); rc = launch_layernorm_affine(stream, w.h, w.xn, TP, d, lw.ffn_g, lw.ffn_b); }
+    if (rc) return rc;
     GemmParams f1{};
     f1.A = w.xn; f1.lda = d; f1.W = lw.Wff1p; f1.ldw = d; f1.C = w.ffmid; f1.ldc = 4 * d; f1.M = TP; f1.N = 8 * d; f1.K = d;
     f1.bias = lw.bff1p;
@@ -750,12 +883,14 @@ extern "C" int rap_sample(const rap_model* m, const float* cond, const float* fe
     float* xt_slot = traj_xt + (size_t)s * n3;
     float* feats = (feats_out && s == num_steps - 1) ? feats_out : nullptr;
     if ((rc = forward_step(m, w, stream, w.xt, w.mod + (size_t)s * mod_step, 0, nullptr, T, w.v, feats))) return rc;
-    if ((rc = launch_euler_step(stream, w.xt, w.v, (float)t, (float)dt, x0_slot, w.xt, rigidity_forcing ? nullptr : xt_slot, n3)))
-      return rc;
+    { ProfScope ps(stream, 5); rc = launch_euler_step(stream, w.xt, w.v, (float)t, (float)dt, x0_slot, w.xt, rigidity_forcing ? nullptr : xt_slot, n3); }
+    if (rc) return rc;
     if (rigidity_forcing) {
-      if ((rc = launch_procrustes_fit(stream, cond, x0_slot, w.part_offsets, np, w.Rc, w.tc, w.proc_partials))) return rc;
+      { ProfScope ps(stream, 6); rc = launch_procrustes_fit(stream, cond, x0_slot, w.part_offsets, np, w.Rc, w.tc, w.proc_partials); }
+      if (rc) return rc;
       const float w0 = (float)(1.0 - t + dt), w1 = (float)(t - dt);
-      if ((rc = launch_rigid_apply(stream, cond, w.Rc, w.tc, w.part_offsets, np, w.xt, x_1, w0, w1, xt_slot, 1))) return rc;
+      { ProfScope ps(stream, 7); rc = launch_rigid_apply(stream, cond, w.Rc, w.tc, w.part_offsets, np, w.xt, x_1, w0, w1, xt_slot, 1); }
+      if (rc) return rc;
     }
   }
   // final poses (modeling.py:389-391): fit_transformations(cond, trajs[-1])
@@ -900,6 +1035,36 @@ extern "C" int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t h
                               const float* gamma_k, void* stream) {
   if (!qk || !gamma_q || !gamma_k) return RAP_ERR_INVALID;
   return launch_qknorm_h16((hipStream_t)stream, dtype, qk, (int)TP, heads, gamma_q, gamma_k, 8.0f);
+}
+
+// ---- split-precision kernel-level entry points (compute dtype 3; paired fp16 head / tail operands, see include/rapflow.h) ----
+extern "C" int rap_x2_pack(const float* src, int64_t ld_src, int64_t rows, int32_t cols, float scale, uint16_t* dst, void* stream) {
+  if (!src || !dst || rows < 0 || cols < 0 || ld_src < cols) return RAP_ERR_INVALID;
+  return launch_x2_pack((hipStream_t)stream, src, (long)ld_src, (long)rows, cols, scale, dst);
+}
+extern "C" int rap_x2_unpack(const uint16_t* src, int64_t rows, int32_t cols, float inv_scale, float* dst, void* stream) {
+  if (!src || !dst || rows < 0 || cols < 0) return RAP_ERR_INVALID;
+  return launch_x2_unpack((hipStream_t)stream, src, (long)rows, cols, inv_scale, dst);
+}
+extern "C" int rap_x2_gemm(int32_t epilogue, const uint16_t* A, int32_t lda, const uint16_t* W, int32_t ldw, void* C, int32_t ldc, int32_t M,
+                           int32_t N, int32_t K_physical, const float* bias, const float* resid, int32_t ldr, float acc_scale, int32_t heads,
+                           const float* gamma_q, const float* gamma_k, float q_mul, uint16_t* vt, int32_t vt_nblk, void* stream) {
+  if (!A || !W || !C) return RAP_ERR_INVALID;
+  GemmParamsH g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K_physical; g.bias = bias;
+  g.resid = resid; g.ldr = ldr; g.heads = heads; g.vt = vt; g.vt_nblk = vt_nblk; g.gamma_q = gamma_q; g.gamma_k = gamma_k;
+  g.q_mul = q_mul; g.acc_scale = acc_scale;
+  return launch_gemm_h16((hipStream_t)stream, RAP_DT_F32X2, epilogue, g);
+}
+extern "C" int rap_x2_attention(const uint16_t* qk, const uint16_t* vt, int32_t vt_nblk, const int32_t* cu_seqlens, int32_t nseg,
+                                uint16_t* out, int64_t TP, int32_t heads, void* ws, size_t ws_bytes, void* stream_) {
+  if (!qk || !vt || !cu_seqlens || !out || nseg < 0 || TP < 0 || TP > 0x7fffffffLL / 16) return RAP_ERR_INVALID;
+  if (!ws || ws_bytes < rap_attention_workspace_bytes(TP, nseg)) return RAP_ERR_WORKSPACE;
+  const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc;
+  if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, 256))) return rc;
+  return launch_attention_x2(stream, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -338,6 +338,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
 // sort_ws: nseg ints; nullptr = segment order (kernel-level entry points without scratch).
 #define WL_THREADS 1024
 #define WL_TILE 4096
+// a segment's length as every stage of the kernel sees it: never negative (a decreasing table -- reachable through the kernel-level
+// entry point, or under deferred validation before round 5 sanitised the tables -- made the item count negative)
+__device__ __forceinline__ int wl_len(const int32_t* __restrict__ cu, int s) { const int l = cu[s + 1] - cu[s]; return l > 0 ? l : 0; }
 __global__ __launch_bounds__(WL_THREADS) void build_attn_worklist_kernel(const int32_t* __restrict__ cu, int nseg, AttnWorkItem* __restrict__ items,
                                                                           int max_items, int bq, int32_t* __restrict__ sort_ws) {
   if (blockIdx.x != 0) return;
@@ -347,8 +350,8 @@ __global__ __launch_bounds__(WL_THREADS) void build_attn_worklist_kernel(const i
     if (tid != 0) return;
     int n = 0;
     for (int s = 0; s < nseg; ++s) {
-      const int a = cu[s], b = cu[s + 1];
-      for (int q0 = 0; q0 < b - a && n < max_items; q0 += bq) { const AttnWorkItem w = {a, b - a, q0, 0}; items[n++] = w; }
+      const int a = cu[s], len = wl_len(cu, s);
+      for (int q0 = 0; q0 < len && n < max_items; q0 += bq) { const AttnWorkItem w = {a, len, q0, 0}; items[n++] = w; }
     }
     for (; n < max_items; ++n) items[n] = none;
     return;
@@ -360,11 +363,11 @@ __global__ __launch_bounds__(WL_THREADS) void build_attn_worklist_kernel(const i
   // ---- ranks
   for (int s0 = 0; s0 < nseg; s0 += WL_THREADS) {          // segments owned by this thread in this pass: s0 + tid
     const int s = s0 + tid;
-    const int my = s < nseg ? cu[s + 1] - cu[s] : -1;
+    const int my = s < nseg ? wl_len(cu, s) : -1;
     int rank = 0;
     for (int j0 = 0; j0 < nseg; j0 += WL_TILE) {
       __syncthreads();
-      for (int j = tid; j < WL_TILE && j0 + j < nseg; j += WL_THREADS) lens[j] = cu[j0 + j + 1] - cu[j0 + j];
+      for (int j = tid; j < WL_TILE && j0 + j < nseg; j += WL_THREADS) lens[j] = wl_len(cu, j0 + j);
       __syncthreads();
       const int nj = nseg - j0 < WL_TILE ? nseg - j0 : WL_TILE;
       if (s < nseg)
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(WL_THREADS) void build_attn_worklist_kernel(const i
   const int per = (nseg + WL_THREADS - 1) / WL_THREADS;
   const int r0 = tid * per, r1 = (r0 + per) < nseg ? (r0 + per) : nseg;
   int sum = 0;
-  for (int r = r0; r < r1; ++r) { const int sg = order[r]; sum += (cu[sg + 1] - cu[sg] + bq - 1) / bq; }
+  for (int r = r0; r < r1; ++r) { const int sg = order[r]; sum += (wl_len(cu, sg) + bq - 1) / bq; }
   partial[tid] = sum;
   __syncthreads();
   if (tid == 0) {
@@ -391,11 +394,12 @@ __global__ __launch_bounds__(WL_THREADS) void build_attn_worklist_kernel(const i
   int n = partial[tid];
   for (int r = r0; r < r1; ++r) {
     const int sg = order[r];
-    const int a = cu[sg], len = cu[sg + 1] - a;
+    const int a = cu[sg], len = wl_len(cu, sg);
     for (int q0 = 0; q0 < len; q0 += bq, ++n)
       if (n < max_items) { const AttnWorkItem w = {a, len, q0, 0}; items[n] = w; }
   }
-  const int total = total_items < max_items ? total_items : max_items;
+  __syncthreads();                     // the padding below must not race with another thread's emit
+  const int total = total_items < 0 ? 0 : total_items < max_items ? total_items : max_items;
   for (int i = total + tid; i < max_items; i += WL_THREADS) items[i] = none;
 }
 

@@ -281,6 +281,177 @@ __device__ __forceinline__ void gemm_h16_qknorm_epilogue(const GemmParamsH& p, f
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-precision epilogues (RAP_DT_F32X2, round 5; half.h).  The accumulators hold acc_scale^-1 times the fp32-accurate product
+// (weights are stored pre-multiplied by a power of two, see rap_model_set_compute_dtype); 16-bit outputs leave as fp16 head / tail
+// planes in the paired layout: the 64 physical columns of a wave tile's line are [32 heads | 32 tails] of ONE 32-column chunk.
+// Same transposition slabs as above (<= H16_STG_BYTES per wave).
+//   EPI_H_BIAS_RESID_F32: C fp32 (M,N) = resid + acc * scale + bias                       (out-projection, ff2)
+//   EPI_H_GEGLU:          C paired (M, 2 * N/2) = split((h + bh) * gelu_erf(g + bg))      (ff1; wave tile = 32 outputs = one chunk)
+//   EPI_H_QKV (c == 2):   vt paired [H][blk][2 chunks][64 d][32 heads | 32 tails] in vt_pos order (chunk = bit 5 of the token index)
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int TM>
+__device__ __forceinline__ void gemm_x2_epilogue(const GemmParamsH& p, f32x16 (&acc)[TM][2], unsigned char* stg, int mw, int nw, int lane) {
+  const int hi = lane >> 5, l31 = lane & 31;
+  const float sc = p.acc_scale;
+  if constexpr (EPI == EPI_H_GEGLU) {
+    u16* C = reinterpret_cast<u16*>(p.C);
+    u16* sh = reinterpret_cast<u16*>(stg);       // [32 rows][72]: heads in columns 0..31, tails in 32..63
+    const float bh = p.bias ? p.bias[nw + l31] : 0.f;
+    const float bg = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      f32x2 h2[8], g2[8], o2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        h2[j] = __builtin_elementwise_fma(f32x2{acc[i][0][2 * j], acc[i][0][2 * j + 1]}, f32x2{sc, sc}, f32x2{bh, bh});
+        g2[j] = __builtin_elementwise_fma(f32x2{acc[i][1][2 * j], acc[i][1][2 * j + 1]}, f32x2{sc, sc}, f32x2{bg, bg});
+      }
+      geglu_pairs<8>(h2, g2, o2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x2 s2 = {f16_sat(o2[j].x), f16_sat(o2[j].y)};
+        const typename H16<RAP_DT_F16>::T2 h16 = __builtin_convertvector(s2, typename H16<RAP_DT_F16>::T2);
+        const typename H16<RAP_DT_F16>::T2 l16 = __builtin_convertvector(s2 - __builtin_convertvector(h16, f32x2), typename H16<RAP_DT_F16>::T2);
+        const unsigned ph = __builtin_bit_cast(unsigned, h16), pl = __builtin_bit_cast(unsigned, l16);
+        sh[mfma32_crow(2 * j, hi) * 72 + l31] = (u16)(ph & 0xffffu);
+        sh[mfma32_crow(2 * j + 1, hi) * 72 + l31] = (u16)(ph >> 16);
+        sh[mfma32_crow(2 * j, hi) * 72 + 32 + l31] = (u16)(pl & 0xffffu);
+        sh[mfma32_crow(2 * j + 1, hi) * 72 + 32 + l31] = (u16)(pl >> 16);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), col = (lane & 7) * 8;
+        const uint4 v = *reinterpret_cast<const uint4*>(sh + row * 72 + col);
+        const int m = mw + i * 32 + row;
+        if (m < p.M) *reinterpret_cast<uint4*>(C + (size_t)m * p.ldc + nw + col) = v;     // physical columns of chunk nw >> 6: [nw, nw + 64)
+      }
+    }
+    return;
+  }
+  if constexpr (EPI == EPI_H_BIAS_RESID_F32) {
+    float* C = reinterpret_cast<float*>(p.C);
+    float* sf = reinterpret_cast<float*>(stg);   // [32 rows][64 columns]
+    const float b0 = p.bias ? p.bias[nw + l31] : 0.f;
+    const float b1 = p.bias ? p.bias[nw + 32 + l31] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float4 rr[8];
+      if (p.resid) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          int m = mw + i * 32 + it * 4 + (lane >> 4);
+          m = m < p.M ? m : p.M - 1;
+          rr[it] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + nw + (lane & 15) * 4);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sf[mfma32_crow(r, hi) * 64 + l31] = __builtin_fmaf(acc[i][0][r], sc, b0);
+        sf[mfma32_crow(r, hi) * 64 + 32 + l31] = __builtin_fmaf(acc[i][1][r], sc, b1);
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4), col = (lane & 15) * 4;
+        float4 v = *reinterpret_cast<const float4*>(sf + row * 64 + col);
+        if (p.resid) { v.x += rr[it].x; v.y += rr[it].y; v.z += rr[it].z; v.w += rr[it].w; }
+        const int m = mw + i * 32 + row;
+        if (m < p.M) *reinterpret_cast<float4*>(C + (size_t)m * p.ldc + nw + col) = v;
+      }
+    }
+    return;
+  }
+  if constexpr (EPI == EPI_H_QKV) {
+    // the V column tiles of the fused QKV projection (normal product: a lane owns a column d and 16 of every 32 tokens)
+    u16* sh = reinterpret_cast<u16*>(stg);       // [64 d][72]: one chunk (32 tokens) of one 64-token block: 32 heads | 32 tails
+    const int dmodel = p.heads * 64;
+    const int h = (nw - 2 * dmodel) >> 6;
+#pragma unroll
+    for (int ip = 0; ip < TM / 2; ++ip) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * ip + ii;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int mb = mw + i * 32 + 8 * g + 4 * hi;          // first of 4 consecutive tokens
+            float v0 = acc[i][j][4 * g + 0] * sc, v1 = acc[i][j][4 * g + 1] * sc, v2 = acc[i][j][4 * g + 2] * sc, v3 = acc[i][j][4 * g + 3] * sc;
+            v0 = (mb + 0 < p.M) ? v0 : 0.f; v1 = (mb + 1 < p.M) ? v1 : 0.f;
+            v2 = (mb + 2 < p.M) ? v2 : 0.f; v3 = (mb + 3 < p.M) ? v3 : 0.f;
+            const int inpos = 16 * (g >> 1) + 8 * hi + 4 * (g & 1);   // = vt_pos(32 ii + 8 g + 4 hi) - 32 ii
+            uint2 ph, pl;
+            x2_split4(v0, v1, v2, v3, ph, pl);
+            *reinterpret_cast<uint2*>(sh + (j * 32 + l31) * 72 + inpos) = ph;
+            *reinterpret_cast<uint2*>(sh + (j * 32 + l31) * 72 + 32 + inpos) = pl;
+          }
+        }
+        u16* dst = p.vt + (((size_t)h * p.vt_nblk + ((mw + 64 * ip) >> 6)) * 2 + ii) * (64 * 64);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int d = it * 8 + (lane >> 3), ch = (lane & 7) * 8;
+          *reinterpret_cast<uint4*>(dst + d * 64 + ch) = *reinterpret_cast<const uint4*>(sh + d * 72 + ch);
+        }
+      }
+    }
+    return;
+  }
+}
+
+// q / k column tiles of the fused QKV projection in split precision (swapped product, cf. gemm_h16_qknorm_epilogue): the row norm in
+// fp32 from the (re-scaled) accumulators, then head / tail planes; plane [c][h][chunk][m][64 physical] (chunk = 32 head dims).
+template <int TM>
+__device__ __forceinline__ void gemm_x2_qknorm_epilogue(const GemmParamsH& p, f32x16 (&acc)[TM][2], int mw, int nw, int lane) {
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int dmodel = p.heads * 64;
+  const int c = nw / dmodel;                      // 0 = q, 1 = k (wave-uniform)
+  const int h = (nw - c * dmodel) >> 6;
+  const float* gam = (c == 0 ? p.gamma_q : p.gamma_k) + h * 64;
+  const float mul = c == 0 ? p.q_mul : 8.0f;
+  const float sc = p.acc_scale;
+  float g[2][16];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[j][r] = gam[32 * j + mfma32_crow(r, hi)] * mul;
+  u16* plane = reinterpret_cast<u16*>(p.C) + (((size_t)(c * p.heads + h) * 2) * p.M) * 64;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] *= sc; ss = __builtin_fmaf(acc[i][j][r], acc[i][j][r], ss); }
+    {
+      const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+      ss = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    const int m = mw + 32 * i + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float v8[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float vx = acc[i][j][8 * t + e] * inv * g[j][8 * t + e];
+          const float vy = acc[i][j][8 * t + 4 + e] * inv * g[j][8 * t + 4 + e];
+          const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(vx), __float_as_uint(vy), false, false);
+          v8[e] = __uint_as_float(s2[0]); v8[4 + e] = __uint_as_float(s2[1]);
+        }
+        x2_t8 h8, l8;
+        x2_split8(v8, h8, l8);
+        u16* dst = plane + ((size_t)j * p.M + m) * 64 + 16 * t + 8 * hi;      // chunk j of the head: dims 32 j + 16 t + 8 hi .. +7
+        if (m < p.M) {
+          *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, h8);
+          *reinterpret_cast<uint4*>(dst + 32) = __builtin_bit_cast(uint4, l8);
+        }
+      }
+    }
+  }
+}
+
 template <int EPI, int DT, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16_kernel(GemmParamsH p) {
   typedef typename H16<DT>::T8 T8;
@@ -465,7 +636,23 @@ extern "C" int rap_debug_gemm_ts(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(
 // LDS image of a stage: A as [h][wave row][2 x 32 rows] x 128 B and W as [g][wave column][32 rows] x 128 B (the halves are
 // contiguous 16 KB blocks = 2 DMA pieces per thread); the permutation lives in the per-lane GLOBAL source address.
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int DT, int PRIO, int STAG>
+// split-precision phase: (head, tail) fragment pairs (ka, kb) of the three kept products, the two row tiles alternating
+#define X2_MMA1(SWP, H, G, FB, KA, KB)                                                                        \
+  if constexpr (SWP) {                                                                                        \
+    acc[2 * (H)][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[KB]), __builtin_bit_cast(T8, fa[0][KA]), acc[2 * (H)][G]);           \
+    acc[2 * (H) + 1][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[KB]), __builtin_bit_cast(T8, fa[1][KA]), acc[2 * (H) + 1][G]);   \
+  } else {                                                                                                    \
+    acc[2 * (H)][G] = H16<DT>::mfma(__builtin_bit_cast(T8, fa[0][KA]), __builtin_bit_cast(T8, FB[KB]), acc[2 * (H)][G]);           \
+    acc[2 * (H) + 1][G] = H16<DT>::mfma(__builtin_bit_cast(T8, fa[1][KA]), __builtin_bit_cast(T8, FB[KB]), acc[2 * (H) + 1][G]);   \
+  }
+#define X2_MMA(SWP, H, G, FB)                                                                                 \
+  X2_MMA1(SWP, H, G, FB, 2, 0) X2_MMA1(SWP, H, G, FB, 0, 2) X2_MMA1(SWP, H, G, FB, 3, 1) X2_MMA1(SWP, H, G, FB, 1, 3)               \
+  X2_MMA1(SWP, H, G, FB, 0, 0) X2_MMA1(SWP, H, G, FB, 1, 1)
+// X2 (round 5): the split-precision product on paired operands (half.h RAP_DT_F32X2; DT = fp16).  A 128-byte line of a stage is 32 heads
+// followed by 32 tails of one 32-column chunk, so the fragments of "k-steps" 0, 1 are head fragments and those of 2, 3 the tail
+// fragments of the same 32 logical columns; a phase multiplies head x head, head x tail and tail x head into the one accumulator:
+// 12 MFMAs instead of 8 on the same fragment reads and LDS-DMA pieces (1.5 x the MFMA work per staged byte of the plain kernel).
+template <int EPI, int DT, int PRIO, int STAG, bool X2 = false>
 __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   typedef typename H16<DT>::T8 T8;
   constexpr int TM = 4;
@@ -543,7 +730,9 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
 #define PH_MMA(SWP, H, G, FB)                                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                                          \
   if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                    \
-  if constexpr (SWP) {                                                                                        \
+  if constexpr (X2) {                                                                                         \
+    X2_MMA(SWP, H, G, FB)                                                                                     \
+  } else if constexpr (SWP) {                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                        \
       acc[2 * (H)][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[ks]), __builtin_bit_cast(T8, fa[0][ks]), acc[2 * (H)][G]);         \
       acc[2 * (H) + 1][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[ks]), __builtin_bit_cast(T8, fa[1][ks]), acc[2 * (H) + 1][G]); \
@@ -611,7 +800,14 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   static_assert(8 * H16_STG_BYTES <= 2 * STAGE, "staging slabs must fit the operand buffers");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if constexpr (EPI == EPI_H_QKV_NORM) {
+  if constexpr (X2) {
+    if constexpr (EPI == EPI_H_QKV_NORM) {
+      if (swp) gemm_x2_qknorm_epilogue<TM>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+      else gemm_x2_epilogue<EPI_H_QKV, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
+    } else {
+      gemm_x2_epilogue<EPI, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
+    }
+  } else if constexpr (EPI == EPI_H_QKV_NORM) {
     if (swp) gemm_h16_qknorm_epilogue<DT, TM>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
     else gemm_h16_epilogue<EPI_H_QKV, DT, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wr * 128, n0 + wc * 64, lane);
   } else {
@@ -620,10 +816,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_ph_kernel(GemmParamsH p) {
   GEMM_TS(4)
 }
 
-template <int EPI, int DT, int PRIO, int STAG>
+template <int EPI, int DT, int PRIO, int STAG, bool X2 = false>
 static int launch_ph(hipStream_t stream, const GemmParamsH& p) {
   constexpr int LDS = 4 * 256 * 128;
-  auto kern = gemm_h16_ph_kernel<EPI, DT, PRIO, STAG>;
+  auto kern = gemm_h16_ph_kernel<EPI, DT, PRIO, STAG, X2>;
   // per device and cheap: set unconditionally (a process may drive several GPUs)
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
     rap_set_last_hip_error((int)hipGetLastError());
@@ -658,7 +854,7 @@ static int launch_ph(hipStream_t stream, const GemmParamsH& p) {
 // epilogue (7.4 with the residual's HBM latency; GEGLU is VALU-bound: the younger wave of each SIMD finishes 2.5 us after the older) +
 // 0.5-0.8 us of turn-around.  Starting every other block half a period late (so that the CUs do not store in lockstep) changes nothing (+-1 %).
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int DT>
+template <int EPI, int DT, bool X2 = false>
 __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
   typedef typename H16<DT>::T8 T8;
   constexpr int TM = 4;
@@ -724,7 +920,9 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
   // the two alternatives are reconciled with register copies at every phase).
 #define PHP_MMA(SWP, H, G, FB)                                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                                          \
-  if constexpr (SWP) {                                                                                        \
+  if constexpr (X2) {                                                                                         \
+    X2_MMA(SWP, H, G, FB)                                                                                     \
+  } else if constexpr (SWP) {                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                        \
       acc[2 * (H)][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[ks]), __builtin_bit_cast(T8, fa[0][ks]), acc[2 * (H)][G]);         \
       acc[2 * (H) + 1][G] = H16<DT>::mfma(__builtin_bit_cast(T8, FB[ks]), __builtin_bit_cast(T8, fa[1][ks]), acc[2 * (H) + 1][G]); \
@@ -841,7 +1039,14 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
       const int last = par ^ 1;                  // the stage the last k-tile was read from: its bytes [16 KB, 64 KB) are idle
       unsigned char* slab = wave < 5 ? smem + last * STAGE + 16384 + wave * H16_STG_BYTES : smem + 2 * STAGE + (wave - 5) * H16_STG_BYTES;
       static_assert(5 * H16_STG_BYTES <= STAGE - 16384 && 3 * H16_STG_BYTES <= 32768, "epilogue slabs must fit the idle regions");
-      if constexpr (EPI == EPI_H_QKV_NORM) {
+      if constexpr (X2) {
+        if constexpr (EPI == EPI_H_QKV_NORM) {
+          if (swp) gemm_x2_qknorm_epilogue<TM>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
+          else gemm_x2_epilogue<EPI_H_QKV, TM>(p, acc, slab, m0 + wr * 128, n0 + wc * 64, lane);
+        } else {
+          gemm_x2_epilogue<EPI, TM>(p, acc, slab, m0 + wr * 128, n0 + wc * 64, lane);
+        }
+      } else if constexpr (EPI == EPI_H_QKV_NORM) {
         if (swp) gemm_h16_qknorm_epilogue<DT, TM>(p, acc, m0 + wr * 128, n0 + wc * 64, lane);
         else gemm_h16_epilogue<EPI_H_QKV, DT, TM>(p, acc, slab, m0 + wr * 128, n0 + wc * 64, lane);
       } else {
@@ -861,10 +1066,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h16_php_kernel(GemmParamsH p) {
   }
 }
 
-template <int EPI, int DT>
+template <int EPI, int DT, bool X2 = false>
 static int launch_php(hipStream_t stream, const GemmParamsH& p) {
   constexpr int LDS = 4 * 256 * 128 + 32768;
-  auto kern = gemm_h16_php_kernel<EPI, DT>;
+  auto kern = gemm_h16_php_kernel<EPI, DT, X2>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
     rap_set_last_hip_error((int)hipGetLastError());
     return RAP_ERR_HIP;
@@ -1036,10 +1241,36 @@ static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
   }
 }
 
+// Split precision (RAP_DT_F32X2): p.K, lda, ldw (and ldc of the GEGLU output) are PHYSICAL fp16 counts = 2 x the logical ones; p.N and the fp32
+// outputs are logical.  The three epilogues of the model path on the phase-split kernels (persistent where the shape allows); any M
+// (rows are clamped by the one-tile kernel), N % 256 == 0, K_physical >= 128.
+static bool use_persistent_x2(const GemmParamsH& p) {
+  return g_rap_gemm_h16_persistent && p.M % 256 == 0 && p.K <= 8192 && (long)(p.M / 256) * (p.N / 256) >= 512 && p.lda <= (1 << 20) && p.ldw <= (1 << 20);
+}
+template <int EPI>
+static int launch_x2_variant(hipStream_t stream, const GemmParamsH& p) {
+  if (use_persistent_x2(p)) return launch_php<EPI, RAP_DT_F16, true>(stream, p);
+  return launch_ph<EPI, RAP_DT_F16, 0, 1, true>(stream, p);
+}
+static int launch_x2(hipStream_t stream, int epilogue, const GemmParamsH& p) {
+  if (p.N % 256 != 0 || p.K < 128 || p.K % 64 != 0) return RAP_ERR_INVALID;
+  switch (epilogue) {
+    case EPI_H_BIAS_RESID_F32: return launch_x2_variant<EPI_H_BIAS_RESID_F32>(stream, p);
+    case EPI_H_GEGLU:
+      if (p.ldc & 7) return RAP_ERR_INVALID;
+      return launch_x2_variant<EPI_H_GEGLU>(stream, p);
+    case EPI_H_QKV_NORM:
+      if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256 || !p.gamma_q || !p.gamma_k) return RAP_ERR_INVALID;
+      return launch_x2_variant<EPI_H_QKV_NORM>(stream, p);
+    default: return RAP_ERR_INVALID;
+  }
+}
+
 int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p) {
   if (p.M <= 0) return RAP_OK;
   if (p.N % 128 != 0 || p.K % 64 != 0 || p.K <= 0) return RAP_ERR_INVALID;      // K % 64: two 32-wide ring slices / one 64-wide tile
   if ((p.lda & 7) || (p.ldw & 7)) return RAP_ERR_INVALID;
+  if (dtype == RAP_DT_F32X2) return launch_x2(stream, epilogue, p);
   if (dtype == RAP_DT_BF16) return launch_dt<RAP_DT_BF16>(stream, epilogue, p);
   if (dtype == RAP_DT_F16) return launch_dt<RAP_DT_F16>(stream, epilogue, p);
   return RAP_ERR_INVALID;

@@ -15,6 +15,13 @@
 #define RAP_DT_F32 0
 #define RAP_DT_BF16 1
 #define RAP_DT_F16 2
+// Round 5: fp32-ACCURATE arithmetic on the fp16 matrix pipe ("split precision").  Every operand x is carried as an fp16 head and an
+// fp16 tail, x = hi + lo (hi = rn16(x), lo = rn16(x - hi): 22 significand bits), and a contraction keeps the three products
+// hi*hi + hi*lo + lo*hi in ONE fp32 accumulator (a product of two fp16 values is exact in fp32; the dropped lo*lo term is 2^-22
+// relative).  Storage is the "paired" layout: a logical row of K values is 2K fp16 values, chunk c = k >> 5 of 32 logical columns
+// occupying physical columns [64c, 64c + 32) = heads and [64c + 32, 64c + 64) = tails -- one 128-byte line per chunk, so the
+// LDS-DMA / swizzle / fragment-read machinery of the 16-bit kernels serves it unchanged with K_physical = 2 K.
+#define RAP_DT_F32X2 3
 
 typedef unsigned short u16;
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -64,11 +71,42 @@ template <int DT> __device__ __forceinline__ typename H16<DT>::T8 h16_pack8(floa
 }
 // Saturating fp16 pack for the 16-bit RESIDUAL STREAM (round 4): a plain float -> _Float16 conversion turns |x| > 65504
 // into inf, which the next LayerNorm turns into NaN for the whole row; the stream instead saturates at the largest finite fp16
-// (v_med3_f32, one VALU instruction per value; NaN stays NaN).  Operand and weight conversions do not saturate (RNE, as torch's).
-__device__ __forceinline__ float f16_sat(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+// (v_med3_f32 + a NaN select).  Operand and weight conversions do not saturate (RNE, as torch's).
+// (v_med3_f32 alone returns the MINIMUM of the other two when one operand is NaN -- it would turn NaN into -65504; ADVICE r04 --
+// hence the explicit select: NaN stays NaN as in the reference's own fp16 arithmetic.)
+__device__ __forceinline__ float f16_sat(float x) {
+  const float m = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+  return x != x ? x : m;
+}
 __device__ __forceinline__ typename H16<RAP_DT_F16>::T8 f16_pack8_sat(float a, float b, float c, float d, float e, float f, float g, float h) {
   return h16_pack8<RAP_DT_F16>(f16_sat(a), f16_sat(b), f16_sat(c), f16_sat(d), f16_sat(e), f16_sat(f), f16_sat(g), f16_sat(h));
 }
+// ---- split precision (RAP_DT_F32X2): head / tail planes of 8 (or 4) fp32 values.  The head saturates at the largest finite fp16
+// (the range of the reference's own fp16 autocast inference); the tail x - hi is exact in fp32 and rounded once.
+typedef typename H16<RAP_DT_F16>::T8 x2_t8;
+typedef typename H16<RAP_DT_F16>::T4 x2_t4;
+__device__ __forceinline__ void x2_split8(const float (&v)[8], x2_t8& hi, x2_t8& lo) {
+  f32x8 s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = f16_sat(v[i]);          // the value itself is clipped to the fp16 range: head AND tail stay finite
+  hi = __builtin_convertvector(s, x2_t8);
+  lo = __builtin_convertvector(s - __builtin_convertvector(hi, f32x8), x2_t8);
+}
+// no saturation: for values bounded by construction (softmax probabilities, attention outputs of finite V)
+__device__ __forceinline__ void x2_split8_nosat(const f32x8 v, x2_t8& hi, x2_t8& lo) {
+  hi = __builtin_convertvector(v, x2_t8);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), x2_t8);
+}
+__device__ __forceinline__ void x2_split4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
+  const f32x4 s = {f16_sat(a), f16_sat(b), f16_sat(c), f16_sat(d)};
+  const x2_t4 h = __builtin_convertvector(s, x2_t4);
+  const x2_t4 l = __builtin_convertvector(s - __builtin_convertvector(h, f32x4), x2_t4);
+  hi = __builtin_bit_cast(uint2, h);
+  lo = __builtin_bit_cast(uint2, l);
+}
+// physical column of logical column k in the paired layout (head plane; the tail is 32 further)
+__host__ __device__ __forceinline__ int x2_col(int k) { return ((k >> 5) << 6) | (k & 31); }
+
 template <int DT> __device__ __forceinline__ void h16_unpack8(uint4 raw, float (&out)[8]) {
   const typename H16<DT>::T8 v = __builtin_bit_cast(typename H16<DT>::T8, raw);
 #pragma unroll

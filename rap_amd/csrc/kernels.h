@@ -92,6 +92,8 @@ int launch_rigid_apply(hipStream_t stream, const float* src, const float* R, con
                        float* traj_slot_or_null, int blend);
 // segment tables
 int launch_token_sample(hipStream_t stream, const int32_t* cu_batch, int B, int32_t* token_sample);
+// out[i] = running maximum of clamp(cu[i], 0, limit): a segment table that is safe to index with, equal to cu when cu is consistent
+int launch_sanitize_cu(hipStream_t stream, const int32_t* cu, int n, long limit, int32_t* out);
 int launch_part_offsets(hipStream_t stream, const int64_t* points_per_part, int nparts, int32_t* part_offsets, long limit = -1);
 int launch_check_batch(hipStream_t stream, const int64_t* points_per_part, const int32_t* cu_batch, int B, int P, long TP, int32_t* flag);
 int launch_poison_on_flag(hipStream_t stream, const int32_t* flag, float* buf, long n);
@@ -133,6 +135,9 @@ struct GemmParamsH {
   // gemm_h16_splits() > 1, K is split over that many blocks per 128 x 128 tile (gridDim.y) writing fp32 partial tiles to splitk_ws, and a
   // combine pass forms residual + (bias + partials) in a fixed order (deterministic; differs from the unsplit sum in fp32 rounding only)
   float* splitk_ws = nullptr;
+  // RAP_DT_F32X2 (split precision): the weight planes are stored multiplied by a power of two (their tails stay normal fp16 numbers);
+  // every epilogue multiplies the accumulators by acc_scale = its inverse (exact) first
+  float acc_scale = 1.0f;
 };
 // 1 = no split; 2 or 4 for GEMMs with K >= 1024 whose 128 x 128 tile grid covers at most a quarter / half of the CUs (tuning key 6)
 int gemm_h16_splits(int M, int N, int K);
@@ -161,6 +166,18 @@ int launch_convert_f16_sat(hipStream_t stream, const float* src, uint16_t* dst, 
 #define RAP_QMUL_PRESCALED 1.44269504088896340736f
 int launch_qknorm_h16(hipStream_t stream, int dtype, uint16_t* qk, int TP, int heads, const float* gamma_q,
                       const float* gamma_k, float q_mul);
+
+// ---------------------------------------------------------------------------------------------
+// Split precision (compute dtype RAP_DT_F32X2 = 3, half.h): fp32-accurate products on the fp16 matrix pipe.  Operands are fp16 head /
+// tail planes in the paired layout (a logical row of K values = 2K fp16); launch_gemm_h16 / launch_layernorm_*_h16 take dtype 3 with
+// PHYSICAL K / lda / ldw (and ldc of the GEGLU output); attention has its own kernel (attn_x2.hip).
+// ---------------------------------------------------------------------------------------------
+int launch_x2_pack(hipStream_t stream, const float* src, long ld_src, long rows, int cols, float scale, uint16_t* dst);
+int launch_x2_unpack(hipStream_t stream, const uint16_t* src, long rows, int cols, float inv_scale, float* dst);
+int launch_max_abs(hipStream_t stream, const float* x, size_t n, float* out);      // *out must be 0 before; non-negative result
+// q, k [2][H][2 chunks][TP][64 physical]; vt [H][vt_nblk][2 chunks][64 d][64 physical]; out paired (TP, 2 * H * 64); online softmax
+int launch_attention_x2(hipStream_t stream, const uint16_t* qk, const uint16_t* vt, int vt_nblk, uint16_t* out, int TP, int heads,
+                        const AttnWorkItem* items, int max_items);
 
 // ---------------------------------------------------------------------------------------------
 // generation selection by rigidity (rigidity.hip; reference modeling.py:456-592, eval/metrics.py:511-622)

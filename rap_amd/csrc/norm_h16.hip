@@ -72,6 +72,68 @@ __global__ __launch_bounds__(256) void layernorm_h16_kernel(const void* __restri
   }
 }
 
+// Split-precision twin (RAP_DT_F32X2, round 5): fp32 residual stream in, the LayerNorm output as fp16 head / tail planes in the paired
+// layout (half.h: logical column k -> physical x2_col(k), tail 32 further; row stride 2 d).  A lane's 4 consecutive columns lie in one
+// 32-column chunk, so it writes 8 bytes of heads and 8 bytes of tails; 8 lanes cover a chunk's 128-byte line.  6 KiB per token.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_x2_kernel(const float* __restrict__ x, u16* __restrict__ out, int TP,
+                                                           const float* __restrict__ gain_base, const float* __restrict__ shift_base,
+                                                           long row_stride, const int32_t* __restrict__ token_row, int add_one) {
+  const int d = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= TP) return;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(x + (size_t)row * d + (i * 64 + lane) * 4);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + e * e);
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  const long mrow = token_row ? (long)token_row[row] : 0;
+  const float* g = gain_base + mrow * row_stride;
+  const float* b = shift_base + mrow * row_stride;
+  const float one = add_one ? 1.0f : 0.0f;
+  u16* orow = out + (size_t)row * (2 * d);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const float4 gg = *reinterpret_cast<const float4*>(g + c);
+    const float4 bb = *reinterpret_cast<const float4*>(b + c);
+    const float ox = (v[i].x - mean) * rstd * (one + gg.x) + bb.x;
+    const float oy = (v[i].y - mean) * rstd * (one + gg.y) + bb.y;
+    const float oz = (v[i].z - mean) * rstd * (one + gg.z) + bb.z;
+    const float ow = (v[i].w - mean) * rstd * (one + gg.w) + bb.w;
+    uint2 hi, lo;
+    x2_split4(ox, oy, oz, ow, hi, lo);
+    *reinterpret_cast<uint2*>(orow + x2_col(c)) = hi;
+    *reinterpret_cast<uint2*>(orow + x2_col(c) + 32) = lo;
+  }
+}
+static int launch_ln_x2(hipStream_t stream, const void* x, int x_f16, u16* out, int TP, int d, const float* gain, const float* shift,
+                        long row_stride, const int32_t* token_row, int add_one) {
+  if (TP <= 0) return RAP_OK;
+  if (d % 256 != 0 || d > 1024 || x_f16) return RAP_ERR_INVALID;      // the split mode keeps the residual stream in fp32
+  const float* xf = reinterpret_cast<const float*>(x);
+  dim3 grid((TP + 3) / 4), block(256);
+  switch (d / 256) {
+    case 1: hipLaunchKernelGGL((layernorm_x2_kernel<1>), grid, block, 0, stream, xf, out, TP, gain, shift, row_stride, token_row, add_one); break;
+    case 2: hipLaunchKernelGGL((layernorm_x2_kernel<2>), grid, block, 0, stream, xf, out, TP, gain, shift, row_stride, token_row, add_one); break;
+    case 3: hipLaunchKernelGGL((layernorm_x2_kernel<3>), grid, block, 0, stream, xf, out, TP, gain, shift, row_stride, token_row, add_one); break;
+    default: hipLaunchKernelGGL((layernorm_x2_kernel<4>), grid, block, 0, stream, xf, out, TP, gain, shift, row_stride, token_row, add_one); break;
+  }
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
 template <int DT, bool XH>
 static int launch_ln_h16(hipStream_t stream, const void* x, u16* out, int TP, int d, const float* gain, const float* shift,
                          long row_stride, const int32_t* token_row, int add_one) {
@@ -89,6 +151,7 @@ static int launch_ln_h16(hipStream_t stream, const void* x, u16* out, int TP, in
 }
 static int launch_ln_h16_any(hipStream_t stream, int dtype, const void* x, int x_f16, u16* out, int TP, int d, const float* gain,
                              const float* shift, long row_stride, const int32_t* token_row, int add_one) {
+  if (dtype == RAP_DT_F32X2) return launch_ln_x2(stream, x, x_f16, out, TP, d, gain, shift, row_stride, token_row, add_one);
   if (dtype == RAP_DT_BF16)
     return x_f16 ? launch_ln_h16<RAP_DT_BF16, true>(stream, x, out, TP, d, gain, shift, row_stride, token_row, add_one)
                  : launch_ln_h16<RAP_DT_BF16, false>(stream, x, out, TP, d, gain, shift, row_stride, token_row, add_one);

@@ -91,6 +91,32 @@ int launch_token_sample(hipStream_t stream, const int32_t* cu_batch, int B, int3
   return RAP_OK;
 }
 
+// out[i] = max_{j <= i} clamp(cu[j], 0, limit): the caller's cu_seqlens made safe to index with (under deferred validation
+// a malformed table -- last entry beyond the point count, or decreasing -- reached token_sample_kernel and the attention work lists
+// un-clamped).  A consistent table is returned unchanged.  One block; thread t owns a contiguous chunk, prefix maximum across chunks.
+#define SAN_THREADS 1024
+__global__ __launch_bounds__(SAN_THREADS) void sanitize_cu_kernel(const int32_t* __restrict__ cu, int n, int limit, int32_t* __restrict__ out) {
+  if (blockIdx.x != 0) return;
+  __shared__ int part[SAN_THREADS];
+  const int tid = threadIdx.x;
+  const int per = (n + SAN_THREADS - 1) / SAN_THREADS;
+  const int i0 = tid * per, i1 = (i0 + per) < n ? (i0 + per) : n;
+  int m = 0;
+  for (int i = i0; i < i1; ++i) { int v = cu[i]; v = v < 0 ? 0 : v > limit ? limit : v; m = v > m ? v : m; }
+  part[tid] = m;
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int t = 0; t < SAN_THREADS; ++t) { const int v = part[t]; part[t] = acc; acc = v > acc ? v : acc; } }
+  __syncthreads();
+  m = part[tid];
+  for (int i = i0; i < i1; ++i) { int v = cu[i]; v = v < 0 ? 0 : v > limit ? limit : v; m = v > m ? v : m; out[i] = m; }
+}
+int launch_sanitize_cu(hipStream_t stream, const int32_t* cu, int n, long limit, int32_t* out) {
+  if (n <= 0) return RAP_OK;
+  hipLaunchKernelGGL(sanitize_cu_kernel, dim3(1), dim3(SAN_THREADS), 0, stream, cu, n, (int)limit, out);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
+
 // part_offsets[i] = sum_{i' < i} points_per_part.flat[i']   (B*P+1 entries; empty parts have zero length --
 // the reference drops them, modeling.py:219-222; zero-length segments are no-ops for every kernel here).
 __global__ void part_offsets_kernel(const int64_t* __restrict__ ppp, int nparts, int32_t* __restrict__ off, long limit) {

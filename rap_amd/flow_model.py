@@ -70,7 +70,7 @@ class PointCloudDiT:
         if not (qk_norm and scale_emb_on and local_feat_concat_on):
             raise NotImplementedError("qk_norm, scale_emb_on, local_feat_concat_on must be True (RAP_inference.yaml:65, "
                                       "point_cloud_dit_12.yaml:8-9)")
-        if attn_dtype not in ("float16", "fp16", "bfloat16", "bf16", "float32", "fp32"):
+        if attn_dtype not in ("float16", "fp16", "bfloat16", "bf16", "float32", "fp32", "float32x2", "f32x2"):      # (the last two: this package's split-precision mode)
             raise ValueError(f"Unsupported attn_dtype: {attn_dtype}")   # point_cloud_dit.py:80-81
         if embed_dim != 64 * num_heads:
             raise NotImplementedError("head_dim must be 64")
@@ -81,7 +81,9 @@ class PointCloudDiT:
         # compute_dtype (an extension): "float32" (default) = exact-fp32 MFMA everywhere, i.e. at or above any
         # attn_dtype the reference accepts; "bfloat16" / "float16" = 16-bit MFMA GEMMs + attention with fp32
         # accumulation (what the reference's GPU inference runs under Lightning "16-mixed" autocast,
-        # trainer/infer.yaml:6); None = follow torch autocast at call time, like the reference's nn.Linear layers do.
+        # trainer/infer.yaml:6); "float32x2" = SPLIT PRECISION (round 5): fp32-accurate blocks on the fp16 matrix pipe -- operands as
+        # fp16 head + tail, three products per contraction, results at "float32"'s distance from fp64 at several times its speed;
+        # None = follow torch autocast at call time, like the reference's nn.Linear layers do.
         self.attn_dtype = attn_dtype
         if compute_dtype is not None and compute_dtype not in _lib.DTYPES:
             raise ValueError(f"Unsupported compute_dtype: {compute_dtype}")
@@ -198,7 +200,7 @@ class PointCloudDiT:
         lib = _lib.load()
         code = self._dtype_code()
         resolved = self.residual_dtype if self.residual_dtype != "auto" else ("float16" if code == 1 else "float32")
-        rcode = _lib.DTYPES[resolved]
+        rcode = 0 if code == 3 else _lib.DTYPES[resolved]      # split precision keeps the residual stream in fp32
         if lib.rap_model_residual_dtype(self._handle) != rcode:
             _lib.check(lib.rap_model_set_residual_dtype(self._handle, rcode), "rap_model_set_residual_dtype")
         if lib.rap_model_compute_dtype(self._handle) != code:

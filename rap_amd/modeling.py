@@ -73,8 +73,10 @@ class RectifiedPointFlow:
         #       per call -- and per shard -- which serialised the ~3 300 enqueues behind the previous call's GPU work.)
         #   "eager": read the flag back before enqueueing (one host sync per call), raise immediately -- the reference's behaviour.
         #   False / RAP_VALIDATE_INPUTS=0: no check (a latency-critical caller that validated its batches itself).
-        # Skipped while the stream is being captured into a HIP graph (a capture cannot read back); rap_sample's clamping of the
-        # part table rules out out-of-bounds reads in every mode.
+        # Skipped while the stream is being captured into a HIP graph (a capture cannot read back).  In EVERY mode the library works
+        # on sanitised segment tables -- the part table clamped to the point count, cu_seqlens clamped to [0, TP] and made
+        # non-decreasing on the device (round 5) -- so a malformed batch yields wrong (deferred: NaN) results, never an
+        # out-of-bounds access.
         if validate_inputs is None:
             env_v = os.environ.get("RAP_VALIDATE_INPUTS", "1")
             validate_inputs = False if env_v == "0" else ("eager" if env_v == "eager" else "deferred")
@@ -326,7 +328,9 @@ class RectifiedPointFlow:
         if flag is not None:
             stream = _lib.current_stream(device)
             with torch.cuda.device(device):
-                for buf in (res["R"], res["t"], res["end_point_trajectory"][S - 1], res["trajectory"][S - 1]):
+                # every result of an inconsistent batch: poses, ALL trajectory steps, the captured features
+                for buf in [res["R"], res["t"], res["end_point_trajectory"], res["trajectory"]] + (
+                        [res["transformer_features"]] if "transformer_features" in res else []):
                     _lib.check(lib.rap_poison_on_flag(_lib.ptr(flag), _lib.ptr(buf), buf.numel(), stream), "rap_poison_on_flag")
         return res
 
@@ -356,8 +360,9 @@ class RectifiedPointFlow:
             _lib.check(rc, "rap_sample")
             flag = d.get("flag")
             if flag is not None:
-                # deferred validation: an inconsistent batch yields NaN poses and a NaN final cloud, never plausible numbers
-                for buf in (R, t, traj_x0[S - 1], traj_xt[S - 1]):
+                # deferred validation: an inconsistent batch yields NaN poses, NaN clouds at EVERY flow step and NaN features -- never
+                # plausible numbers (round 4 poisoned only the poses and the last step)
+                for buf in [R, t, traj_x0, traj_xt] + ([feats_out] if feats_out is not None else []):
                     _lib.check(lib.rap_poison_on_flag(_lib.ptr(flag), _lib.ptr(buf), buf.numel(), stream), "rap_poison_on_flag")
         out = {"end_point_trajectory": traj_x0, "trajectory": traj_xt, "R": R, "t": t}
         if return_transformer_features:

@@ -149,5 +149,5 @@ def test_splitk_rule_of_the_16bit_residual_gemm_is_host_arithmetic():
     # epilogue 6 (two different meanings in rounds 2 and 3) is retired with ABI version 4: refused, never reinterpreted
     assert lib.rap_gemm_h16_splitk(1, 6, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 1 << 30, N) == -1
     assert lib.rap_gemm_h16(1, 6, one, 512, one, 512, one, 512, 256, 512, 512, N, one, 512, 0, N, 0, N) == -1
-    assert lib.rap_version() == _lib.ABI_VERSION == 4
+    assert lib.rap_version() == _lib.ABI_VERSION == 5
     assert lib.rap_poison_on_flag(N, one, 4, N) == -1 and lib.rap_poison_on_flag(one, N, 4, N) == -1

@@ -134,7 +134,15 @@ def test_c1_all_32_pairs_match_the_checker(dev):
     outh, t_h = _hip(cfg, sd, inp, 20, True, dev, dtype="bfloat16")
     eh = _errors(outh, ref, inp["cu_seqlens"], inp["points_per_part"])
     _record({"case": "c1_all_32_pairs", "dtype": "bf16", **eh, "hip_s": t_h})
-    assert eh["final_cloud"] <= 5e-2 and eh["R_frob"] <= 1e-1 and eh["t"] <= 5e-2, eh
+    # ~3 x the WORST pair of the 32 measured on MI355X (r04: cloud 4.9e-3, |dR|_F 9.7e-3, t 2.3e-3 -- pair 11, five times pair 0's): a 10 x
+    # regression of the bf16 path fails (the class bounds 5e-2 / 1e-1 of rounds 1-4 would have passed it)
+    assert eh["final_cloud"] <= 1.5e-2 and eh["R_frob"] <= 3e-2 and eh["t"] <= 7e-3, eh
+    del outh
+    # split precision (round 5): fp32-ACCURATE arithmetic on the fp16 matrix pipe -- held to the fp32 asserts, on every pair
+    outx, t_x = _hip(cfg, sd, inp, 20, True, dev, dtype="float32x2")
+    ex = _errors(outx, ref, inp["cu_seqlens"], inp["points_per_part"])
+    _record({"case": "c1_all_32_pairs", "dtype": "f32x2", **ex, "hip_s": t_x})
+    _assert_fp32(ex)
 
 
 def test_c3_16_samples_all_30_steps_match_the_checker(dev):
@@ -159,11 +167,15 @@ def test_c4_all_50_steps_match_the_checker(dev):
     _record({"case": "c4_all_50_steps", "dtype": "f32", **e, "hip_s": t_hip, "checker_s": t_ref})
     _assert_fp32(e)
     del out
-    for dtype, cloud_tol, R_tol in (("bfloat16", 5e-2, 1e-1),):
+    # bf16: ~3 x the measured deviation (r04: 5.4e-4 / 1.5e-3 / 3.1e-4); split precision: the fp32 asserts
+    for dtype, cloud_tol, R_tol, t_tol in (("bfloat16", 1.7e-3, 4.5e-3, 1e-3), ("float32x2", None, None, None)):
         outh, t_h = _hip(cfg, sd, inp, 50, True, dev, dtype=dtype)
         eh = _errors(outh, ref, inp["cu_seqlens"], inp["points_per_part"])
         _record({"case": "c4_all_50_steps", "dtype": dtype, **eh, "hip_s": t_h})
-        assert eh["final_cloud"] <= cloud_tol and eh["R_frob"] <= R_tol and eh["t"] <= cloud_tol, eh
+        if dtype == "float32x2":
+            _assert_fp32(eh)
+        else:
+            assert eh["final_cloud"] <= cloud_tol and eh["R_frob"] <= R_tol and eh["t"] <= t_tol, eh
         det = torch.linalg.det(outh["R"].double())
         assert (det - 1).abs().max().item() < 1e-4
 
@@ -174,7 +186,8 @@ def test_400k_token_sample_matches_the_checker(dev):
     velocity recovered from the end point (t = 1: x0_hat = x_1 - v) on every 16th point, everything else on all points."""
     cfg, sd = _weights(2)
     inp = S.make_inputs([[25000] * 16], seed=77)
-    for dtype, vtol, ctol in (("float32", 1e-4, TOL_CLOUD), ("bfloat16", 3e-2, 5e-2)):
+    # bf16: ~3 x the measured deviation (r04: velocity 5.4e-4, cloud 6.2e-4, last x_t 2.9e-3); split precision: the fp32 bounds
+    for dtype, vtol, ctol in (("float32", 1e-4, TOL_CLOUD), ("float32x2", 1e-4, TOL_CLOUD), ("bfloat16", 1.7e-3, 9e-3)):
         out, t_hip = _hip(cfg, sd, inp, 1, True, dev, dtype=dtype)
         if dtype == "float32":
             ref, t_ref = _checker(cfg, sd, inp, 1, True, dev)
@@ -187,7 +200,7 @@ def test_400k_token_sample_matches_the_checker(dev):
                  "checker_s": t_ref})
         assert ev <= vtol * max(1.0, vmax), (dtype, ev, vmax)
         assert e["final_cloud"] <= ctol and e["final_x_t"] <= ctol, (dtype, e)
-        if dtype == "float32":
+        if dtype in ("float32", "float32x2"):
             assert e["R_frob"] <= TOL_R and e["t"] <= TOL_T, e
 
 
@@ -206,7 +219,7 @@ def test_ragged_regime_batch_on_the_padded_fast_path(dev):
     TP = int(inp["pointclouds"].shape[0])
     assert TP % 256 != 0
     ref = None
-    for dtype in ("float32", "bfloat16", "float16"):
+    for dtype in ("float32", "bfloat16", "float16", "float32x2"):
         out, _ = _hip(cfg, sd, inp, 2, True, dev, dtype=dtype)
         with torch.inference_mode():                          # (the workspace tensors were allocated under inference_mode)
             for buf in FM._WORKSPACES.values():
@@ -231,7 +244,13 @@ def test_ragged_regime_batch_on_the_padded_fast_path(dev):
             e = _errors(out, ref, inp["cu_seqlens"], inp["points_per_part"])
             _record({"case": "ragged_regime_70k", "dtype": "f32", **e})
             _assert_fp32(e)
+        elif dtype == "float32x2":
+            e = _errors(out, ref, inp["cu_seqlens"], inp["points_per_part"])
+            _record({"case": "ragged_regime_70k", "dtype": dtype, **e})
+            _assert_fp32(e)
         else:
             e = _errors(out, ref, inp["cu_seqlens"], inp["points_per_part"])
             _record({"case": "ragged_regime_70k", "dtype": dtype, **e})
-            assert e["final_cloud"] <= 5e-2 and e["R_frob"] <= 1e-1, (dtype, e)
+            # ~3 x the measured deviation (r04: bf16 8.5e-4 / 1.5e-3, fp16 1.4e-4 / 2.6e-4)
+            ctol, rtol = (2.6e-3, 4.5e-3) if dtype == "bfloat16" else (4.2e-4, 7.8e-4)
+            assert e["final_cloud"] <= ctol and e["R_frob"] <= rtol, (dtype, e)

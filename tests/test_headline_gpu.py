@@ -109,12 +109,15 @@ def _errors(out, g):
     return e
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float32x2"], ids=["exact-fp32", "split-precision"])
 @pytest.mark.parametrize("name", ["headline_c1_rigid", "headline_c1_free", "headline_c3_rigid", "headline_c2_rank1", "headline_c1_ragged",
                                   "headline_c1_rap16"])
-def test_fp32_all_steps_match_the_reference(name, dev):
+def test_fp32_all_steps_match_the_reference(name, dtype, dev):
+    """Both fp32-accurate arithmetic modes against the SAME asserts: the exact-fp32 MFMA path (compute dtype 0) and, since round 5, the
+    split-precision path (compute dtype 3: fp16 head + tail operands, three products per contraction on the 16-bit matrix pipe)."""
     g = _golden(name)
-    e = _errors(_run_sample(g, "float32", dev), g)
-    _record({"case": name, "dtype": "f32", **{k: v for k, v in e.items() if not k.startswith("per_step")},
+    e = _errors(_run_sample(g, dtype, dev), g)
+    _record({"case": name, "dtype": "f32" if dtype == "float32" else "f32x2", **{k: v for k, v in e.items() if not k.startswith("per_step")},
              "per_step_end_point_max": max(e["per_step_end_point"]), "per_step_end_point_last": e["per_step_end_point"][-1]})
     # the stated tolerances, at every step
     assert max(e["per_step_end_point"]) <= 5e-4 and max(e["per_step_x_t"]) <= 5e-4, e
@@ -129,10 +132,24 @@ def test_fp32_all_steps_match_the_reference(name, dev):
         assert e["R_frob"] <= 1e-3 and e["t"] <= 1e-3, e
 
 
+# Bounds of the 16-bit modes: ~3 x the WORST value measured on MI355X for that fixture and operand type over the
+# residual-stream variants (profiles/r03_c29_headline_parity_all.jsonl; 4 x where only the fp32-stream variant had been measured) --
+# (final cloud, |dR|_F, |dt|).  The class bounds of rounds 1-4 (5e-2 / 1e-1 for bf16) were 10-100 x the measured values: a 10 x
+# regression passed.  The companion file tests/golden/h16_deviation.json holds the measured values these were derived from.
+TOL16 = {
+    ("headline_c1_rigid", "bfloat16"): (1.6e-3, 4e-3, 1e-3), ("headline_c1_rigid", "float16"): (7e-4, 1.3e-3, 2.3e-4),
+    ("headline_c3_rigid", "bfloat16"): (6e-3, 1.5e-2, 1.3e-3), ("headline_c3_rigid", "float16"): (2.1e-3, 5.6e-3, 3e-4),
+    ("headline_c2_rank1", "bfloat16"): (5.7e-3, 7.6e-3, 1.9e-3), ("headline_c2_rank1", "float16"): (7.3e-4, 9e-4, 1.5e-4),
+    ("headline_c1_ragged", "bfloat16"): (9e-3, 2.2e-2, 2.5e-3), ("headline_c1_ragged", "float16"): (4.6e-4, 9e-4, 2.5e-4),
+    ("headline_c1_rap16", "bfloat16"): (4.4e-3, 4.6e-3, 3.3e-3), ("headline_c1_rap16", "float16"): (2.5e-4, 1.6e-4, 1.9e-4),
+    ("headline_c4_steps", "bfloat16"): (3.7e-3, 5.8e-3, 1.7e-3), ("headline_c4_steps", "float16"): (5e-4, 6e-4, 2e-4),
+}
+
+
 @pytest.mark.parametrize("stream", ["float32", "auto"], ids=["fp32-stream", "shipped-default-stream"])
-@pytest.mark.parametrize("dtype,cloud_tol,R_tol", [("bfloat16", 5e-2, 1e-1), ("float16", 1e-2, 2e-2)])
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 @pytest.mark.parametrize("name", ["headline_c1_rigid", "headline_c3_rigid", "headline_c2_rank1", "headline_c1_ragged", "headline_c1_rap16"])
-def test_16bit_all_steps_deviation_from_the_reference(name, dtype, cloud_tol, R_tol, stream, dev):
+def test_16bit_all_steps_deviation_from_the_reference(name, dtype, stream, dev):
     """north_star: report the measured deviation of the reduced-precision modes -- against the reference's fp32 result.  Both with the
     fp32 residual stream and with the SHIPPED default ("auto": fp16 stream under bf16 operands, saturating at +-65504 since round 4;
     fp32 stream under fp16 operands) -- ADVICE r03: the headline suite must run the configuration users get."""
@@ -141,16 +158,17 @@ def test_16bit_all_steps_deviation_from_the_reference(name, dtype, cloud_tol, R_
     e = _errors(out, g)
     _record({"case": name, "dtype": dtype, "residual_stream": stream, **{k: v for k, v in e.items() if not k.startswith("per_step")},
              "per_step_end_point_max": max(e["per_step_end_point"]), "per_step_end_point_last": e["per_step_end_point"][-1]})
-    assert e["final_end_point"] <= cloud_tol and e["R_frob"] <= R_tol and e["t"] <= cloud_tol, e
+    cloud_tol, R_tol, t_tol = TOL16[(name, dtype)]
+    assert e["final_end_point"] <= cloud_tol and e["R_frob"] <= R_tol and e["t"] <= t_tol, e
     nonempty = torch.from_numpy(g["R"]).abs().sum(dim=(-1, -2)) > 0      # an empty part has R = 0, t = 0 in the reference too (procrustes.py:71-76)
     assert torch.equal(out["R"].abs().sum(dim=(-1, -2)) > 0, nonempty)
     det = torch.linalg.det(out["R"].double())[nonempty]
     assert (det - 1).abs().max().item() < 1e-4          # proper rotations in every mode
 
 
-@pytest.mark.parametrize("dtype,cloud_tol,R_tol", [("bfloat16", 5e-2, 1e-1), ("float16", 1e-2, 2e-2)])
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 @pytest.mark.parametrize("name", ["headline_c1_rigid", "headline_c3_rigid"])
-def test_16bit_residual_stream_all_steps_deviation_from_the_reference(name, dtype, cloud_tol, R_tol, dev):
+def test_16bit_residual_stream_all_steps_deviation_from_the_reference(name, dtype, dev):
     """Round 3: the residual stream itself held in fp16 (PointCloudDiT(residual_dtype="float16"), what the reference's own
     "16-mixed" inference holds) -- deviation from the reference's fp32 result over ALL flow steps, recorded next to the fp32-stream
     rows of the test above and bounded by the same loose class bounds."""
@@ -159,7 +177,8 @@ def test_16bit_residual_stream_all_steps_deviation_from_the_reference(name, dtyp
     e = _errors(out, g)
     _record({"case": name, "dtype": dtype, "residual_stream": "fp16", **{k: v for k, v in e.items() if not k.startswith("per_step")},
              "per_step_end_point_max": max(e["per_step_end_point"]), "per_step_end_point_last": e["per_step_end_point"][-1]})
-    assert e["final_end_point"] <= cloud_tol and e["R_frob"] <= R_tol and e["t"] <= cloud_tol, e
+    cloud_tol, R_tol, t_tol = TOL16[(name, dtype)]
+    assert e["final_end_point"] <= cloud_tol and e["R_frob"] <= R_tol and e["t"] <= t_tol, e
     det = torch.linalg.det(out["R"].double())
     assert (det - 1).abs().max().item() < 1e-4
 
@@ -173,14 +192,15 @@ def test_c4_geometry_all_layers_two_flow_steps_match_the_reference(dev):
     g = _golden("headline_c4_steps")
     stride = int(g["stride"])
     f_ref = torch.from_numpy(g["sample_features_strided"]); fmax = float(g["sample_features_max"])
-    for dtype, cloud_tol, R_tol in (("float32", 5e-4, 1e-3), ("bfloat16", 5e-2, 1e-1), ("float16", 1e-2, 2e-2)):
+    for dtype in ("float32", "float32x2", "bfloat16", "float16"):
+        cloud_tol, R_tol, t_tol = (5e-4, 1e-3, 1e-3) if dtype.startswith("float32") else TOL16[("headline_c4_steps", dtype)]
         out = _run_sample(g, dtype, dev, features=True)
         e = _errors(out, g)
         ef = (out["transformer_features"][::stride] - f_ref).abs().max().item()
         _record({"case": "headline_c4_steps", "dtype": dtype, **{k: v for k, v in e.items() if not k.startswith("per_step")},
                  "per_step_end_point": e["per_step_end_point"], "features_max_abs_err": ef, "features_max_abs": fmax})
-        assert e["final_end_point"] <= cloud_tol and e["final_x_t"] <= cloud_tol and e["R_frob"] <= R_tol and e["t"] <= cloud_tol, (dtype, e)
-        if dtype == "float32":
+        assert e["final_end_point"] <= cloud_tol and e["final_x_t"] <= cloud_tol and e["R_frob"] <= R_tol and e["t"] <= t_tol, (dtype, e)
+        if dtype.startswith("float32"):
             assert max(e["per_step_end_point"]) <= 5e-4 and max(e["per_step_x_t"]) <= 5e-4, e
             assert ef <= 2e-4 * max(1.0, fmax), (ef, fmax)
             # what an exact-fp32 path achieves (an order of magnitude inside the stated bounds)
@@ -198,7 +218,8 @@ def test_c4_geometry_forward_matches_the_reference(dev):
     d = {k: v.to(dev) for k, v in inp.items()}
     v_ref = torch.from_numpy(g["velocity"])
     vmax = v_ref.abs().max().item()
-    for dtype, tol in (("float32", 1e-4), ("bfloat16", 3e-2), ("float16", 5e-3)):
+    # 16-bit: ~3 x the measured deviation (r03: bf16 4.9e-4, fp16 5.1e-5 of max|v| 0.36)
+    for dtype, tol in (("float32", 1e-4), ("float32x2", 1e-4), ("bfloat16", 4.2e-3), ("float16", 4.3e-4)):
         model = _model(2, dtype, dev)
         v = model(x=d["x_1"], timesteps=torch.tensor([float(g["timestep"])], device=dev), cond_coord=d["pointclouds"],
                   local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
@@ -207,5 +228,5 @@ def test_c4_geometry_forward_matches_the_reference(dev):
         err = (v.cpu() - v_ref).abs().max().item()
         _record({"case": "headline_c4_forward", "dtype": dtype, "velocity_max_abs_err": err, "max_abs_v": vmax})
         assert err <= tol * vmax, (dtype, err, vmax)
-        if dtype == "float32":
+        if dtype.startswith("float32"):
             assert err < 2e-5 * max(1.0, vmax), err

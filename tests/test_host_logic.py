@@ -141,6 +141,43 @@ def test_bench_cpu_baseline_times_the_live_reference_when_the_mount_exists():
     assert base["seconds_per_pair_all_steps"] > 0 and full["seconds_per_pair_all_steps"] > 0       # (tiny sizes: no ratio claim)
 
 
+def test_bench_se3_field_compares_poses_of_the_same_flow_step(monkeypatch):
+    """bench.py's `se3_vs_cpu_oracle` subtracted poses of DIFFERENT flow steps (the bounded CPU leg fits its poses on
+    the last step it computed, step 1; the GPU side was fitted on step 0) and printed 2.2 degrees for a run whose clouds agreed to 1e-6.
+    Here the "GPU" side is the oracle's own all-step result: compared like with like the field is at rounding level, and it names the step."""
+    import types
+    import torch
+    import bench
+    from oracle import rap_oracle as O
+    from oracle import ref_loader
+    from rap_amd import synthetic as S
+    monkeypatch.setattr(ref_loader, "reference_available", lambda: False)        # the GPU box's situation: the pinned port is timed
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    sd = S.make_weights(cfg, 0)
+    args = types.SimpleNamespace(views=2, points=64, flow_steps=6, rigidity=1)
+    inp = S.make_uniform_inputs(1, 2, 64, seed=1234)
+    nthreads = torch.get_num_threads()
+    try:
+        allsteps = O.sample(sd, cfg, inp, 6, True)
+        cu_b, _ = O.prepare_cu_seqlens(inp)
+
+        def fit(step):
+            R, t = O.fit_transformations(inp["pointclouds"], allsteps["end_point_trajectory"][step], inp["points_per_part"], cu_b)
+            return R[0], t[0]
+
+        base, err = bench.cpu_baseline(cfg, sd, args, (allsteps["end_point_trajectory"], allsteps["trajectory"], fit))
+    finally:
+        torch.set_num_threads(nthreads)
+    assert base["kind"] == "port" and base["steps_timed"] == 2
+    assert err["steps_compared"] == 2 and err["pose_fit_on_step"] == 1
+    assert err["x0_max_abs"] < 1e-4 and err["x_t_max_abs"] < 1e-4 and err["R_frob_max"] < 1e-4 and err["trans_abs_max"] < 1e-4, err
+    assert err["rot_err_deg_max"] < 0.05, err                # (acos near 1: 0.03 degrees is the fp32 floor of the formula)
+    # ... and the mismatch round 4 printed is what a step-0 fit gives against the step-1 poses
+    R0, _ = fit(0)
+    R1, _ = fit(1)
+    assert float(torch.linalg.matrix_norm(R0 - R1).max()) > 10 * max(err["R_frob_max"], 1e-6)
+
+
 def test_ragged_regime_batch_is_in_the_reference_regime():
     from rap_amd import synthetic as S
     parts = S.ragged_regime_parts(262144, seed=4321)

@@ -22,13 +22,18 @@ pytestmark = pytest.mark.gpu
 _MODELS = {}
 
 
-def get_model(num_layers, seed, dev):
-    key = (num_layers, seed)
+# the two fp32-ACCURATE arithmetic modes: exact-fp32 MFMA (compute dtype 0) and split precision (round 5, compute dtype 3: fp16 head + tail
+# operands, three products per contraction on the 16-bit matrix pipe) -- the golden-vector tests hold both to the SAME asserts
+FP32_MODES = ["float32", "float32x2"]
+
+
+def get_model(num_layers, seed, dev, compute_dtype="float32"):
+    key = (num_layers, seed, compute_dtype)
     if key not in _MODELS:
         cfg = dict(S.RAP_12); cfg["num_layers"] = num_layers
         sd = S.make_weights(cfg, seed)
         m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=num_layers, num_heads=8,
-                                  local_feat_dim=32, attn_dtype="float32")
+                                  local_feat_dim=32, attn_dtype="float32", compute_dtype=compute_dtype)
         m.load_state_dict(sd)
         _MODELS[key] = (cfg, sd, m.to(dev))
     return _MODELS[key]
@@ -44,10 +49,11 @@ def to_dev(inp, dev):
     return {k: v.to(dev) for k, v in inp.items()}
 
 
+@pytest.mark.parametrize("mode", FP32_MODES)
 @pytest.mark.parametrize("name", GOLDEN_CASES)
-def test_forward_matches_reference_golden(name, dev):
+def test_forward_matches_reference_golden(name, mode, dev):
     g, inp = load_golden(name)
-    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev)
+    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev, mode)
     cu_b, cu_p = O.prepare_cu_seqlens(inp)
     d = to_dev(inp, dev)
     out = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
@@ -60,10 +66,11 @@ def test_forward_matches_reference_golden(name, dev):
     assert ev < 2e-5 and ef < 2e-4, (ev, ef)                    # what an exact-fp32 path actually achieves
 
 
+@pytest.mark.parametrize("mode", FP32_MODES)
 @pytest.mark.parametrize("name", GOLDEN_CASES)
-def test_sample_matches_reference_golden(name, dev):
+def test_sample_matches_reference_golden(name, mode, dev):
     g, inp = load_golden(name)
-    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev)
+    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev, mode)
     flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=int(g["num_steps"]),
                                       rigidity_forcing=bool(g["rigidity"]))
     d = to_dev(inp, dev)
@@ -92,12 +99,13 @@ def test_sample_matches_reference_golden(name, dev):
     print(f"{name}: x0 {e0:.2e} xt {e1:.2e} |dR|_F {eR:.2e} dt {et:.2e} rot {deg:.4f} deg")
 
 
+@pytest.mark.parametrize("mode", FP32_MODES)
 @pytest.mark.parametrize("name", MODEL_SIZE_CASES)
-def test_other_model_sizes_match_reference_golden(name, dev):
+def test_other_model_sizes_match_reference_golden(name, mode, dev):
     """rap_16 and rap_10 (the reference's other two shipped model sizes): one forward and the whole sampling call against fixtures
     written by the unmodified reference, at the STATED tolerances (velocity 1e-4 max|v|, clouds 5e-4, poses 1e-3)."""
     g, inp = load_golden(name)
-    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev)
+    cfg, sd, model = get_model(int(g["num_layers"]), int(g["weight_seed"]), dev, mode)
     cu_b, cu_p = O.prepare_cu_seqlens(inp)
     d = to_dev(inp, dev)
     out = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
