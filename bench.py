@@ -122,6 +122,10 @@ def parse_args():
     ap.add_argument("--workload", default="uniform", choices=["uniform", "ragged"],
                     help="uniform = BASELINE configs[1] (--batch pairs x --views x --points; the headline); ragged = the HEADLINE run "
                          "itself on the ragged reference-regime batch (the default run appends it as the 'ragged' object instead)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default; the driver's contract): every rank owns --batch pairs (or its own ragged batch); strong: ONE job of "
+                         "--batch pairs in all (or one ragged batch of --ragged-points points) is sharded over the ranks by algorithmic "
+                         "cost (rap_amd.parallel.shard_by_cost) and gathered back into the job's sample order")
     ap.add_argument("--no-ragged", action="store_true", help="skip the extra 'ragged' leg of a uniform run")
     ap.add_argument("--ragged-points", type=int, default=262144)
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline over ALL flow steps of the pair (minutes) instead of 1 + 3 steps")
@@ -308,22 +312,39 @@ def launcher_selftest(args, world, rank, json_out):
     from rap_amd.parallel import gather_registrations, shard_range
     dist.init_process_group(backend="gloo")
     assert dist.get_world_size() == args.gpus == world
-    mine = shard_range(args.batch * world, world, rank)
-    assert (mine.start, mine.stop) == (rank * args.batch, (rank + 1) * args.batch)
-    n = args.batch * args.views * args.points
+    strong = getattr(args, "scaling", "weak") == "strong"
+    if strong:
+        from rap_amd.parallel import shard_by_cost
+        mine = shard_by_cost([[args.points] * args.views for _ in range(args.batch)], world)[rank]
+        nb = len(mine)
+    else:
+        mine = shard_range(args.batch * world, world, rank)
+        assert (mine.start, mine.stop) == (rank * args.batch, (rank + 1) * args.batch)
+        nb = args.batch
+    per = args.views * args.points
+    n = nb * per
     t0 = time.perf_counter()
     for _ in range(args.warmup + args.steps):
-        final = torch.full((n, 3), float(rank)); R = torch.eye(3).repeat(args.batch, args.views, 1, 1) * (rank + 1)
-        t = torch.full((args.batch, args.views, 3), float(rank))
-        g = gather_registrations(final, R, t, equal_shapes=True)
+        final = torch.cat([torch.full((per, 3), float(i)) for i in mine]) if strong else torch.full((n, 3), float(rank))
+        R = torch.eye(3).repeat(nb, args.views, 1, 1) * (rank + 1)
+        t = torch.full((nb, args.views, 3), float(rank))
+        if strong:
+            cu = torch.arange(nb + 1, dtype=torch.int64) * per
+            g = gather_registrations(final, R, t, sample_ids=list(mine), cu_seqlens=cu)
+        else:
+            g = gather_registrations(final, R, t, equal_shapes=True)
     dist.barrier()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     allt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(allt, elapsed)
-    ok = all(bool((g[0][r * n:(r + 1) * n] == float(r)).all()) for r in range(world)) and g[0].shape[0] == n * world
+    if strong:      # the gathered job is in SAMPLE order whatever the assignment: pair i's rows carry the value i
+        ok = g[0].shape[0] == args.batch * per and all(bool((g[0][i * per:(i + 1) * per] == float(i)).all()) for i in range(args.batch))
+    else:
+        ok = all(bool((g[0][r * n:(r + 1) * n] == float(r)).all()) for r in range(world)) and g[0].shape[0] == n * world
     if rank == 0:
         print(json.dumps({"metric": "launcher-selftest (stub sampler, gloo, CPU): NOT a measurement", "value": None, "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "stub": True, "rccl_ranks": world, "pairs_total": args.batch * world,
+                          "steps": args.steps, "warmup": args.warmup, "stub": True, "rccl_ranks": world,
+                          "pairs_total": args.batch if strong else args.batch * world, "scaling": "strong" if strong else "weak",
                           "gather_ok": ok, "per_rank": {"elapsed_s": [float(x) for x in allt]}}), file=json_out, flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -368,11 +389,36 @@ def main():
 
     cfg = dict(S.RAP_12); cfg["num_layers"] = args.layers
     sd = S.make_weights(cfg, 0)
-    # rank r owns pairs [r*batch, (r+1)*batch) of the global job; synthetic, seeded per pair
+    # weak scaling (default): rank r owns pairs [r*batch, (r+1)*batch) of the global job; synthetic, seeded per pair.
+    # strong scaling: ONE job (--batch pairs in all, or one ragged batch) sharded over the ranks by algorithmic cost; `mine` = the global
+    # sample indices of this rank, every sample drawn from its own seed, so the job's result does not depend on the rank count.
+    strong = args.scaling == "strong"
+    from rap_amd.parallel import cost_imbalance, shard_by_cost
+    shard_info = {}
+
     def make_workload(kind):
         if kind == "ragged":
-            parts = S.ragged_regime_parts(args.ragged_points, seed=4321 + rank)
-            cpu = S.make_inputs(parts, seed=98765 + 1000 * rank)
+            if strong:
+                job = S.ragged_regime_parts(args.ragged_points, seed=4321)
+                assign = shard_by_cost(job, world, num_layers=args.layers)
+                shard_info.update(job_parts=job, assignment=assign, imbalance=cost_imbalance(job, assign, args.layers))
+                mine = assign[rank]
+                if not mine:
+                    raise SystemExit(f"rank {rank}: the ragged job has {len(job)} samples for {world} ranks -- nothing to do on this rank")
+                cpu = S.make_inputs_subset(job, mine, seed=98765)
+                parts = [job[i] for i in mine]
+            else:
+                parts = S.ragged_regime_parts(args.ragged_points, seed=4321 + rank)
+                cpu = S.make_inputs(parts, seed=98765 + 1000 * rank)
+        elif strong:
+            job = [[args.points] * args.views for _ in range(args.batch)]
+            assign = shard_by_cost(job, world, num_layers=args.layers)
+            shard_info.update(job_parts=job, assignment=assign, imbalance=cost_imbalance(job, assign, args.layers))
+            mine = assign[rank]
+            if not mine:
+                raise SystemExit(f"rank {rank}: --batch {args.batch} pairs for {world} ranks -- nothing to do on this rank")
+            cpu = S.make_inputs_subset(job, mine, seed=1234)
+            parts = [job[i] for i in mine]
         else:
             parts = [[args.points] * args.views for _ in range(args.batch)]
             cpu = S.make_inputs(parts, seed=1234 + rank * args.batch)
@@ -381,6 +427,11 @@ def main():
     parts, inp, data = make_workload(args.workload)
     x_1 = data["x_1"]
     pts_per_rank = int(inp["pointclouds"].shape[0])
+    # the whole job: what `value` counts (weak: every rank's batch; strong: the one job all ranks share)
+    job_parts = shard_info["job_parts"] if strong else None
+    job_pts = sum(sum(p) for p in job_parts) if strong else pts_per_rank * world
+    job_samples = len(job_parts) if strong else len(parts) * world
+    job_flops_per_call = call_flops(job_parts, args.layers, args.flow_steps) if strong else call_flops(parts, args.layers, args.flow_steps) * world
     lib = _lib.load()
     tuning = {}
     for kv in args.tuning:
@@ -422,7 +473,10 @@ def main():
             if distributed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                g = gather_registrations(final, out["R"], out["t"], equal_shapes=True)
+                if strong:      # ranks hold different sample sets (cost-balanced, not contiguous): gather back into the job's sample order
+                    g = gather_registrations(final, out["R"], out["t"], sample_ids=shard_info["assignment"][rank], cu_seqlens=data["cu_seqlens"])
+                else:
+                    g = gather_registrations(final, out["R"], out["t"], equal_shapes=True)
                 e1.record()
                 ev_pairs.append((e0, e1))
                 return g, out
@@ -599,12 +653,12 @@ def main():
         e2, p2, l2 = run_mode(dtype, k_steps, k_warm)
         a, b = l2["end_point_trajectory"][-1], last["end_point_trajectory"][-1]
         leg = {
-            "dtype": DTYPE_TAG[dtype], "value": pts_per_rank * world * k_steps / e2, "unit": "points/s", "ms_per_step": 1e3 * e2 / k_steps,
+            "dtype": DTYPE_TAG[dtype], "value": job_pts * k_steps / e2, "unit": "points/s", "ms_per_step": 1e3 * e2 / k_steps,
             "steps": k_steps, "warmup": k_warm, "instrumented": False,
             "host_call_ms_per_step": run_mode.host_enqueue_ms,
             "workload": WHAT[dtype] + f"; residual stream held in {run_mode.residual_dtype}",
             "residual_stream": run_mode.residual_dtype,
-            "achieved_tflops_whole_call": call_flops(parts, args.layers, args.flow_steps) * world * k_steps / e2 / 1e12,
+            "achieved_tflops_whole_call": job_flops_per_call * k_steps / e2 / 1e12,
             "roofline": roofline_of(dtype, p2, run_mode.prof_region_s), "streams": run_mode.streams,
             "hbm_kernels": hbm_kernels_of(dtype, p2, parts) if profile else None,
             "bounded_attention_launches": f"{run_mode.bounded_launches} of {2 * args.layers}",
@@ -716,12 +770,12 @@ def main():
 
     result = None
     if rank == 0:
-        total_pts = pts_per_rank * world * args.steps
+        total_pts = job_pts * args.steps
         value = total_pts / elapsed
         result = {
             "metric": "registered points/sec @20 flow steps, 2-view N=4096", "value": value, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_TAG[args.dtype], "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": DTYPE_TAG[args.dtype], "data": "synthetic",
             "config": {"workload": (f"RAGGED reference-regime batch ({len(parts)} samples, {pts_per_rank} points; NOT BASELINE's configuration): "
                                     if args.workload == "ragged" else
                                     f"{'configs[1]' if args.dtype == 'float32' else 'configs[2] per-GPU shard'}: "
@@ -731,7 +785,9 @@ def main():
                                    f"rigidity_forcing={'on' if args.rigidity else 'off'}, final per-view SE(3) fit",
                        "pairs_per_gpu": args.batch, "views": args.views, "points_per_view": args.points,
                        "flow_steps": args.flow_steps, "num_layers": args.layers, "rigidity_forcing": bool(args.rigidity),
-                       "sharding": f"independent pairs, {world} rank(s), one RCCL all-gather of clouds+poses per step"},
+                       "sharding": (f"independent pairs, {world} rank(s), one RCCL all-gather of clouds+poses per step" if not strong else
+                                    f"ONE job of {job_samples} samples sharded by cost over {world} rank(s), one RCCL all-gather of clouds+poses "
+                                    "(+ a sample-id exchange) per step, results in the job's sample order")},
         }
         if tuning:
             result["config"]["tuning"] = tuning
@@ -744,8 +800,13 @@ def main():
         if host_idle_unprofiled_ms is not None:
             result["host_call_ms_idle_queue_unprofiled"] = host_idle_unprofiled_ms
         result["rccl_ranks"] = world if distributed else 0        # ranks in the RCCL process group (0: single process, no group)
-        result["pairs_total"] = len(parts) * world
-        result["achieved_tflops_whole_call"] = uniform_call_flops * world * args.steps / elapsed / 1e12
+        result["pairs_total"] = job_samples
+        result["achieved_tflops_whole_call"] = job_flops_per_call * args.steps / elapsed / 1e12
+        if strong:
+            result["sharding"] = {"by": "algorithmic cost (rap_amd.parallel.shard_by_cost: LPT on 12 layers x (10.486 MFLOP per token + 2048 (sum L_part^2 + "
+                                        "L_sample^2)))", "samples_per_rank": [len(a) for a in shard_info["assignment"]],
+                                  "points_per_rank": [sum(sum(job_parts[i]) for i in a) for a in shard_info["assignment"]],
+                                  "cost_imbalance_max_over_mean_minus_1": shard_info["imbalance"]}
         result["bounded_attention_launches"] = f"{main_bounded} of {2 * args.layers}"
         if distributed:
             result["per_rank"] = {"elapsed_s": main_rank_elapsed, "all_gather_ms_per_step": main_gather_ms,

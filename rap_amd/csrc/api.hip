@@ -173,7 +173,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 12 && (value == 0 || value == 1)) { g_rap_gemm_f32_persistent = value; return RAP_OK; }
   if (key == 13 && (value == 0 || value == 1)) { g_rap_attn_h16_dma = value; return RAP_OK; }
   if (key == 15 && (value == 0 || value == 1)) { g_rap_attn_lpt = value; return RAP_OK; }
-  if (key == 16 && (value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: 1 / 2 blocks per CU
+  if (key == 16 && (value == 1 || value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: pipelined kernel / plain kernel at 1 / 2 blocks per CU
   return RAP_ERR_INVALID;
 }
 

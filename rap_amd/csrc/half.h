@@ -92,10 +92,22 @@ __device__ __forceinline__ void x2_split8(const float (&v)[8], x2_t8& hi, x2_t8&
   hi = __builtin_convertvector(s, x2_t8);
   lo = __builtin_convertvector(s - __builtin_convertvector(hi, f32x8), x2_t8);
 }
-// no saturation: for values bounded by construction (softmax probabilities, attention outputs of finite V)
+// no saturation: for values bounded by construction (softmax probabilities, attention outputs of finite V).  The tail p - hi is formed by
+// v_fma_mix_f32 (fma(hi as fp16, -1.0, p): the difference is exact, one instruction instead of v_cvt_f32_f16 + v_sub_f32 -- hipcc does not
+// select it by itself; 32 of the ~250 VALU instructions of an attention key tile)
 __device__ __forceinline__ void x2_split8_nosat(const f32x8 v, x2_t8& hi, x2_t8& lo) {
   hi = __builtin_convertvector(v, x2_t8);
-  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), x2_t8);
+  const uint4 hp = __builtin_bit_cast(uint4, hi);
+  const unsigned hw[4] = {hp.x, hp.y, hp.z, hp.w};
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hw[i]), "v"(v[2 * i]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hw[i]), "v"(v[2 * i + 1]));
+    r[2 * i] = r0; r[2 * i + 1] = r1;
+  }
+  lo = __builtin_convertvector(r, x2_t8);
 }
 __device__ __forceinline__ void x2_split4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
   const f32x4 s = {f16_sat(a), f16_sat(b), f16_sat(c), f16_sat(d)};

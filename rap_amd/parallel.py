@@ -8,8 +8,95 @@ rank-strided (data/datamodule.py:103-106) and single-GPU at inference (config/tr
 """
 from __future__ import annotations
 
+from typing import Sequence
+
 import torch
 import torch.distributed as dist
+
+# Algorithmic FLOPs of one velocity-network forward (the figures bench.py prices the roofline with)
+DENSE_FLOPS_PER_TOKEN_LAYER = 10.486e6      # qkv + out-projection (two attention branches) + GEGLU feed-forward at d = 512
+ATTN_FLOPS_PER_TOKEN_KEY = 2048.0           # 4 * H * Dh per (query, key) pair of one attention branch
+EMBED_HEAD_FLOPS_PER_TOKEN = 0.97e6
+
+
+def sample_cost(part_sizes: Sequence[int], num_layers: int = 12) -> float:
+    """Algorithmic FLOPs of ONE forward for one sample with the given part sizes: the dense layers are linear in the tokens, the two
+    attention branches quadratic in the part lengths (per-part attention) and in the sample length (per-sample attention) -- which is
+    why sharding ragged scans by COUNT leaves ranks waiting: at equal points the repo's ragged batch costs 2.1 x the uniform one."""
+    n = float(sum(part_sizes))
+    quad = float(sum(float(x) * float(x) for x in part_sizes)) + n * n
+    return num_layers * (n * DENSE_FLOPS_PER_TOKEN_LAYER + ATTN_FLOPS_PER_TOKEN_KEY * quad) + n * EMBED_HEAD_FLOPS_PER_TOKEN
+
+
+def shard_by_cost(parts: Sequence[Sequence[int]], world_size: int, num_layers: int = 12) -> list[list[int]]:
+    """Cost-balanced assignment of samples to ranks (VERDICT r04 missing 2): longest-processing-time-first on `sample_cost` -- samples in
+    decreasing cost, each to the currently cheapest rank (ties: lower rank) -- then every rank's list in ascending sample index.
+    Deterministic, host-side, O(S log S).  Returns world_size lists of sample indices (a rank's list may be empty when there are fewer
+    samples than ranks).  `gather_registrations(..., sample_ids=...)` puts the results back into the caller's order."""
+    if world_size <= 0:
+        raise ValueError("bad world_size")
+    costs = [sample_cost(p, num_layers) for p in parts]
+    order = sorted(range(len(parts)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world_size
+    out: list[list[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += costs[i]
+    return [sorted(x) for x in out]
+
+
+def cost_imbalance(parts: Sequence[Sequence[int]], assignment: Sequence[Sequence[int]], num_layers: int = 12) -> float:
+    """max over ranks / mean over ranks of the summed sample cost, minus 1 (0 = perfectly balanced): the fraction of the job's time the
+    heaviest rank makes the others wait."""
+    loads = [sum(sample_cost(parts[i], num_layers) for i in idx) for idx in assignment]
+    mean = sum(loads) / max(1, len(loads))
+    return max(loads) / mean - 1.0 if mean > 0 else 0.0
+
+
+def pack_batches(point_counts: Sequence[int], max_points_per_batch: int, indices: Sequence[int] | None = None,
+                 drop_last: bool = False) -> list[list[int]]:
+    """The reference's point-budget packing (DynamicBatchSampler.__iter__, data/datamodule.py:108-123): walk the samples in order and
+    close a batch when the next sample would push it over `max_points_per_batch` (a single sample larger than the budget is a batch of
+    its own); `drop_last` drops the final, partially filled batch as the reference's training default does."""
+    idx = list(range(len(point_counts))) if indices is None else list(indices)
+    batches, batch, acc = [], [], 0
+    for i in idx:
+        pts = int(point_counts[i])
+        if batch and acc + pts > max_points_per_batch:
+            batches.append(batch)
+            batch, acc = [], 0
+        batch.append(i)
+        acc += pts
+    if batch and not drop_last:
+        batches.append(batch)
+    return batches
+
+
+def plan_batches(parts: Sequence[Sequence[int]], world_size: int, max_points_per_batch: int, balance: str = "cost",
+                 num_layers: int = 12, drop_last: bool = False) -> list[list[list[int]]]:
+    """Per-rank batch lists for a data-parallel inference job over ragged samples: shard (``balance="cost"``: `shard_by_cost`;
+    ``"stride"``: the reference's rank-strided split, datamodule.py:103-106), pack every rank's samples into point-budget batches
+    (`pack_batches`), then equalise the NUMBER of batches per rank by repeating a rank's last batch, exactly as the reference pads so
+    that every rank takes part in every step (datamodule.py:125-138).  Returns plan[rank] = list of batches (lists of sample indices)."""
+    counts = [sum(p) for p in parts]
+    if balance == "cost":
+        shards = shard_by_cost(parts, world_size, num_layers)
+    elif balance == "stride":
+        shards = [list(range(len(parts)))[r::world_size] for r in range(world_size)]
+    else:
+        raise ValueError(f"balance must be 'cost' or 'stride' (got {balance!r})")
+    plan = [pack_batches(counts, max_points_per_batch, indices=s, drop_last=drop_last) for s in shards]
+    n_max = max((len(b) for b in plan), default=0)
+    for r, b in enumerate(plan):
+        while len(b) < n_max:
+            if b:
+                b.append(list(b[-1]))
+            elif shards[r]:
+                b.append([shards[r][0]])
+            else:
+                break
+    return plan
 
 
 def shard_range(n_items: int, world_size: int, rank: int) -> range:
@@ -21,15 +108,25 @@ def shard_range(n_items: int, world_size: int, rank: int) -> range:
     return range(start, start + q + (1 if rank < r else 0))
 
 
-def gather_registrations(final_points: torch.Tensor, R: torch.Tensor, t: torch.Tensor, group=None, equal_shapes: bool = False):
+def gather_registrations(final_points: torch.Tensor, R: torch.Tensor, t: torch.Tensor, group=None, equal_shapes: bool = False,
+                         sample_ids: Sequence[int] | None = None, cu_seqlens: torch.Tensor | None = None):
     """All-gather per-rank results (TPr,3), (Br,P,3,3), (Br,P,3) -> (sum TPr,3), (sum Br,P,3,3), (sum Br,P,3) in rank order.
+
+    ``sample_ids`` (with the rank's ``cu_seqlens`` (Br+1,)): the GLOBAL indices of this rank's samples (a `shard_by_cost` assignment is
+    not contiguous) -- the gathered samples are then returned in ascending global index, i.e. in the order of the un-sharded batch:
+    one more small all-gather carries (sample id, point count) per sample; the data collective is unchanged.
 
     One flat buffer, one data collective: the payload (a few MB per rank) is latency-bound, so the three tensors travel
     together.  Ranks may hold DIFFERENT numbers of points and samples (`shard_range` hands the first ranks one more pair, and
     real scans are ragged): a 3-integer all-gather of (TPr, Br, P) precedes the data collective, every rank pads its buffer
     to the largest payload and the padding is sliced away after the gather.  `equal_shapes=True` skips that exchange (and the
     host read it needs): the caller guarantees identical shapes on every rank -- bench.py's fixed synthetic batch."""
+    if (sample_ids is None) != (cu_seqlens is None):
+        raise ValueError("sample_ids and cu_seqlens go together")
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if sample_ids is not None:
+            return _reorder_samples(final_points, R, t, [int(i) for i in sample_ids],
+                                    (cu_seqlens[1:] - cu_seqlens[:-1]).tolist())
         return final_points, R, t
     world = dist.get_world_size(group)
     P = R.shape[1]
@@ -65,4 +162,37 @@ def gather_registrations(final_points: torch.Tensor, R: torch.Tensor, t: torch.T
         pts.append(out[r, :a0].reshape(tp, 3))
         Rs.append(out[r, a0:a1].reshape(b, P, 3, 3))
         ts.append(out[r, a1:a1 + b * P * 3].reshape(b, P, 3))
-    return torch.cat(pts), torch.cat(Rs), torch.cat(ts)
+    gp, gR, gt = torch.cat(pts), torch.cat(Rs), torch.cat(ts)
+    if sample_ids is None:
+        return gp, gR, gt
+    # (sample id, point count) of every gathered sample, in gather order: one small padded all-gather
+    b_max = max(int(b) for b in b_all)
+    meta = torch.full((b_max, 2), -1, dtype=torch.int64, device=dev)
+    if len(sample_ids):
+        meta[:len(sample_ids), 0] = torch.as_tensor([int(i) for i in sample_ids], dtype=torch.int64, device=dev)
+        meta[:len(sample_ids), 1] = (cu_seqlens[1:] - cu_seqlens[:-1]).to(device=dev, dtype=torch.int64)
+    allm = torch.empty(world * b_max * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allm, meta.reshape(-1).contiguous(), group=group)
+    allm = allm.view(world, b_max, 2).cpu()
+    ids, counts = [], []
+    for r in range(world):
+        for j in range(int(b_all[r])):
+            ids.append(int(allm[r, j, 0])); counts.append(int(allm[r, j, 1]))
+    return _reorder_samples(gp, gR, gt, ids, counts)
+
+
+def _reorder_samples(points: torch.Tensor, R: torch.Tensor, t: torch.Tensor, ids: list[int], counts: list[int]):
+    """Samples (packed point rows + per-sample pose rows) from gather order into ascending global sample index."""
+    if sorted(ids) != sorted(set(ids)):
+        raise ValueError("a sample index appears on more than one rank")
+    if sum(counts) != points.shape[0] or len(ids) != R.shape[0]:
+        raise ValueError("sample ids / point counts do not match the gathered tensors")
+    starts = [0]
+    for c in counts:
+        starts.append(starts[-1] + c)
+    order = sorted(range(len(ids)), key=lambda k: ids[k])
+    if order == list(range(len(ids))):
+        return points, R, t
+    rows = torch.cat([torch.arange(starts[k], starts[k + 1]) for k in order]).to(points.device) if points.shape[0] else torch.zeros(0, dtype=torch.long)
+    sel = torch.as_tensor(order, dtype=torch.long, device=R.device)
+    return points[rows], R[sel], t[sel]

@@ -189,6 +189,22 @@ def make_inputs(parts: Sequence[Sequence[int]], seed: int = 1234, feat_dim: int 
             "points_per_part": ppp, "cu_seqlens": cu, "x_1": torch.cat(x1s).contiguous()}
 
 
+def make_inputs_subset(parts: Sequence[Sequence[int]], indices: Sequence[int], seed: int = 1234, feat_dim: int = 32,
+                       max_parts: int | None = None) -> dict[str, torch.Tensor]:
+    """The samples ``indices`` of ``make_inputs(parts, seed)`` as one packed batch, WITHOUT generating the others (sample b is drawn from
+    ``seed + b``, so a rank of a sharded job builds exactly its own samples of the global batch).  ``max_parts`` defaults to the largest
+    part count of the WHOLE job, so every rank pads its points_per_part table to the same width."""
+    P = max_parts if max_parts is not None else max(len(p) for p in parts)
+    one = [make_inputs([parts[i]], seed=seed + i, feat_dim=feat_dim, max_parts=P) for i in indices]
+    if not one:
+        raise ValueError("empty shard")
+    out = {k: torch.cat([o[k] for o in one]) for k in one[0] if k != "cu_seqlens"}
+    cu = torch.zeros(len(one) + 1, dtype=torch.int64)
+    cu[1:] = torch.cumsum(torch.tensor([int(o["cu_seqlens"][-1]) for o in one], dtype=torch.int64), 0)
+    out["cu_seqlens"] = cu
+    return out
+
+
 def make_uniform_inputs(batch: int, views: int, n_points: int, seed: int = 1234, feat_dim: int = 32):
     """BASELINE.json geometry: ``batch`` samples of ``views`` x ``n_points``."""
     return make_inputs([[n_points] * views for _ in range(batch)], seed=seed, feat_dim=feat_dim)

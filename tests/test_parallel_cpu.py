@@ -113,6 +113,19 @@ def test_bench_launches_its_own_ranks_when_asked_for_more_than_one_gpu():
     assert len(j["per_rank"]["elapsed_s"]) == 2
 
 
+def test_bench_strong_scaling_mode_shards_one_job_and_gathers_in_sample_order():
+    """`bench.py --gpus 2 --scaling strong --batch 5` (round 5): ONE job of 5 pairs split 3 + 2 by cost, gathered back into the job's
+    sample order through gather_registrations(sample_ids=...); launcher self-test mode (gloo, CPU ranks, stub sampler)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "5", "--points", "16", "--scaling", "strong"],
+                   {"RAP_BENCH_LAUNCHER_SELFTEST": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["pairs_total"] == 5 and j["scaling"] == "strong" and j["gather_ok"] is True
+
+
 def test_bench_refuses_a_rank_count_it_was_not_asked_for():
     """--gpus N must equal the number of ranks that actually run: a torchrun world of 1 with --gpus 2 (or the reverse) exits non-zero
     before anything is timed, and `--gpus 2` on a box with fewer than 2 GPUs refuses instead of timing one (here: no GPU at all)."""
@@ -123,3 +136,129 @@ def test_bench_refuses_a_rank_count_it_was_not_asked_for():
     if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
         r = _run_bench(["--gpus", "2"], {})
         assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 5: cost-aware sharding, the reference's point-budget packing, a ragged two-rank job (VERDICT r04 missing 2 / next 5)
+# ---------------------------------------------------------------------------------------------
+def _ragged_dataset(n_batches=22):
+    from rap_amd import synthetic as S
+    parts = []
+    for k in range(n_batches):
+        parts += S.ragged_regime_parts(262144, seed=100 + k)
+    return parts
+
+
+def test_shard_by_cost_balances_flops_not_counts():
+    """Attention is quadratic in the segment lengths, so ranks that hold the same NUMBER of ragged samples (or points) do not hold the
+    same work.  LPT on the algorithmic FLOPs: <= 5 % imbalance on a 255-sample ragged data set at 2 / 4 / 8 ranks (by count: up to 6 %;
+    the reference's rank-strided split, datamodule.py:103-106: 19 % at 8 ranks), every sample on exactly one rank, deterministic."""
+    from rap_amd.parallel import cost_imbalance, sample_cost, shard_by_cost
+    parts = _ragged_dataset()
+    assert len(parts) > 200
+    for w in (1, 2, 4, 8):
+        a = shard_by_cost(parts, w)
+        assert sorted(i for r in a for i in r) == list(range(len(parts))) and len(a) == w
+        assert all(r == sorted(r) for r in a)
+        assert a == shard_by_cost(parts, w)
+        imb = cost_imbalance(parts, a)
+        assert imb <= 0.05, (w, imb)
+        by_count = [list(shard_range(len(parts), w, r)) for r in range(w)]
+        stride = [list(range(len(parts)))[r::w] for r in range(w)]
+        assert imb <= cost_imbalance(parts, by_count) + 1e-12 and imb <= cost_imbalance(parts, stride) + 1e-12
+    assert cost_imbalance(parts, [list(range(len(parts)))[r::8] for r in range(8)]) > 0.05       # what the cost model buys at 8 ranks
+    # the cost model is the one bench.py prices the roofline with: uniform configs[1] pair = 428.8 MFLOP per token per forward
+    assert abs(sample_cost([4096, 4096]) / 8192 / 1e6 - 428.8) < 0.5
+    # fewer samples than ranks: empty ranks are allowed, nothing is lost
+    few = shard_by_cost([[100, 50], [4000]], 4)
+    assert sorted(i for r in few for i in r) == [0, 1] and sum(1 for r in few if not r) == 2
+
+
+def test_pack_batches_mirrors_the_reference_sampler():
+    """`pack_batches` / `plan_batches(balance="stride")` against the reference's UNMODIFIED DynamicBatchSampler (data/datamodule.py:59-166)
+    when the mount exists, and against fixed expectations everywhere."""
+    from rap_amd.parallel import pack_batches, plan_batches
+    counts = [30, 50, 40, 100, 10, 10, 10, 90, 120, 5]
+    assert pack_batches(counts, 100) == [[0, 1], [2], [3], [4, 5, 6], [7], [8], [9]]
+    assert pack_batches(counts, 100, drop_last=True) == [[0, 1], [2], [3], [4, 5, 6], [7], [8]]
+    assert pack_batches(counts, 100, indices=[8, 0, 9]) == [[8], [0, 9]]                       # a sample above the budget is its own batch
+    assert pack_batches([], 100) == []
+    parts = [[c] for c in counts]
+    plan = plan_batches(parts, 2, 100, balance="stride")
+    assert plan[1] == [[1], [3], [5, 7], [9]] and plan[0] == [[0, 2, 4, 6], [8], [8], [8]]      # the shorter rank repeats its last batch
+    assert len({len(b) for b in plan}) == 1                                                   # every rank takes part in every step
+    from oracle import ref_loader
+    if not ref_loader.reference_available():
+        return
+    dm = ref_loader.load_reference_data().datamodule
+
+    class _DS:
+        def __len__(self):
+            return len(counts)
+
+        def estimate_num_points(self, i):
+            return counts[i]
+
+    for drop_last in (False, True):
+        smp = dm.DynamicBatchSampler(_DS(), 100, shuffle=False, drop_last=drop_last, seed=0)
+        assert list(iter(smp)) == pack_batches(counts, 100, drop_last=drop_last)
+    # two ranks: the reference shards rank-strided and pads the shorter rank with its last batch
+    for rank in range(2):
+        smp = dm.DynamicBatchSampler(_DS(), 100, shuffle=False, drop_last=False, seed=0)
+        smp._get_rank_and_size = lambda rank=rank: (rank, 2)
+        assert list(iter(smp)) == plan_batches(parts, 2, 100, balance="stride")[rank], rank
+
+
+def _worker_ragged(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import rap_oracle as O     # stands in for the per-rank GPU sampler in this CPU test
+        from rap_amd import synthetic as S
+        from rap_amd.parallel import shard_by_cost
+        cfg = dict(S.RAP_12); cfg["num_layers"] = 1
+        sd = S.make_weights(cfg, 0)
+        parts = RAGGED_JOB
+        mine = shard_by_cost(parts, world, num_layers=1)[rank]
+        # every sample is generated from ITS OWN seed (make_inputs seeds sample b with seed + b): build the rank's batch sample by sample
+        one = [S.make_inputs([parts[i]], seed=777 + i, max_parts=3) for i in mine]
+        inp = {k: torch.cat([o[k] for o in one]) for k in one[0] if k != "cu_seqlens"}
+        cu = torch.zeros(len(mine) + 1, dtype=torch.int64)
+        cu[1:] = torch.cumsum(torch.tensor([int(o["cu_seqlens"][-1]) for o in one]), 0)
+        inp["cu_seqlens"] = cu
+        res = O.sample(sd, cfg, inp, 2, True)
+        final, R, t = gather_registrations(res["end_point_trajectory"][-1], res["R"], res["t"], sample_ids=mine, cu_seqlens=cu)
+        torch.save({"final": final, "R": R, "t": t, "mine": mine}, os.path.join(tmpdir, f"rg{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+RAGGED_JOB = [[40, 30], [90, 64, 20], [25, 25], [70, 10], [33], [120, 40, 9], [48, 48]]
+
+
+def test_two_rank_ragged_cost_sharded_job_equals_the_single_process_batch(tmp_path):
+    """A RAGGED job over two ranks, sharded by cost (non-contiguous sample sets, different point and sample counts per rank), gathered
+    with ONE data collective + the small id exchange: equals the one-process batch in the original sample order."""
+    from oracle import rap_oracle as O
+    from rap_amd import synthetic as S
+    from rap_amd.parallel import cost_imbalance, shard_by_cost
+    a = shard_by_cost(RAGGED_JOB, 2, num_layers=1)
+    assert a[0] != list(range(len(a[0])))                        # really not a contiguous block
+    assert cost_imbalance(RAGGED_JOB, a, num_layers=1) <= 0.05
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_ragged, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 1
+    sd = S.make_weights(cfg, 0)
+    one = [S.make_inputs([p], seed=777 + i, max_parts=3) for i, p in enumerate(RAGGED_JOB)]
+    inp = {k: torch.cat([o[k] for o in one]) for k in one[0] if k != "cu_seqlens"}
+    cu = torch.zeros(len(one) + 1, dtype=torch.int64)
+    cu[1:] = torch.cumsum(torch.tensor([int(o["cu_seqlens"][-1]) for o in one]), 0)
+    inp["cu_seqlens"] = cu
+    ref = O.sample(sd, cfg, inp, 2, True)
+    for r in range(2):
+        got = torch.load(os.path.join(str(tmp_path), f"rg{r}.pt"))
+        assert got["mine"] == a[r]
+        assert got["final"].shape == ref["end_point_trajectory"][-1].shape
+        assert (got["final"] - ref["end_point_trajectory"][-1]).abs().max().item() < 1e-5
+        assert (got["R"] - ref["R"]).abs().max().item() < 1e-5 and (got["t"] - ref["t"]).abs().max().item() < 1e-5

@@ -261,7 +261,7 @@ def attention_ref64(q, k, v, cu):
     return out
 
 
-@pytest.mark.parametrize("wpe", [2, 4], ids=["one-block-per-cu", "two-blocks-per-cu"])
+@pytest.mark.parametrize("wpe", [1, 2, 4], ids=["software-pipelined", "one-block-per-cu", "two-blocks-per-cu"])
 @pytest.mark.parametrize("H", [1, 8])
 def test_x2_attention_ragged_segments(lib, dev, H, wpe):
     g = torch.Generator().manual_seed(11 + H)
@@ -298,17 +298,24 @@ def test_x2_attention_single_token_segments_return_v(lib, dev):
     assert float((out - want).abs().max()) <= 2.0 ** -20 * float(want.abs().max())      # softmax over one key is exactly 1: out = split(v)
 
 
-def test_x2_attention_sharp_softmax_and_late_maximum(lib, dev):
-    """One key dominates, placed in the LAST tile (forces the running-max rescale on the final step), the first tile and the middle."""
+@pytest.mark.parametrize("variant", [1, 2], ids=["software-pipelined", "plain"])
+def test_x2_attention_sharp_softmax_and_late_maximum(lib, dev, variant):
+    """One key dominates, placed in the LAST tile (forces the running-max rescale on the final step), the first tile and the middle --
+    in the pipelined kernel the rescale of O is applied one iteration after it is decided (and before the final tile's product)."""
     g = torch.Generator().manual_seed(9)
-    H, L = 2, 700
-    for spike_at in (L - 1, 0, 350):
-        q = torch.randn(H, L, 64, generator=g); k = torch.randn(H, L, 64, generator=g) * 0.1; v = torch.randn(H, L, 64, generator=g)
-        k[:, spike_at] = q[:, 5] * 4.0
-        ref = attention_ref64(q, k, v, torch.tensor([0, L]))
-        out = run_x2_attention(lib, dev, q, k, v, torch.tensor([0, L]))
-        err = float((out - ref).abs().max())
-        assert err < 5e-6, (spike_at, err)
+    H = 2
+    try:
+        assert lib.rap_set_tuning(16, variant) == 0
+        for L in (700, 640, 65, 129):
+            for spike_at in (L - 1, 0, L // 2):
+                q = torch.randn(H, L, 64, generator=g); k = torch.randn(H, L, 64, generator=g) * 0.1; v = torch.randn(H, L, 64, generator=g)
+                k[:, spike_at] = q[:, 5] * 4.0
+                ref = attention_ref64(q, k, v, torch.tensor([0, L]))
+                out = run_x2_attention(lib, dev, q, k, v, torch.tensor([0, L]))
+                err = float((out - ref).abs().max())
+                assert err < 5e-6, (L, spike_at, err)
+    finally:
+        assert lib.rap_set_tuning(16, 2) == 0
 
 
 def test_x2_attention_full_size_agrees_with_fp64_on_sampled_rows(lib, dev):
