@@ -80,6 +80,13 @@ int rap_model_compute_dtype(const rap_model* m);
  * flow_model/norm.py:15-33); the others take the online-softmax kernel.  Decided per launch, so one hot head of a trained checkpoint
  * costs one (layer, branch) the faster kernel, not the model.  Returns < 0 for a NULL model. */
 int rap_model_bounded_attention_launches(const rap_model* m);
+/* qk_norm of the reference's constructor (flow_model/point_cloud_dit.py:28; layer.py:75-83,103-104): 1 (default, every shipped configuration) =
+ * MultiHeadRMSNorm on q and k; 0 = q and k go to the attention as projected -- no bound on the logits exists then, every attention launch
+ * takes the online-softmax kernel, and the gamma entries of the weight blob are ignored.  (The reference's other two constructor switches,
+ * scale_emb_on / local_feat_concat_on, only narrow the embedding projection's input: a caller widens emb_proj.weight with zero columns for
+ * the absent inputs -- rap_amd.PointCloudDiT does -- which is exact.) */
+int rap_model_set_qk_norm(rap_model* m, int32_t on);
+int rap_model_qk_norm(const rap_model* m);
 /* Storage type of the residual stream in the 16-bit compute modes: 0 = fp32 (default), 2 = fp16.  With fp16 the stream between the
  * layer kernels is held the way the reference's own "16-mixed" inference holds it (nn.Linear outputs are 16-bit under autocast and
  * flow_model/layer.py:155-164 adds them): every residual sum is formed in fp32 from the GEMM's fp32 accumulators and rounded once,

@@ -30,7 +30,14 @@ CASES = [
     # the reference's other two model sizes (config/model/flow_model/point_cloud_dit_{10,16}.yaml): rap_10 and rap_16
     ("l16_small_rigid", 16, [[96, 64], [40, 128, 33]], 41, 2, 3, True),
     ("l10_small_free", 10, [[80, 80], [150, 30]], 43, 3, 3, False),
+    # round 5: the constructor switches of PointCloudDiT every shipped config leaves True (point_cloud_dit.py:28,33-34) -- one fixture each
+    ("l2_noqknorm_rigid", 2, [[60, 41], [130, 20, 77]], 51, 4, 3, True),
+    ("l2_noscale_free", 2, [[37, 64, 100], [50, 129]], 53, 5, 3, False),
+    ("l2_nofeat_rigid", 2, [[90, 33], [45, 45, 45]], 55, 6, 3, True),
 ]
+# name -> PointCloudDiT keyword overrides
+CASE_SWITCHES = {"l2_noqknorm_rigid": {"qk_norm": False}, "l2_noscale_free": {"scale_emb_on": False},
+                 "l2_nofeat_rigid": {"local_feat_concat_on": False}}
 
 
 def weights_checksum(sd) -> float:
@@ -45,6 +52,7 @@ def main():
         if only and name not in only:
             continue
         cfg = dict(S.RAP_12); cfg["num_layers"] = L
+        cfg.update(CASE_SWITCHES.get(name, {}))
         sd = S.make_weights(cfg, wseed)
         inp = S.make_inputs(parts, seed=iseed)
         ref = ref_loader.reference_sample(cfg, sd, inp, steps, rigid)

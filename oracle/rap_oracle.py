@@ -71,10 +71,15 @@ def posenc(x: torch.Tensor, num_freqs: int = 10) -> torch.Tensor:
     return torch.cat(outs, -1)
 
 
-def encoding_manager(sd, x, cond, feats, scales_pt):
-    """embedding.py:131-179: cat[PE63(cond), PE63(x), PE21(scale), feat] -> emb_proj."""
-    emb = torch.cat([posenc(cond), posenc(x), posenc(scales_pt.unsqueeze(-1)), feats], dim=-1)
-    return F.linear(emb, sd["encoding_manager.emb_proj.weight"], sd["encoding_manager.emb_proj.bias"])
+def encoding_manager(sd, x, cond, feats, scales_pt, cfg=None):
+    """embedding.py:131-179: cat[PE63(cond), PE63(x), PE21(scale) if scale_emb_on, feat if local_feat_concat_on] -> emb_proj."""
+    cfg = cfg or {}
+    cols = [posenc(cond), posenc(x)]
+    if cfg.get("scale_emb_on", True):                                         # embedding.py:169-172
+        cols.append(posenc(scales_pt.unsqueeze(-1)))
+    if cfg.get("local_feat_concat_on", True) and feats is not None:           # embedding.py:175-177
+        cols.append(feats)
+    return F.linear(torch.cat(cols, dim=-1), sd["encoding_manager.emb_proj.weight"], sd["encoding_manager.emb_proj.bias"])
 
 
 # ----------------------------------------------------------------------------
@@ -182,8 +187,9 @@ def attention_block(sd, prefix, which, x, cu_seqlens, H):
     T, d = x.shape
     qkv = F.linear(x, sd[prefix + f"{which}_qkv_proj.weight"]).reshape(T, 3, H, d // H)
     q, k, v = qkv.unbind(dim=1)                                               # layer.py:91-96
-    q = multi_head_rms_norm(q, sd[prefix + f"{which}_q_norm.gamma"])
-    k = multi_head_rms_norm(k, sd[prefix + f"{which}_k_norm.gamma"])
+    if prefix + f"{which}_q_norm.gamma" in sd:                                # layer.py:103-104: only with qk_norm=True
+        q = multi_head_rms_norm(q, sd[prefix + f"{which}_q_norm.gamma"])
+        k = multi_head_rms_norm(k, sd[prefix + f"{which}_k_norm.gamma"])
     out = varlen_attention(torch.stack([q, k, v], dim=1), cu_seqlens).reshape(T, d)
     return F.linear(out, sd[prefix + f"{which}_out_proj.weight"], sd[prefix + f"{which}_out_proj.bias"])
 
@@ -224,7 +230,7 @@ def dit_forward(sd, cfg, x, timesteps, cond, feats, scales, anchor, cu_batch, cu
                 return_transformer_features: bool = False, taps: dict | None = None):
     """PointCloudDiT.forward (point_cloud_dit.py:141-191)."""
     scales_pt = repeat_by_cu_seqlens(scales, cu_batch)                        # :174
-    h = encoding_manager(sd, x, cond, feats, scales_pt)                       # :175
+    h = encoding_manager(sd, x, cond, feats, scales_pt, cfg)                  # :175
     emb = sd["anchor_part_emb.weight"]
     h = h + torch.where(anchor[:, None], emb[1][None, :], emb[0][None, :])    # :119-139
     if taps is not None:

@@ -407,8 +407,9 @@ def build_reference_dit(cfg, state_dict, dtype=torch.float32):
     """Instantiate the reference's PointCloudDiT and load ``state_dict`` into it."""
     ns = load_reference()
     m = ns.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
-                         num_heads=cfg["num_heads"], attn_dtype="float32",
-                         local_feat_dim=cfg["local_feat_dim"], scale_emb_on=True, local_feat_concat_on=True)
+                         num_heads=cfg["num_heads"], attn_dtype="float32", qk_norm=cfg.get("qk_norm", True),
+                         local_feat_dim=cfg["local_feat_dim"], scale_emb_on=cfg.get("scale_emb_on", True),
+                         local_feat_concat_on=cfg.get("local_feat_concat_on", True))
     # fp32 only: the reference forces its head to fp32 (point_cloud_dit.py:183-184 `embed.float()`), so an
     # fp64 ground truth cannot be produced by the unmodified modules; oracle/rap_oracle.py (pinned to this
     # loader in fp32) provides the fp64 ground truth instead.

@@ -40,6 +40,8 @@ SIGNATURES = {
     "rap_model_set_compute_dtype": (c_int32, [_P, c_int32, _P]),
     "rap_model_compute_dtype": (c_int32, [_P]),
     "rap_model_bounded_attention_launches": (c_int32, [_P]),
+    "rap_model_set_qk_norm": (c_int32, [_P, c_int32]),
+    "rap_model_qk_norm": (c_int32, [_P]),
     "rap_model_set_residual_dtype": (c_int32, [_P, c_int32]),
     "rap_model_residual_dtype": (c_int32, [_P]),
     "rap_workspace_bytes": (c_size_t, [_P, c_int64, c_int32, c_int32, c_int32]),

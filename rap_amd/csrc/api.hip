@@ -108,6 +108,7 @@ struct rap_model {
   rap_model_desc desc;
   int d, L, H, F, E;
   int dtype = RAP_DT_F32;     // arithmetic type of the transformer blocks (rap_model_set_compute_dtype)
+  bool qk_norm = true;        // MultiHeadRMSNorm on q / k (rap_model_set_qk_norm; every shipped configuration has it on)
   int resid_dtype = RAP_DT_F32;   // storage type of the residual stream in the 16-bit modes (rap_model_set_residual_dtype): fp32 or fp16
   HalfWeights half[4];        // indexed by dtype (slot 0 unused; 3 = the paired head / tail planes of the split-precision mode)
   float* logit_bound = nullptr;   // (L, 2, H) per-head bounds on q.k/8 after qk-norm; null until a 16-bit dtype is selected
@@ -173,7 +174,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 12 && (value == 0 || value == 1)) { g_rap_gemm_f32_persistent = value; return RAP_OK; }
   if (key == 13 && (value == 0 || value == 1)) { g_rap_attn_h16_dma = value; return RAP_OK; }
   if (key == 15 && (value == 0 || value == 1)) { g_rap_attn_lpt = value; return RAP_OK; }
-  if (key == 16 && (value == 1 || value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: pipelined kernel / plain kernel at 1 / 2 blocks per CU
+  if (key == 16 && (value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: 1 / 2 blocks per CU
   return RAP_ERR_INVALID;
 }
 
@@ -420,7 +421,16 @@ extern "C" int rap_model_set_residual_dtype(rap_model* m, int32_t dtype) {
   return RAP_OK;
 }
 extern "C" int rap_model_residual_dtype(const rap_model* m) { return m ? m->resid_dtype : RAP_ERR_INVALID; }
-extern "C" int rap_model_bounded_attention_launches(const rap_model* m) { return m ? m->n_bounded : RAP_ERR_INVALID; }
+extern "C" int rap_model_bounded_attention_launches(const rap_model* m) { return m ? (m->qk_norm ? m->n_bounded : 0) : RAP_ERR_INVALID; }
+// qk_norm = False of the reference's constructor (point_cloud_dit.py:28, layer.py:75-83,103-104): q and k go to the attention as projected.
+// Without the norm there is no bound on the logits, so every attention launch takes the online-softmax kernel; the gains in the blob are ignored.
+extern "C" int rap_model_set_qk_norm(rap_model* m, int32_t on) {
+  if (!m) return RAP_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(m->cfg_mu);
+  m->qk_norm = on != 0;
+  return RAP_OK;
+}
+extern "C" int rap_model_qk_norm(const rap_model* m) { return m ? (m->qk_norm ? 1 : 0) : RAP_ERR_INVALID; }
 
 // ---------------------------------------------------------------------------------------------
 // workspace
@@ -597,7 +607,8 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         if (rc) return rc;
         GemmParamsH g{};
         g.A = w.xnh; g.lda = 2 * d; g.W = lh.Wqkv[a]; g.ldw = 2 * d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = 2 * d; g.heads = H;
-        g.vt = w.vth; g.vt_nblk = w.vt_nblk; g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; g.q_mul = 8.0f; g.acc_scale = lh.s_qkv[a];
+        g.vt = w.vth; g.vt_nblk = w.vt_nblk; g.q_mul = 8.0f; g.acc_scale = lh.s_qkv[a];
+        if (m->qk_norm) { g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; }      // null gains: the epilogue splits q / k as projected
         { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV_NORM, g); }
         if (rc) return rc;
         {
@@ -636,13 +647,13 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         GemmParamsH g{};
         g.A = w.xnh; g.lda = d; g.W = lh.Wqkv[a]; g.ldw = d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
         g.vt = w.vth; g.vt_nblk = w.vt_nblk;
-        const bool bnd = m->bounded[j] != 0;                              // this launch's softmax kernel (per layer and branch)
+        const bool bnd = m->qk_norm && m->bounded[j] != 0;                // this launch's softmax kernel (per layer and branch)
         const bool prescale = attention_h16_wants_prescaled_q(dt, bnd);
         // few-token calls (fewer 256 x 256 tiles than CUs): the 128 x 128 kernel fills the chip better than the fused epilogue's 256 x 256
         // tiles save (it exists only in the phase-split kernels), so the projection and qk-norm run as two kernels there
         // (r03 call 32: one pair of 2 x 1024 points, 10 steps, bf16: 21.3 -> 18.5 ms; at 2 x 4096 -- 192 tiles -- the fused form is still ahead)
         const bool few_tiles = (long)((TP + 255) / 256) * (3 * d / 256) < 128;
-        if (g_rap_fuse_qknorm && !few_tiles) {
+        if (g_rap_fuse_qknorm && !few_tiles && m->qk_norm) {
           // qk-norm in the QKV epilogue: one kernel, q / k normalised from the fp32 accumulators (no 16-bit round trip through HBM)
           g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; g.q_mul = prescale ? RAP_QMUL_PRESCALED : 8.0f;
           { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV_NORM, g); }
@@ -650,7 +661,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         } else {
           { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV, g); }
           if (rc) return rc;
-          if ((rc = launch_qknorm_h16(stream, dt, w.qkh, TP, H, lw.gq[a], lw.gk[a], prescale ? RAP_QMUL_PRESCALED : 8.0f))) return rc;
+          if (m->qk_norm && (rc = launch_qknorm_h16(stream, dt, w.qkh, TP, H, lw.gq[a], lw.gk[a], prescale ? RAP_QMUL_PRESCALED : 8.0f))) return rc;
         }
         {
           ProfScope ps(stream, a);
@@ -688,14 +699,14 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       if (rc) return rc;
       GemmParams g{};
       g.A = w.xn; g.lda = d; g.W = lw.Wqkv[a]; g.ldw = d; g.C = w.qkv; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
-      const bool fuse_qk = g_rap_fuse_qknorm != 0;
+      const bool fuse_qk = g_rap_fuse_qknorm != 0 && m->qk_norm;
       if (fuse_qk) { g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; }        // qk-norm in the QKV epilogue (tuning key 7)
       { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_QKV_HEADMAJOR, g); }
       if (rc) return rc;
-      if (!fuse_qk && (rc = launch_qknorm(stream, w.qkv, TP, H, lw.gq[a], lw.gk[a]))) return rc;
+      if (!fuse_qk && m->qk_norm && (rc = launch_qknorm(stream, w.qkv, TP, H, lw.gq[a], lw.gk[a]))) return rc;
       {
         ProfScope ps(stream, a);
-        const float* bound = m->bounded[j] ? m->logit_bound + (size_t)j * H : nullptr;
+        const float* bound = (m->qk_norm && m->bounded[j]) ? m->logit_bound + (size_t)j * H : nullptr;
         // few-token calls: split the keys of every work item over up to 4 blocks; the partial O planes live in the (idle) FFN
         // buffer (4 x TP x d floats), the partial row sums in the (idle) LN-output buffer
         const int max_items = a == 0 ? w.max_items_part : w.max_items_batch;

@@ -252,249 +252,14 @@ __global__ __launch_bounds__(512, WPE) void attention_x2_kernel(const u16* __res
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Software-pipelined form (round 5, tuning key 16 = 1).  In the kernel above a wave runs S = K Q^T (24 MFMAs), THEN the softmax (~250
-// VALU instructions, 32 of them v_exp_f32), THEN O += V^T P^T (24 MFMAs): during the softmax the wave issues no MFMA, and because all
-// eight waves of the block leave the one barrier per tile in the same role, the two waves of a SIMD run their softmax at the same time --
-// the matrix pipe idles for that stretch (measured: 0.44 of the 833 TF split-precision peak, i.e. the pipe ~0.6 busy at the clock the
-// part sustains).  Here the softmax of tile t + 1 is interleaved, in program order, with the P V MFMAs of tile t -- they are independent:
-//   iteration t:   S' = K(t+1) Q^T                      24 MFMAs
-//                  row maxima of S', rescale decision    ~25 VALU
-//                  for each of the 4 key steps:          6 MFMAs of O += V(t) P(t)   |   exp / sum / head-tail split of 8 values of S'
-//                  P(t+1) replaces P(t) in place (32 registers: 4 x (head, tail) fragments)
-// so every wave's own instruction stream keeps the matrix pipe fed.  K runs one tile ahead of V^T in the LDS ring (two slots each, the
-// same 64 KB).  Results are identical to the kernel above up to the order in which a tile's probabilities enter the row sum.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void attention_x2p_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt, int vt_nblk,
-                                                               u16* __restrict__ out, int TP, int heads,
-                                                               const AttnWorkItem* __restrict__ items) {
-  typedef x2_t8 T8;
-  extern __shared__ __attribute__((aligned(1024))) u16 smem[];   // [K slot 0 | K slot 1 | V slot 0 | V slot 1], each 2 chunks x 8 KB
-  const int tid = threadIdx.x;
-  const int head = blockIdx.x % heads;
-  const AttnWorkItem it = items[blockIdx.x / heads];
-  const int len = it.seg_len;
-  if (len <= 0) return;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int seg0 = it.seg_start, seg1 = it.seg_start + len;
-  const u16* Qg = qk + (size_t)head * 2 * TP * 64;
-  const u16* Kg = qk + (size_t)(heads + head) * 2 * TP * 64;
-  const u16* Vg = vt + (size_t)head * vt_nblk * (2 * XSUB);
-  const int qw0 = it.q0 + wave * 32;
-  const bool wave_active = qw0 < len;
-
-  T8 qh[4], ql[4];
-  {
-    int q = qw0 + l31;
-    q = q < len ? q : len - 1;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const u16* qp = Qg + ((size_t)(s >> 1) * TP + seg0 + q) * 64 + 16 * (s & 1) + 8 * hi;
-      qh[s] = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(qp));
-      ql[s] = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(qp + 32));
-    }
-  }
-  f32x16 o0, o1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float mrun = -1e30f, lsum = 0.f;
-  const float c = 0.125f * 1.44269504088896340736f;
-  const int b_first = seg0 >> 6;
-  const int ntile = ((seg1 - 1) >> 6) - b_first + 1;
-  const int drow = wave * 8 + (lane >> 3);
-  const int dls = ((lane & 7) ^ ((drow >> 1) & 7)) * 8;
-  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) u16*)smem + (unsigned)wave * 1024u);
-  // K tile T -> K slot (T & 1) at bytes [slot * 16 KB, +16 KB); V^T tile T -> V slot (T & 1) at 32 KB + slot * 16 KB
-#define XP_DMA_K(T)                                                                                           \
-  {                                                                                                           \
-    int tok_ = (b_first + (T)) * 64 + drow;                                                                   \
-    tok_ = tok_ < TP ? tok_ : TP - 1;                                                                         \
-    const unsigned st_ = lds_base + (unsigned)((T) & 1) * (2 * XSUB * 2);                                     \
-    XATT_DMA1(Kg + (size_t)tok_ * 64 + dls, st_)                                                              \
-    XATT_DMA1(Kg + ((size_t)TP + tok_) * 64 + dls, st_ + XSUB * 2)                                            \
-  }
-#define XP_DMA_V(T)                                                                                           \
-  {                                                                                                           \
-    const int blk_ = b_first + (T);                                                                           \
-    const unsigned st_ = lds_base + 4 * XSUB * 2 + (unsigned)((T) & 1) * (2 * XSUB * 2);                      \
-    XATT_DMA1(Vg + ((size_t)(2 * blk_) * 64 + drow) * 64 + dls, st_)                                          \
-    XATT_DMA1(Vg + ((size_t)(2 * blk_ + 1) * 64 + drow) * 64 + dls, st_ + XSUB * 2)                           \
-  }
-  const int swz = (l31 >> 1) & 7;
-  // S = K(T) Q^T into (s0, s1), keys outside the segment masked
-#define XP_SCORES(T)                                                                                          \
-  {                                                                                                           \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }                              \
-    const u16* kt_ = smem + ((T) & 1) * (2 * XSUB);                                                           \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                           \
-      const u16* kp = kt_ + (s >> 1) * XSUB + l31 * 64;                                                       \
-      const int oh = ((2 * (s & 1) + hi) ^ swz) * 8, ol = ((4 + 2 * (s & 1) + hi) ^ swz) * 8;                 \
-      const T8 k0h = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + oh));                       \
-      const T8 k0l = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + ol));                       \
-      const T8 k1h = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 32 * 64 + oh));             \
-      const T8 k1l = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(kp + 32 * 64 + ol));             \
-      s0 = H16<RAP_DT_F16>::mfma(k0l, qh[s], s0);                                                             \
-      s1 = H16<RAP_DT_F16>::mfma(k1l, qh[s], s1);                                                             \
-      s0 = H16<RAP_DT_F16>::mfma(k0h, ql[s], s0);                                                             \
-      s1 = H16<RAP_DT_F16>::mfma(k1h, ql[s], s1);                                                             \
-      s0 = H16<RAP_DT_F16>::mfma(k0h, qh[s], s0);                                                             \
-      s1 = H16<RAP_DT_F16>::mfma(k1h, qh[s], s1);                                                             \
-    }                                                                                                         \
-    const int tile0 = (b_first + (T)) * 64;                                                                   \
-    if (tile0 < seg0 || tile0 + 64 > seg1) {                                                                  \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
-        const int kg = tile0 + mfma32_crow(r, hi);                                                            \
-        s0[r] = (kg >= seg0 && kg < seg1) ? s0[r] : -1e30f;                                                   \
-        s1[r] = (kg + 32 >= seg0 && kg + 32 < seg1) ? s1[r] : -1e30f;                                         \
-      }                                                                                                       \
-    }                                                                                                         \
-  }
-  // row maxima of (s0, s1), the deferred-rescale decision, the new running maximum; alpha = the factor O and l take (1 when unchanged)
-#define XP_ROWMAX()                                                                                           \
-  {                                                                                                           \
-    float ma = x_max3(s0[0], s0[1], s0[2]), mb = x_max3(s1[0], s1[1], s1[2]);                                 \
-    _Pragma("unroll") for (int r = 3; r < 15; r += 2) { ma = x_max3(ma, s0[r], s0[r + 1]); mb = x_max3(mb, s1[r], s1[r + 1]); } \
-    const float mx = x_xhalf_max(x_max3(ma, mb, fmaxf(s0[15], s1[15])));                                      \
-    need = !__all((mx - mrun) * c <= X_DEFER_THR);                                                            \
-    const float mnew = need ? fmaxf(mrun, mx) : mrun;                                                         \
-    alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);                                                        \
-    mrun = mnew;                                                                                              \
-    lsum *= alpha;                                                                                            \
-  }
-  // probabilities of key step KS (8 values of sub-tile KS >> 1) -> row sum and the (head, tail) fragments ph[KS], pl[KS]
-#define XP_PROBS(KS, PH, PL)                                                                                  \
-  {                                                                                                           \
-    const int rb = 8 * ((KS) & 1);                                                                            \
-    f32x8 p8;                                                                                                 \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                             \
-      p8[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(((KS) >> 1) == 0 ? s0[rb + e] : s1[rb + e], c, nmc));     \
-    ps += ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));                          \
-    x2_split8_nosat(p8, PH[KS], PL[KS]);                                                                      \
-  }
-#define XP_PV(T, KS, PH, PL)                                                                                  \
-  {                                                                                                           \
-    const u16* vp = smem + 4 * XSUB + ((T) & 1) * (2 * XSUB) + ((KS) >> 1) * XSUB + l31 * 64;                 \
-    const int oh = ((2 * ((KS) & 1) + hi) ^ swz) * 8, ol = ((4 + 2 * ((KS) & 1) + hi) ^ swz) * 8;             \
-    const T8 v0h = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + oh));                         \
-    const T8 v0l = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + ol));                         \
-    const T8 v1h = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 32 * 64 + oh));               \
-    const T8 v1l = __builtin_bit_cast(T8, *reinterpret_cast<const uint4*>(vp + 32 * 64 + ol));               \
-    o0 = H16<RAP_DT_F16>::mfma(v0l, PH[KS], o0);                                                              \
-    o1 = H16<RAP_DT_F16>::mfma(v1l, PH[KS], o1);                                                              \
-    o0 = H16<RAP_DT_F16>::mfma(v0h, PL[KS], o0);                                                              \
-    o1 = H16<RAP_DT_F16>::mfma(v1h, PL[KS], o1);                                                              \
-    o0 = H16<RAP_DT_F16>::mfma(v0h, PH[KS], o0);                                                              \
-    o1 = H16<RAP_DT_F16>::mfma(v1h, PH[KS], o1);                                                              \
-  }
-
-  // ---- prologue: K(0), V(0), K(1) in flight; scores and probabilities of tile 0
-  XP_DMA_K(0)
-  XP_DMA_V(0)
-  if (ntile > 1) { XP_DMA_K(1) }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    uint4 a_ = __builtin_bit_cast(uint4, qh[s]), b_ = __builtin_bit_cast(uint4, ql[s]);
-    asm volatile("" : "+v"(a_.x), "+v"(a_.y), "+v"(a_.z), "+v"(a_.w), "+v"(b_.x), "+v"(b_.y), "+v"(b_.z), "+v"(b_.w));
-    qh[s] = __builtin_bit_cast(T8, a_); ql[s] = __builtin_bit_cast(T8, b_);
-  }
-  __syncthreads();
-
-  f32x16 s0, s1;
-  T8 pha[4], pla[4], phb[4], plb[4];            // P(t) and P(t + 1): two fragment sets, so that the softmax of tile t + 1 does not wait for
-  bool need;                                    // the MFMAs that read P(t) (32 more registers; the loop is unrolled by two over the sets)
-  float alpha, nmc, ps;
-  if (wave_active) {
-    XP_SCORES(0)
-    XP_ROWMAX()                      // first tile: mrun = -1e30 -> the maximum is taken, alpha = 0 on l = 0 and O = 0
-    nmc = -mrun * c; ps = 0.f;
-    XP_PROBS(0, pha, pla) XP_PROBS(1, pha, pla) XP_PROBS(2, pha, pla) XP_PROBS(3, pha, pla)
-    lsum += ps;
-  }
-  need = false;                                 // (tile 0's "rescale" acted on O = 0)
-
-  // one iteration: tile T's P V product (fragments PH / PL) with the scores and the softmax of tile T + 1 (-> NH / NL)
-#define XP_ITER(T, PH, PL, NH, NL)                                                                            \
-  {                                                                                                           \
-    if ((T) + 2 < ntile) { XP_DMA_K((T) + 2) }      /* into the slot K(T) left at the last barrier */           \
-    XP_DMA_V((T) + 1)                               /* into the slot V(T - 1) left at the last barrier */       \
-    if (wave_active) {                                                                                        \
-      if (need) {   /* rare (deferred rescale, decided one iteration ago): O of tiles <= T moves to the reference P(T) was formed against */ \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }                    \
-      }                                                                                                       \
-      XP_SCORES((T) + 1)                                                                                      \
-      /* ONE scheduling region from here to the barrier: the 24 MFMAs of O += V(T) P(T) with the softmax of tile T + 1 in their shadow */ \
-      XP_ROWMAX()                                                                                             \
-      nmc = -mrun * c; ps = 0.f;                                                                              \
-      XP_PV(T, 0, PH, PL) XP_PROBS(0, NH, NL)                                                                 \
-      XP_PV(T, 1, PH, PL) XP_PROBS(1, NH, NL)                                                                 \
-      XP_PV(T, 2, PH, PL) XP_PROBS(2, NH, NL)                                                                 \
-      XP_PV(T, 3, PH, PL) XP_PROBS(3, NH, NL)                                                                 \
-      lsum += ps;                                                                                             \
-      /* the interleave hipcc does not choose by itself (it issues the 24 MFMAs back to back and the ~230 VALU instructions after   \
-         them, and a wave issues in order): per MFMA one V^T fragment read while there are any, then a share of the VALU work */   \
-      _Pragma("unroll") for (int i = 0; i < 24; ++i) {                                                        \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                    \
-        if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                                    \
-      }                                                                                                       \
-    }                                                                                                         \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
-    __syncthreads();                                                                                          \
-  }
-  int t = 0;
-  for (; t + 2 < ntile; t += 2) {
-    XP_ITER(t, pha, pla, phb, plb)
-    XP_ITER(t + 1, phb, plb, pha, pla)
-  }
-  bool last_in_b = false;
-  if (t + 1 < ntile) {
-    XP_ITER(t, pha, pla, phb, plb)
-    last_in_b = true;
-  }
-  if (wave_active) {
-    const int tl = ntile - 1;
-    if (need) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-    }
-    if (last_in_b) { XP_PV(tl, 0, phb, plb) XP_PV(tl, 1, phb, plb) XP_PV(tl, 2, phb, plb) XP_PV(tl, 3, phb, plb) }
-    else { XP_PV(tl, 0, pha, pla) XP_PV(tl, 1, pha, pla) XP_PV(tl, 2, pha, pla) XP_PV(tl, 3, pha, pla) }
-  }
-  __syncthreads();                 // the output slabs (36 KB from the start of the LDS) reach into V slot 0: every wave has read its last V^T tile
-  if (!wave_active) return;
-  // ---- normalise, split and store (as above)
-  const float inv = 1.0f / x_xhalf_sum(lsum);
-  u16* slab = smem + wave * (32 * XLD);
-  u16* wp = slab + l31 * XLD + 4 * hi;
-  const size_t orow = (size_t)heads * 128;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v4 = e == 0 ? f32x4{o0[4 * g + 0], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]} : f32x4{o1[4 * g + 0], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
-      const f32x4 n4 = v4 * inv;
-      const x2_t4 h4 = __builtin_convertvector(n4, x2_t4);
-      const x2_t4 l4 = __builtin_convertvector(n4 - __builtin_convertvector(h4, f32x4), x2_t4);
-      *reinterpret_cast<uint2*>(wp + 8 * g) = __builtin_bit_cast(uint2, h4);
-      *reinterpret_cast<uint2*>(wp + 32 + 8 * g) = __builtin_bit_cast(uint2, l4);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (lane >> 3) + 8 * i, piece = lane & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(slab + row * XLD + piece * 8);
-      if (qw0 + row < len)
-        *reinterpret_cast<uint4*>(out + (size_t)(seg0 + qw0 + row) * orow + head * 128 + e * 64 + piece * 8) = v;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-rap_tuning_t g_rap_attn_x2_wpe = 2;      // tuning key 16: 1 = the software-pipelined kernel; 2 / 4 = the plain kernel at one / two blocks per CU
+// Measured and NOT kept (round 5, GPU call 2; source at commit "split-precision attention: software-pipelined kernel", numbers in
+// profiles/r05_c2_x2_attention_pipelined_ab.jsonl): a software-pipelined form of this kernel -- the softmax of tile t + 1 interleaved, by
+// sched_group_barrier, with the 24 P V MFMAs of tile t (K one tile ahead of V^T in the LDS ring, ping-pong P fragments, 200 VGPRs) so
+// that a wave never stops issuing MFMAs for the ~180 VALU instructions of a tile's softmax: 5.99 / 11.44 ms per launch at L = 4096 /
+// 8192 against 5.62 / 11.05 ms for this kernel, 43.4 k vs 45.1 k points/s for the whole call.  Two blocks per CU (WPE = 4) are no
+// faster either.  As for the bf16 kernel, every schedule lands on the same ~1.2 PFLOP/s of issued fp16 MFMA work: the
+// SQ counters (profiles/r05_c3_mfma_utilisation_x2.txt) show the clock the part sustains under this load, not the schedule, as the limit.
+rap_tuning_t g_rap_attn_x2_wpe = 2;      // tuning key 16: 2 / 4 = one / two blocks per CU
 
 int launch_attention_x2(hipStream_t stream, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP, int heads,
                         const AttnWorkItem* items, int max_items) {
@@ -502,15 +267,13 @@ int launch_attention_x2(hipStream_t stream, const u16* qk, const u16* vt, int vt
   if (heads <= 0 || vt_nblk * 64 < TP) return RAP_ERR_INVALID;
   constexpr int LDS = 2 * 4 * XSUB * 2;      // 64 KB
   static_assert(8 * 32 * XLD * 2 <= LDS, "output slabs must fit the stages");
-  const int variant = g_rap_attn_x2_wpe;
-  const void* fn = variant == 1 ? reinterpret_cast<const void*>(attention_x2p_kernel)
-                   : variant == 4 ? reinterpret_cast<const void*>(attention_x2_kernel<4>) : reinterpret_cast<const void*>(attention_x2_kernel<2>);
+  const bool two = g_rap_attn_x2_wpe == 4;
+  const void* fn = two ? reinterpret_cast<const void*>(attention_x2_kernel<4>) : reinterpret_cast<const void*>(attention_x2_kernel<2>);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
     rap_set_last_hip_error((int)hipGetLastError());
     return RAP_ERR_HIP;
   }
-  if (variant == 1) hipLaunchKernelGGL(attention_x2p_kernel, dim3(max_items * heads), dim3(512), LDS, stream, qk, vt, vt_nblk, out, TP, heads, items);
-  else if (variant == 4) hipLaunchKernelGGL(attention_x2_kernel<4>, dim3(max_items * heads), dim3(512), LDS, stream, qk, vt, vt_nblk, out, TP, heads, items);
+  if (two) hipLaunchKernelGGL(attention_x2_kernel<4>, dim3(max_items * heads), dim3(512), LDS, stream, qk, vt, vt_nblk, out, TP, heads, items);
   else hipLaunchKernelGGL(attention_x2_kernel<2>, dim3(max_items * heads), dim3(512), LDS, stream, qk, vt, vt_nblk, out, TP, heads, items);
   RAP_LAUNCH_CHECK();
   return RAP_OK;

@@ -406,14 +406,15 @@ __device__ __forceinline__ void gemm_x2_qknorm_epilogue(const GemmParamsH& p, f3
   const int dmodel = p.heads * 64;
   const int c = nw / dmodel;                      // 0 = q, 1 = k (wave-uniform)
   const int h = (nw - c * dmodel) >> 6;
-  const float* gam = (c == 0 ? p.gamma_q : p.gamma_k) + h * 64;
+  const bool norm = p.gamma_q != nullptr;         // null gains (qk_norm = False, layer.py:103-104): q / k leave as projected
+  const float* gam = norm ? (c == 0 ? p.gamma_q : p.gamma_k) + h * 64 : nullptr;
   const float mul = c == 0 ? p.q_mul : 8.0f;
   const float sc = p.acc_scale;
   float g[2][16];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) g[j][r] = gam[32 * j + mfma32_crow(r, hi)] * mul;
+    for (int r = 0; r < 16; ++r) g[j][r] = norm ? gam[32 * j + mfma32_crow(r, hi)] * mul : 1.0f;
   u16* plane = reinterpret_cast<u16*>(p.C) + (((size_t)(c * p.heads + h) * 2) * p.M) * 64;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -426,7 +427,7 @@ __device__ __forceinline__ void gemm_x2_qknorm_epilogue(const GemmParamsH& p, f3
       const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
       ss = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
     }
-    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    const float inv = norm ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
     const int m = mw + 32 * i + l31;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1260,7 +1261,7 @@ static int launch_x2(hipStream_t stream, int epilogue, const GemmParamsH& p) {
       if (p.ldc & 7) return RAP_ERR_INVALID;
       return launch_x2_variant<EPI_H_GEGLU>(stream, p);
     case EPI_H_QKV_NORM:
-      if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256 || !p.gamma_q || !p.gamma_k) return RAP_ERR_INVALID;
+      if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256 || ((p.gamma_q == nullptr) != (p.gamma_k == nullptr))) return RAP_ERR_INVALID;
       return launch_x2_variant<EPI_H_QKV_NORM>(stream, p);
     default: return RAP_ERR_INVALID;
   }

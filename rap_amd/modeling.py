@@ -353,7 +353,8 @@ class RectifiedPointFlow:
         ws = workspace(device, lib.rap_workspace_bytes(model._handle, TP, B, B * P, S))
         stream = _lib.current_stream(device)
         with torch.cuda.device(device):
-            rc = lib.rap_sample(model._handle, _lib.ptr(cond), _lib.ptr(d["feats"]), _lib.ptr(d["scales"]), _lib.ptr(d["anchor"]),
+            feats = d["feats"] if getattr(model, "_native_feat", 1) else None      # local_feat_concat_on=False: the features are not an input
+            rc = lib.rap_sample(model._handle, _lib.ptr(cond), _lib.ptr(feats), _lib.ptr(d["scales"]), _lib.ptr(d["anchor"]),
                                 _lib.ptr(d["ppp"]), _lib.ptr(d["cu_batch"]), _lib.ptr(x_1), B, P, TP, S,
                                 1 if self.rigidity_forcing else 0, _lib.ptr(traj_x0), _lib.ptr(traj_xt), _lib.ptr(R),
                                 _lib.ptr(t), _lib.ptr(feats_out), _lib.ptr(ws), ws.numel(), stream)
@@ -412,6 +413,17 @@ class RectifiedPointFlow:
         if batch_generations is None:
             batch_generations = os.environ.get("RAP_BATCH_GENERATIONS", "1") != "0"
         stacked_call = batch_generations and G > 1 and G * B * P <= 65535 and G * TP <= 0x7fffffff // 8
+        if stacked_call:
+            # memory gate: the stacked call needs the workspace AND the trajectories of G x TP points at once (fp32: ~23 KB of
+            # workspace per point + 24 B per point per flow step); near-limit batches with several generations would exhaust the device where
+            # the loop fits.  Stack only when that fits into half of the memory that is free right now.
+            model = self.flow_model
+            model._activate(cond.device)
+            S_ = int(self.inference_sampling_steps)
+            need = (_lib.load().rap_workspace_bytes(model._handle, G * TP, G * B, G * B * P, S_) + 2 * S_ * G * TP * 12
+                    + G * TP * (24 + 4 * (d["feats"].shape[1] if d["feats"].dim() == 2 else 0)))
+            free, _total = torch.cuda.mem_get_info(cond.device)
+            stacked_call = need <= (free + torch.cuda.memory_reserved(cond.device) - torch.cuda.memory_allocated(cond.device)) // 2
         avg = use_average_rigidity_rmse and self.return_end_point_trajectory
         if stacked_call:
             device = cond.device

@@ -26,8 +26,8 @@ RAP_16 = dict(embed_dim=512, num_layers=16, num_heads=8, local_feat_dim=32)
 
 
 def embed_in_dim(cfg) -> int:
-    """63 (cond PE) + 63 (x_t PE) + 21 (scale PE) + local_feat_dim  (embedding.py:107-116)."""
-    return 63 + 63 + 21 + cfg["local_feat_dim"]
+    """63 (cond PE) + 63 (x_t PE) + 21 (scale PE, if scale_emb_on) + local_feat_dim (if local_feat_concat_on)  (embedding.py:107-118)."""
+    return 63 + 63 + (21 if cfg.get("scale_emb_on", True) else 0) + (cfg["local_feat_dim"] if cfg.get("local_feat_concat_on", True) else 0)
 
 
 def weight_spec(cfg) -> list[tuple[str, tuple[int, ...]]]:
@@ -49,9 +49,10 @@ def weight_spec(cfg) -> list[tuple[str, tuple[int, ...]]]:
                      (p + f"{a}_prenorm.linear.bias", (2 * d,)),
                      (p + f"{a}_qkv_proj.weight", (3 * d, d)),
                      (p + f"{a}_out_proj.weight", (d, d)),
-                     (p + f"{a}_out_proj.bias", (d,)),
-                     (p + f"{a}_q_norm.gamma", (H, dh)),
-                     (p + f"{a}_k_norm.gamma", (H, dh))]
+                     (p + f"{a}_out_proj.bias", (d,))]
+            if cfg.get("qk_norm", True):                       # layer.py:75-77, 83-85: the norms exist only with qk_norm=True
+                spec += [(p + f"{a}_q_norm.gamma", (H, dh)),
+                         (p + f"{a}_k_norm.gamma", (H, dh))]
         spec += [(p + "ff_norm.weight", (d,)), (p + "ff_norm.bias", (d,)),
                  (p + "ff.net.0.proj.weight", (8 * d, d)), (p + "ff.net.0.proj.bias", (8 * d,)),
                  (p + "ff.net.2.weight", (d, 4 * d)), (p + "ff.net.2.bias", (d,))]

@@ -31,3 +31,7 @@ GOLDEN_CASES = ["l2_ragged_rigid", "l2_ragged_free", "l2_emptypart_rigid", "l12_
 # the reference's other two model sizes (rap_10, rap_16; config/model/flow_model/point_cloud_dit_{10,16}.yaml), fixtures from the unmodified
 # reference like the ones above (oracle/make_golden.py --case=...)
 MODEL_SIZE_CASES = ["l16_small_rigid", "l10_small_free"]
+# the constructor switches of PointCloudDiT every shipped config leaves True (point_cloud_dit.py:28,33-34), one fixture each from the
+# unmodified reference (round 5; oracle/make_golden.py CASE_SWITCHES): name -> keyword overrides
+SWITCH_CASES = {"l2_noqknorm_rigid": {"qk_norm": False}, "l2_noscale_free": {"scale_emb_on": False},
+                "l2_nofeat_rigid": {"local_feat_concat_on": False}}

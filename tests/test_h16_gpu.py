@@ -218,6 +218,21 @@ def test_gemm_h16_fp16_residual_epilogue(lib, dev, dt, M, K):
     gemm_h(lib, dev, dt, 7, A2d, W2d, bigd, M, N, K, resid=bigd)
     assert torch.isfinite(bigd).all() and bool((bigd.abs().float() == 65504.0).all())
     assert bool((torch.sign(bigd.float()) == sgn.to(dev)).all())
+    # ... and NaN stays NaN (round 5, ADVICE r04: v_med3_f32 alone returns the minimum of the other two operands for a NaN input, i.e. the
+    # saturation laundered a NaN of the stream into -65504 where the reference's fp16 arithmetic propagates it): a NaN in the residual
+    # and a NaN in the operands both reach the output; the finite rows next to them are untouched
+    h1 = (torch.randn(M, N, generator=g) * 3).to(torch.float16)
+    h1[1, 5] = float("nan")
+    A3 = A.clone(); A3[3, 7] = float("nan")
+    ref3 = h1.double() + A3.double() @ W.double().T + bias.double()
+    A3d, h1d = A3.to(dev), h1.to(dev).clone()
+    gemm_h(lib, dev, dt, 7, A3d, Wd, h1d, M, N, K, bias=bd, resid=h1d)
+    out3 = h1d.cpu()
+    assert torch.isnan(out3[1, 5]) and bool(torch.isnan(out3[3]).all())
+    keep = torch.ones(M, N, dtype=torch.bool); keep[1, 5] = False; keep[3] = False
+    assert bool(torch.isfinite(out3[keep]).all())
+    err3 = ((out3.double() - ref3).abs() / (ref3.abs() + 1e-2))[keep]
+    assert err3.max().item() < 1.01 * ULP[2] + 1e-4
     # the epilogue needs its residual: without one the call is refused (a plain fp16-output GEMM is epilogue 0 with dtype fp16)
     rc = lib.rap_gemm_h16(dt, 7, _lib.ptr(Ad), K, _lib.ptr(Wd), K, _lib.ptr(hd), N, M, N, K, _lib.ptr(bd), _lib.ptr(None), 0, 0, _lib.ptr(None), 0,
                           stream(dev))

@@ -234,3 +234,42 @@ def test_bench_golden_parity_accepts_the_rank1_fixture():
         assert r["fixture"].endswith((name or "headline_c1_rigid") + ".npz")
         assert r["final_cloud_max_abs"] == 0 and r["R_frob_max"] == 0 and r["t_max_abs"] == 0 and r["per_step_max_abs"]["max"] == 0
     assert bench.golden_parity(types.SimpleNamespace(views=8, points=2048, flow_steps=30, layers=12, rigidity=1), last, None) is None
+
+
+def test_constructor_switches_map_onto_the_native_weight_layout():
+    """qk_norm / scale_emb_on / local_feat_concat_on = False (point_cloud_dit.py:28,33-34): the reference's state_dict for that
+    configuration (fewer embedding columns, no q / k gains) is widened to the native model's full layout on the host -- zero weight
+    columns for an absent embedding input (exact), unit gains the native model never reads.  Host-side only (no GPU)."""
+    import ctypes
+    import torch
+    import rap_amd
+    from conftest import SWITCH_CASES
+    from rap_amd import _lib, synthetic as S
+    lib = _lib.load()
+    for name, kw in SWITCH_CASES.items():
+        cfg = dict(S.RAP_12); cfg["num_layers"] = 2; cfg.update(kw)
+        sd = S.make_weights(cfg, 1)
+        m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=2, num_heads=8, local_feat_dim=32, **kw)
+        res = m.load_state_dict(sd)
+        assert res.missing_keys == [] and res.unexpected_keys == []
+        native = list(m._native_tensors())
+        desc = _lib.ModelDesc(512, 2, 8, m._native_feat)
+        assert sum(t.numel() for t in native) == lib.rap_weight_count(ctypes.byref(desc)), name
+        spec = S.weight_spec(m._native_cfg)
+        emb = native[[n for n, _ in spec].index("encoding_manager.emb_proj.weight")]
+        w = sd["encoding_manager.emb_proj.weight"]
+        assert torch.equal(emb[:, :126], w[:, :126])
+        if name == "l2_noscale_free":
+            assert emb.shape[1] == 179 and float(emb[:, 126:147].abs().max()) == 0.0 and torch.equal(emb[:, 147:], w[:, 126:])
+        if name == "l2_nofeat_rigid":
+            assert m._native_feat == 0 and emb.shape[1] == 147 and torch.equal(emb, w)
+        if name == "l2_noqknorm_rigid":
+            assert not any(k.endswith("_norm.gamma") for k in sd) and emb.shape[1] == 179
+            gains = [t for (n, _), t in zip(spec, native) if n.endswith("_norm.gamma")]
+            assert len(gains) == 8 and all(bool((t == 1).all()) for t in gains)
+    # a state_dict of the WRONG configuration is refused like nn.Module does
+    import pytest
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=2, num_heads=8, local_feat_dim=32, qk_norm=False)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(S.make_weights(cfg, 1))          # carries q / k gains this configuration does not have

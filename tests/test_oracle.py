@@ -7,22 +7,23 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, MODEL_SIZE_CASES, load_golden
+from conftest import GOLDEN_CASES, MODEL_SIZE_CASES, SWITCH_CASES, load_golden
 from oracle import rap_oracle as O
 from oracle import ref_loader
 from rap_amd import synthetic as S
 
 
-def _cfg(g):
+def _cfg(g, name=None):
     cfg = dict(S.RAP_12)
     cfg["num_layers"] = int(g["num_layers"])
+    cfg.update(SWITCH_CASES.get(name, {}))
     return cfg
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES + MODEL_SIZE_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + MODEL_SIZE_CASES + list(SWITCH_CASES))
 def test_oracle_matches_reference_golden(name):
     g, inp = load_golden(name)
-    cfg = _cfg(g)
+    cfg = _cfg(g, name)
     sd = S.make_weights(cfg, int(g["weight_seed"]))
     chk = float(sum(v.double().sum().item() for v in sd.values()))
     assert abs(chk - float(g["weights_checksum"])) < 1e-6, "seeded weights differ from the ones the golden was made with"
@@ -44,11 +45,13 @@ def test_oracle_matches_reference_golden(name):
 
 
 @pytest.mark.skipif(not ref_loader.reference_available(), reason="/root/reference is only mounted in the build container")
-def test_oracle_matches_live_reference_modules():
+@pytest.mark.parametrize("switch", [{}] + list(SWITCH_CASES.values()), ids=["shipped-config"] + list(SWITCH_CASES))
+def test_oracle_matches_live_reference_modules(switch):
     cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    cfg.update(switch)
     sd = S.make_weights(cfg, 3)
     inp = S.make_inputs([[40, 77], [130, 20, 65]], seed=99)
-    for rigid in (False, True):
+    for rigid in ((False, True) if not switch else (True,)):
         ref = ref_loader.reference_sample(cfg, sd, inp, 3, rigid)
         mine = O.sample(sd, cfg, inp, 3, rigid)
         for k in ("end_point_trajectory", "trajectory", "R", "t"):

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import rap_amd
-from conftest import GOLDEN_CASES, MODEL_SIZE_CASES, load_golden
+from conftest import GOLDEN_CASES, MODEL_SIZE_CASES, SWITCH_CASES, load_golden
 from oracle import rap_oracle as O
 from rap_amd import synthetic as S
 
@@ -125,6 +125,46 @@ def test_other_model_sizes_match_reference_golden(name, mode, dev):
         et = (t.cpu() - torch.from_numpy(g["t"])).abs().max().item()
         assert eR <= 1e-3 and et <= 1e-3, (eR, et)
     print(f"{name} (L = {int(g['num_layers'])}): velocity {ev:.2e}  x0 {e0:.2e}  xt {e1:.2e}")
+
+
+@pytest.mark.parametrize("mode", FP32_MODES + ["bfloat16"])
+@pytest.mark.parametrize("name", list(SWITCH_CASES))
+def test_constructor_switches_match_reference_golden(name, mode, dev):
+    """qk_norm=False / scale_emb_on=False / local_feat_concat_on=False (point_cloud_dit.py:28,33-34; every shipped config leaves them True):
+    one forward and the whole sampling call against fixtures of the unmodified reference built with that switch, in both fp32-accurate
+    modes at the fp32 asserts (bf16: class bound; the qk_norm=False case runs the online-softmax kernels, logits unbounded)."""
+    g, inp = load_golden(name)
+    cfg = dict(S.RAP_12); cfg["num_layers"] = int(g["num_layers"]); cfg.update(SWITCH_CASES[name])
+    sd = S.make_weights(cfg, int(g["weight_seed"]))
+    assert abs(sum(v.double().sum().item() for v in sd.values()) - float(g["weights_checksum"])) < 1e-6
+    model = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=cfg["num_layers"], num_heads=8, local_feat_dim=32,
+                                  attn_dtype="float32", compute_dtype=mode, **SWITCH_CASES[name])
+    assert set(model.load_state_dict(sd).missing_keys) == set() and set(model.state_dict()) == set(sd)
+    model.to(dev)
+    cu_b, cu_p = O.prepare_cu_seqlens(inp)
+    d = to_dev(inp, dev)
+    out = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"],
+                local_features=d["features"], latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"],
+                cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev), return_transformer_features=True)
+    v_ref = torch.from_numpy(g["fwd_velocity"])
+    ev = (out["velocity"].cpu() - v_ref).abs().max().item()
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=int(g["num_steps"]), rigidity_forcing=bool(g["rigidity"]))
+    res = flow.sample_rectified_flow(d, None, x_1=d["x_1"])
+    e0 = (res["end_point_trajectory"].cpu() - torch.from_numpy(g["end_point_trajectory"])).abs().max().item()
+    e1 = (res["trajectory"].cpu() - torch.from_numpy(g["trajectory"])).abs().max().item()
+    print(f"{name} [{mode}]: velocity {ev:.2e}  x0 {e0:.2e}  xt {e1:.2e}")
+    if mode == "bfloat16":
+        assert ev <= 3e-2 * max(1.0, v_ref.abs().max().item()) and e0 <= 5e-2 and e1 <= 5e-2, (ev, e0, e1)
+        return
+    assert ev <= 1e-4 * v_ref.abs().max().item() and ev < 2e-5, ev
+    assert e0 < 5e-5 and e1 < 5e-5, (e0, e1)
+    if bool(g["rigidity"]):
+        R, t = flow.last_poses
+        assert torch.linalg.matrix_norm(R.cpu() - torch.from_numpy(g["R"])).max().item() < 1e-4
+        assert (t.cpu() - torch.from_numpy(g["t"])).abs().max().item() < 1e-4
+    if name == "l2_noqknorm_rigid":
+        from rap_amd import _lib
+        assert _lib.load().rap_model_bounded_attention_launches(model._handle) == 0      # no norm, no logit bound: online softmax everywhere
 
 
 def test_sample_matches_oracle_on_fresh_ragged_batch(dev):
@@ -676,3 +716,27 @@ def test_graph_replay_mode_equals_the_eager_call(dev):
         fast.synchronize()
     assert torch.isnan(res["R"]).all()
     model.load_state_dict(sd); model.to(dev)                                # leave the shared test model as it was
+
+
+def test_checkpoint_acceptance_script(dev, tmp_path):
+    """scripts/check_checkpoint.py (round 5): the one-command check for the day trained weights exist -- bounded launches, residual-stream
+    range against fp16, deviation and speed of every arithmetic mode with the checkpoint's own gains.  Run here on a Lightning-keyed
+    checkpoint file written from the seeded weights (what `torch.load(path)["state_dict"]` of the reference's loader sees)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    sd = S.make_weights(cfg, 0)
+    sd = {k: (v * 3.0 if "layers.1.global_q_norm" in k else v) for k, v in sd.items()}          # one hot branch: its launch goes online
+    path = os.path.join(str(tmp_path), "model.ckpt")
+    torch.save({"state_dict": {"flow_model." + k: v for k, v in sd.items()}, "epoch": 3}, path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_checkpoint.py"), path, "--layers", "2", "--points", "512",
+                        "--steps", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout[r.stdout.index("{"):])
+    assert j["bounded_attention_launches"] == "3 of 4" and j["logit_bound_8_max_gq_max_gk"]["heads_above_40"] >= 1
+    assert all(j[m]["finite"] for m in ("float32", "float32x2", "bfloat16", "float16"))
+    assert j["verdict"]["split_precision_is_fp32_accurate_here"] and not j["verdict"]["fp16_stream_saturates"]
+    assert j["float32x2"]["deviation_from_fp32"]["final_cloud_max_abs"] < j["float16"]["deviation_from_fp32"]["final_cloud_max_abs"]
