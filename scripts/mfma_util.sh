@@ -5,7 +5,7 @@ set -u
 OUT=$1; shift; mkdir -p "$OUT"; : > "$OUT/mfma_utilisation.txt"
 export TMPDIR=/tmp
 C="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"
-for dt in float32 bfloat16; do
+for dt in ${DTYPES:-float32 bfloat16}; do
   D=$(mktemp -d /tmp/mfu.XXXXXX)
   ( cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$D" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --dtype $dt --steps 1 --warmup 0 \
       --flow-steps 1 --no-cpu-baseline --no-secondary --no-ragged --no-profile --gamma-scale 0 "$@" > "$GRAFT_REPO_ROOT/$OUT/mfma_$dt.log" 2>&1 )
