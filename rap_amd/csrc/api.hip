@@ -153,6 +153,12 @@ extern rap_tuning_t g_rap_attn_h16_dma;          // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_f32_persistent;   // gemm_f32.hip
 extern rap_tuning_t g_rap_attn_x2_wpe;           // attn_x2.hip
 rap_tuning_t g_rap_attn_lpt = 1;               // tuning key 15: attention work lists longest-segment-first (1, default) or in segment order (0)
+// tuning key 17: split precision takes over from this many token rows (align_up(TP, 256)) per call; SMALLER calls of a model in compute
+// dtype 3 run the exact-fp32 kernels -- both are fp32-accurate, and below a few thousand tokens every kernel of a layer sits at the launch
+// floor, where the fp32 path's few-token forms (128 x 128 tiles, split-K, split-KV) are the faster ones (r05 call 3: configs[0] geometry,
+// one pair of 2 x 1024 points: 48.3 ms fp32 vs 52.6 ms on the 256 x 256-tile split kernels).  The two layouts need the same workspace
+// bytes (two 16-bit planes per value = one fp32).
+rap_tuning_t g_rap_x2_min_rows = 4096;
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 // Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
 // fp32 summation order -- 5 split-KV for few-token calls (fp32 attention), 6 split-K for few-row calls (fp32 GEMMs and the 16-bit
@@ -174,6 +180,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 12 && (value == 0 || value == 1)) { g_rap_gemm_f32_persistent = value; return RAP_OK; }
   if (key == 13 && (value == 0 || value == 1)) { g_rap_attn_h16_dma = value; return RAP_OK; }
   if (key == 15 && (value == 0 || value == 1)) { g_rap_attn_lpt = value; return RAP_OK; }
+  if (key == 17 && value >= 0) { g_rap_x2_min_rows = value; return RAP_OK; }   // split precision from this many token rows per call (smaller calls: exact fp32)
   if (key == 16 && (value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: 1 / 2 blocks per CU
   return RAP_ERR_INVALID;
 }
@@ -435,6 +442,11 @@ extern "C" int rap_model_qk_norm(const rap_model* m) { return m ? (m->qk_norm ? 
 // ---------------------------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------------------------
+// the arithmetic a call of `rows` token rows actually runs in (see g_rap_x2_min_rows)
+static int eff_dtype(const rap_model* m, size_t rows) {
+  return (m->dtype == RAP_DT_F32X2 && (long)rows < (long)g_rap_x2_min_rows) ? RAP_DT_F32 : m->dtype;
+}
+
 struct Workspace {
   float *base, *h, *xn, *qkv, *att, *ffmid, *ax, *v, *mod, *ada_scratch, *xt, *Rc, *tc, *tgrid;
   u16* h16;                            // the residual stream when it is held in fp16 (16-bit modes with resid_dtype = fp16; h is then null)
@@ -443,6 +455,7 @@ struct Workspace {
   float* splitk_h;                      // reduced-precision mode, few-token calls only: fp32 partial planes of the split-K ff2 GEMM (else null)
   int vt_nblk;
   int rows;                             // TQ = align_up(TP, 256): rows of every token-row buffer
+  int dtype;                            // the arithmetic this call runs in (eff_dtype: the model's, or fp32 for a small split-precision call)
   double* proc_partials;
   int32_t *token_sample, *part_offsets, *attn_sort;
   int32_t *cu_batch_s, *cu_part_s;      // sanitised copies of the caller's segment tables (clamped to [0, TP], non-decreasing)
@@ -462,16 +475,17 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   // ranges stop at the true segment ends).  See forward_step.
   const size_t T = align_up((size_t)TP, 256);
   w.rows = (int)T;
+  const int dtype = w.dtype = eff_dtype(m, T);
   w.base = (float*)take(T * d * 4);
-  const bool x2 = m->dtype == RAP_DT_F32X2;    // split precision: fp32 residual stream, every 16-bit activation buffer holds heads AND tails
-  const bool h16 = m->dtype != RAP_DT_F32 && !x2 && m->resid_dtype == RAP_DT_F16;
+  const bool x2 = dtype == RAP_DT_F32X2;    // split precision: fp32 residual stream, every 16-bit activation buffer holds heads AND tails
+  const bool h16 = dtype != RAP_DT_F32 && !x2 && m->resid_dtype == RAP_DT_F16;
   w.h = h16 ? nullptr : (float*)take(T * d * 4);
   w.h16 = h16 ? (u16*)take(T * d * 2) : nullptr;
   w.xn = w.qkv = w.att = w.ffmid = nullptr;
   w.xnh = w.qkh = w.vth = w.atth = w.ffmidh = nullptr;
   w.splitk_h = nullptr;
   w.vt_nblk = 0;
-  if (m->dtype == RAP_DT_F32) {
+  if (dtype == RAP_DT_F32) {
     w.xn = (float*)take(T * d * 4);            // also head hidden 1 (TP,d)
     w.qkv = (float*)take(T * 3 * d * 4);
     w.att = (float*)take(T * d * 4);           // also head hidden 2 (TP,d/2)
@@ -545,7 +559,7 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
     cu_part = w.cu_part_s;
   }
   if ((rc = launch_token_sample(stream, cu_batch, B, w.token_sample))) return rc;
-  const int bq = m->dtype == RAP_DT_F32 ? 0 : m->dtype == RAP_DT_F32X2 ? 256 : attention_h16_block_queries(m->dtype);
+  const int bq = w.dtype == RAP_DT_F32 ? 0 : w.dtype == RAP_DT_F32X2 ? 256 : attention_h16_block_queries(w.dtype);
   int32_t* sort_ws = g_rap_attn_lpt ? w.attn_sort : nullptr;
   if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch, bq, sort_ws))) return rc;
   if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part, bq, sort_ws))) return rc;
@@ -558,8 +572,8 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
   if ((rc = zero_rows(stream, w.base, (size_t)d * 4, TP, TQ))) return rc;
   if ((rc = zero_rows(stream, w.ax, 64 * 4, TP, TQ))) return rc;
   if ((rc = zero_rows(stream, w.token_sample, 4, TP, TQ))) return rc;
-  if (m->dtype == RAP_DT_F32) { if ((rc = zero_rows(stream, w.att, (size_t)d * 4, TP, TQ))) return rc; }
-  else if ((rc = zero_rows(stream, w.atth, (size_t)d * 2 * (m->dtype == RAP_DT_F32X2 ? 2 : 1), TP, TQ))) return rc;
+  if (w.dtype == RAP_DT_F32) { if ((rc = zero_rows(stream, w.att, (size_t)d * 4, TP, TQ))) return rc; }
+  else if ((rc = zero_rows(stream, w.atth, (size_t)d * 2 * (w.dtype == RAP_DT_F32X2 ? 2 : 1), TP, TQ))) return rc;
   // base = [PE63(cond) | PE21(scale) | feat | 0] Wstatic^T + emb bias + anchor embedding   (embedding.py:155-179,
   // point_cloud_dit.py:119-139) -- everything in the embedding that does not depend on x_t.
   float* astatic = w.astatic;
@@ -590,7 +604,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
     if ((rc = launch_gemm_f32(stream, EPI_BIAS_RESID, g))) return rc;
     if (w.h16 && (rc = launch_convert_f16_sat(stream, w.hid1, w.h16, (size_t)TP * d))) return rc;
   }
-  const int dt = m->dtype;
+  const int dt = w.dtype;
   const void* hres = w.h16 ? (const void*)w.h16 : (const void*)w.h;      // the residual stream as the 16-bit LayerNorms read it
   const int hres_f16 = w.h16 ? 1 : 0;
   const int epi_resid = w.h16 ? EPI_H_BIAS_RESID_H16 : EPI_H_BIAS_RESID_F32;

@@ -39,6 +39,18 @@ def get_model(num_layers, seed, dev, compute_dtype="float32"):
     return _MODELS[key]
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _split_precision_on_small_calls():
+    """By default a model in compute dtype "float32x2" runs calls below 4 096 token rows on the exact-fp32 kernels (tuning key 17: the
+    few-token forms of the fp32 path are faster there).  The fixtures of this file ARE small: force the split-precision kernels so that
+    they are what is tested (ragged row counts, one-tile launches); test_x2_small_calls_fall_back_to_exact_fp32 covers the default."""
+    from rap_amd import _lib as _l
+    lib = _l.load()
+    assert lib.rap_set_tuning(17, 0) == 0
+    yield
+    assert lib.rap_set_tuning(17, 4096) == 0
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available()

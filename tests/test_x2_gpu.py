@@ -21,6 +21,18 @@ from rap_amd.flow_model import workspace
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _split_precision_on_small_calls():
+    """By default a model in compute dtype "float32x2" runs calls below 4 096 token rows on the exact-fp32 kernels (tuning key 17: the
+    few-token forms of the fp32 path are faster there).  The fixtures of this file ARE small: force the split-precision kernels so that
+    they are what is tested (ragged row counts, one-tile launches); test_x2_small_calls_fall_back_to_exact_fp32 covers the default."""
+    from rap_amd import _lib as _l
+    lib = _l.load()
+    assert lib.rap_set_tuning(17, 0) == 0
+    yield
+    assert lib.rap_set_tuning(17, 4096) == 0
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
@@ -394,3 +406,35 @@ def test_x2_model_forward_is_deterministic_and_close_to_exact_fp32(dev):
     ex2 = float((outs["float32x2"]["velocity"].cpu().double() - ref).abs().max())
     print(f"velocity vs fp64 oracle: exact-fp32 path {e32:.2e}, split precision {ex2:.2e} (max|v| {float(ref.abs().max()):.2f})")
     assert ex2 < 2e-5 and ex2 < 10 * max(e32, 2e-7), (ex2, e32)
+
+
+def test_x2_small_calls_fall_back_to_exact_fp32(lib, dev):
+    """Tuning key 17 (default 4 096 token rows): a SMALL call of a split-precision model runs the exact-fp32 kernels -- both are
+    fp32-accurate, and below a few thousand tokens the fp32 path's few-token forms are faster (configs[0] geometry: 48 vs 53 ms).  With the
+    default the result is bit-identical to compute_dtype="float32"; forced (key 17 = 0) it is the split kernels' (different bits, same
+    accuracy class); a call above the threshold takes the split kernels whatever the key says."""
+    import rap_amd
+    from rap_amd import synthetic as S
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    sd = S.make_weights(cfg, 3)
+
+    def run(mode, inp):
+        m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=2, num_heads=8, local_feat_dim=32, compute_dtype=mode)
+        m.load_state_dict(sd); m.to(dev)
+        flow = rap_amd.RectifiedPointFlow(flow_model=m, inference_sampling_steps=2, rigidity_forcing=True)
+        d = {k: v.to(dev) for k, v in inp.items()}
+        return flow.sample_and_register(d, x_1=d["x_1"])["end_point_trajectory"]
+
+    small = S.make_inputs([[700, 650]], seed=5)                   # 1 350 tokens -> 1 536 rows < 4 096
+    big = S.make_inputs([[2500, 2400]], seed=6)                   # 4 900 tokens -> 5 120 rows
+    ref_small, ref_big = run("float32", small), run("float32", big)
+    try:
+        assert lib.rap_set_tuning(17, 4096) == 0
+        assert torch.equal(run("float32x2", small), ref_small)                       # the fp32 kernels ran
+        xb = run("float32x2", big)
+        assert not torch.equal(xb, ref_big) and float((xb - ref_big).abs().max()) < 2e-5   # the split kernels ran: fp32-accurate, other bits
+        assert lib.rap_set_tuning(17, 0) == 0
+        xs = run("float32x2", small)
+        assert not torch.equal(xs, ref_small) and float((xs - ref_small).abs().max()) < 2e-5
+    finally:
+        assert lib.rap_set_tuning(17, 0) == 0                     # (this module's fixture restores the default at the end)
