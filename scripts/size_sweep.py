@@ -19,8 +19,12 @@ from rap_amd import synthetic as S
 dev = torch.device("cuda:0")
 cfg = dict(S.RAP_12)
 sd = S.make_weights(cfg, 0)
-sizes = [int(x) for x in sys.argv[1:]] or [1000, 2000, 4000, 8000, 16000, 32000]
-for dtype in ("float32", "bfloat16"):
+sizes = [int(x) for x in sys.argv[1:] if not x.startswith("--")] or [1000, 2000, 4000, 8000, 16000, 32000]
+modes = [a.split("=", 1)[1].split(",") for a in sys.argv[1:] if a.startswith("--modes=")]
+if "--x2-forced" in sys.argv:          # split precision at EVERY size (default: calls below 4 096 token rows run the exact-fp32 kernels)
+    from rap_amd import _lib
+    assert _lib.load().rap_set_tuning(17, 0) == 0
+for dtype in (modes[0] if modes else ("float32", "bfloat16")):
     m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=12, num_heads=8, local_feat_dim=32, attn_dtype=dtype, compute_dtype=dtype)
     m.load_state_dict(sd); m.to(dev)
     flow = rap_amd.RectifiedPointFlow(flow_model=m, inference_sampling_steps=20, rigidity_forcing=True)
