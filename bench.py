@@ -228,6 +228,9 @@ def cpu_baseline(cfg, sd, args, gpu_first_step, full=False):
     return out, err
 
 
+_CHECKER_CACHE: dict = {}
+
+
 def device_checker_last_pair(cfg, sd, args, last, inp_cpu, dev):
     """The LAST pair of the timed batch vs the pinned oracle run on this GPU in fp32 through PyTorch-ROCm (test infrastructure)."""
     from oracle import rap_oracle as O
@@ -237,7 +240,10 @@ def device_checker_last_pair(cfg, sd, args, last, inp_cpu, dev):
     n = args.views * args.points
     a0 = b * n
     assert torch.equal(one["pointclouds"], inp_cpu["pointclouds"][a0:a0 + n]) and torch.equal(one["x_1"], inp_cpu["x_1"][a0:a0 + n])
-    ref = O.sample(sd, cfg, one, args.flow_steps, bool(args.rigidity), device=dev)
+    key = (b, n, args.flow_steps, bool(args.rigidity))
+    if _CHECKER_CACHE.get("key") != key:          # the checker's result for this pair is computed once per run (the split-precision leg reuses it)
+        _CHECKER_CACHE["key"], _CHECKER_CACHE["ref"] = key, O.sample(sd, cfg, one, args.flow_steps, bool(args.rigidity), device=dev)
+    ref = _CHECKER_CACHE["ref"]
     ep = last["end_point_trajectory"][:, a0:a0 + n]; tr = last["trajectory"][:, a0:a0 + n]
     per_step = (ep - ref["end_point_trajectory"]).abs().amax(dim=(1, 2))
     return {"pair": b, "checker": "oracle/rap_oracle.py sample(device=cuda), fp32 torch ops (pinned: tests/test_fullconfig_gpu.py)",
@@ -725,10 +731,10 @@ def main():
                   "algorithmic_tflop_per_call": rflops / 1e12, "uniform_algorithmic_tflop_per_call": uniform_call_flops / 1e12}
         for dt_name, k_steps in ((args.dtype, 1),) + ((("float32x2", 1), ("bfloat16", 2)) if args.dtype == "float32" and not args.no_secondary else ()):
             # fp32: no warm-up call (34 s each at this size; the instrumented call after the timed one has the workspace warm)
-            er, pr, lr = run_mode(dt_name, k_steps, 0 if dt_name == "float32" else 1, data=rdata, x_1=rdata["x_1"])
+            er, pr, lr = run_mode(dt_name, k_steps, 1 if dt_name == "bfloat16" else 0, data=rdata, x_1=rdata["x_1"])
             finite = bool(torch.isfinite(lr["end_point_trajectory"][-1]).all() and torch.isfinite(lr["R"]).all())
             ragged[DTYPE_TAG[dt_name]] = {
-                "points_per_s": rpts * k_steps / er, "ms_per_step": 1e3 * er / k_steps, "steps": k_steps, "warmup": 0 if dt_name == "float32" else 1,
+                "points_per_s": rpts * k_steps / er, "ms_per_step": 1e3 * er / k_steps, "steps": k_steps, "warmup": 1 if dt_name == "bfloat16" else 0,
                 "achieved_tflops_whole_call": rflops * k_steps / er / 1e12, "results_finite": finite,
                 "roofline": roofline_of(dt_name, pr, run_mode.prof_region_s, parts=rparts)}
             del lr
@@ -740,9 +746,9 @@ def main():
         online = {"gamma_scale": args.gamma_scale,
                   "what": "same batch, MultiHeadRMSNorm gains of the seeded weights multiplied by gamma_scale: every logit bound "
                           "8 max|gamma_q| max|gamma_k| exceeds 40, so every attention launch takes the online-softmax kernel "
-                          "(what a trained checkpoint with large gains runs); 1 warm-up + 1 timed sample call"}
+                          "(what a trained checkpoint with large gains runs); 1 timed sample call (+ 1 warm-up in bf16)"}
         for dt_name in ([args.dtype] if (args.dtype != "float32" or args.no_secondary) else ["float32", "bfloat16"]):
-            eo, po, lo = run_mode(dt_name, 1, 1, gamma_scale=args.gamma_scale)
+            eo, po, lo = run_mode(dt_name, 1, 0 if dt_name == "float32" else 1, gamma_scale=args.gamma_scale)      # (fp32: 16 s per call -- the workspace is warm already)
             ro = roofline_of(dt_name, po, run_mode.prof_region_s, bounded=False)
             if run_mode.bounded_launches != 0:
                 raise SystemExit(f"gamma scale {args.gamma_scale}: {run_mode.bounded_launches} launches still bounded")

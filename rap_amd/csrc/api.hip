@@ -156,9 +156,10 @@ rap_tuning_t g_rap_attn_lpt = 1;               // tuning key 15: attention work 
 // tuning key 17: split precision takes over from this many token rows (align_up(TP, 256)) per call; SMALLER calls of a model in compute
 // dtype 3 run the exact-fp32 kernels -- both are fp32-accurate, and below a few thousand tokens every kernel of a layer sits at the launch
 // floor, where the fp32 path's few-token forms (128 x 128 tiles, split-K, split-KV) are the faster ones (r05 call 3: configs[0] geometry,
-// one pair of 2 x 1024 points: 48.3 ms fp32 vs 52.6 ms on the 256 x 256-tile split kernels).  The two layouts need the same workspace
+// one pair of 2 x 1024 points: 48.3 ms fp32 vs 52.6 ms on the 256 x 256-tile split kernels; call 4, one sample of 8 views, 20 steps:
+// 1 024 tokens 71 vs 89 ms, 2 048: 92 vs 99, 4 096: 197 vs 124, 8 000: 459 vs 197 -- the crossover lies between 2 048 and 4 096).  The two layouts need the same workspace
 // bytes (two 16-bit planes per value = one fp32).
-rap_tuning_t g_rap_x2_min_rows = 4096;
+rap_tuning_t g_rap_x2_min_rows = 3072;
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 // Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
 // fp32 summation order -- 5 split-KV for few-token calls (fp32 attention), 6 split-K for few-row calls (fp32 GEMMs and the 16-bit
@@ -456,6 +457,7 @@ struct Workspace {
   int vt_nblk;
   int rows;                             // TQ = align_up(TP, 256): rows of every token-row buffer
   int dtype;                            // the arithmetic this call runs in (eff_dtype: the model's, or fp32 for a small split-precision call)
+  bool qk_norm;                         // snapshot of the model's switch (the configuration mutex is held only while the layout is carved)
   double* proc_partials;
   int32_t *token_sample, *part_offsets, *attn_sort;
   int32_t *cu_batch_s, *cu_part_s;      // sanitised copies of the caller's segment tables (clamped to [0, TP], non-decreasing)
@@ -476,6 +478,7 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   const size_t T = align_up((size_t)TP, 256);
   w.rows = (int)T;
   const int dtype = w.dtype = eff_dtype(m, T);
+  w.qk_norm = m->qk_norm;
   w.base = (float*)take(T * d * 4);
   const bool x2 = dtype == RAP_DT_F32X2;    // split precision: fp32 residual stream, every 16-bit activation buffer holds heads AND tails
   const bool h16 = dtype != RAP_DT_F32 && !x2 && m->resid_dtype == RAP_DT_F16;
@@ -622,7 +625,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         GemmParamsH g{};
         g.A = w.xnh; g.lda = 2 * d; g.W = lh.Wqkv[a]; g.ldw = 2 * d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = 2 * d; g.heads = H;
         g.vt = w.vth; g.vt_nblk = w.vt_nblk; g.q_mul = 8.0f; g.acc_scale = lh.s_qkv[a];
-        if (m->qk_norm) { g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; }      // null gains: the epilogue splits q / k as projected
+        if (w.qk_norm) { g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; }      // null gains: the epilogue splits q / k as projected
         { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV_NORM, g); }
         if (rc) return rc;
         {
@@ -661,13 +664,13 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         GemmParamsH g{};
         g.A = w.xnh; g.lda = d; g.W = lh.Wqkv[a]; g.ldw = d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
         g.vt = w.vth; g.vt_nblk = w.vt_nblk;
-        const bool bnd = m->qk_norm && m->bounded[j] != 0;                // this launch's softmax kernel (per layer and branch)
+        const bool bnd = w.qk_norm && m->bounded[j] != 0;                // this launch's softmax kernel (per layer and branch)
         const bool prescale = attention_h16_wants_prescaled_q(dt, bnd);
         // few-token calls (fewer 256 x 256 tiles than CUs): the 128 x 128 kernel fills the chip better than the fused epilogue's 256 x 256
         // tiles save (it exists only in the phase-split kernels), so the projection and qk-norm run as two kernels there
         // (r03 call 32: one pair of 2 x 1024 points, 10 steps, bf16: 21.3 -> 18.5 ms; at 2 x 4096 -- 192 tiles -- the fused form is still ahead)
         const bool few_tiles = (long)((TP + 255) / 256) * (3 * d / 256) < 128;
-        if (g_rap_fuse_qknorm && !few_tiles && m->qk_norm) {
+        if (g_rap_fuse_qknorm && !few_tiles && w.qk_norm) {
           // qk-norm in the QKV epilogue: one kernel, q / k normalised from the fp32 accumulators (no 16-bit round trip through HBM)
           g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; g.q_mul = prescale ? RAP_QMUL_PRESCALED : 8.0f;
           { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV_NORM, g); }
@@ -675,7 +678,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         } else {
           { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV, g); }
           if (rc) return rc;
-          if (m->qk_norm && (rc = launch_qknorm_h16(stream, dt, w.qkh, TP, H, lw.gq[a], lw.gk[a], prescale ? RAP_QMUL_PRESCALED : 8.0f))) return rc;
+          if (w.qk_norm && (rc = launch_qknorm_h16(stream, dt, w.qkh, TP, H, lw.gq[a], lw.gk[a], prescale ? RAP_QMUL_PRESCALED : 8.0f))) return rc;
         }
         {
           ProfScope ps(stream, a);
@@ -713,14 +716,14 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       if (rc) return rc;
       GemmParams g{};
       g.A = w.xn; g.lda = d; g.W = lw.Wqkv[a]; g.ldw = d; g.C = w.qkv; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
-      const bool fuse_qk = g_rap_fuse_qknorm != 0 && m->qk_norm;
+      const bool fuse_qk = g_rap_fuse_qknorm != 0 && w.qk_norm;
       if (fuse_qk) { g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; }        // qk-norm in the QKV epilogue (tuning key 7)
       { ProfScope ps(stream, 2); rc = launch_gemm_f32(stream, EPI_QKV_HEADMAJOR, g); }
       if (rc) return rc;
-      if (!fuse_qk && m->qk_norm && (rc = launch_qknorm(stream, w.qkv, TP, H, lw.gq[a], lw.gk[a]))) return rc;
+      if (!fuse_qk && w.qk_norm && (rc = launch_qknorm(stream, w.qkv, TP, H, lw.gq[a], lw.gk[a]))) return rc;
       {
         ProfScope ps(stream, a);
-        const float* bound = (m->qk_norm && m->bounded[j]) ? m->logit_bound + (size_t)j * H : nullptr;
+        const float* bound = (w.qk_norm && m->bounded[j]) ? m->logit_bound + (size_t)j * H : nullptr;
         // few-token calls: split the keys of every work item over up to 4 blocks; the partial O planes live in the (idle) FFN
         // buffer (4 x TP x d floats), the partial row sums in the (idle) LN-output buffer
         const int max_items = a == 0 ? w.max_items_part : w.max_items_batch;
@@ -785,8 +788,10 @@ extern "C" int rap_dit_forward(const rap_model* m, const float* x_t, const float
   if (B <= 0 || VP < 0 || TP < 0 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
   if (TP == 0) return RAP_OK;
   if (!ws) return RAP_ERR_WORKSPACE;
-  std::lock_guard<std::mutex> lock(m->cfg_mu);
-  Workspace w = carve_workspace(m, TP, B, VP, B, (char*)ws);
+  // the configuration (compute / residual dtype, qk_norm) is snapshotted into the workspace descriptor under the model's mutex; the enqueue
+  // itself runs unlocked, so threads sharing a model do not serialise on a (possibly queue-bound) enqueue
+  Workspace w;
+  { std::lock_guard<std::mutex> lock(m->cfg_mu); w = carve_workspace(m, TP, B, VP, B, (char*)ws); }
   if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
@@ -883,8 +888,8 @@ extern "C" int rap_sample(const rap_model* m, const float* cond, const float* fe
   if (B <= 0 || P <= 0 || TP <= 0 || num_steps <= 0 || TP > 0x7fffffffLL / 8 || (int64_t)B * P > 65535) return RAP_ERR_INVALID;
   const int np = B * P;
   if (!ws) return RAP_ERR_WORKSPACE;
-  std::lock_guard<std::mutex> lock(m->cfg_mu);
-  Workspace w = carve_workspace(m, TP, B, np, num_steps, (char*)ws);
+  Workspace w;
+  { std::lock_guard<std::mutex> lock(m->cfg_mu); w = carve_workspace(m, TP, B, np, num_steps, (char*)ws); }      // see rap_dit_forward
   if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const int T = (int)TP;

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f32_kernel(const float* 
 // sort_ws: nseg ints; nullptr = segment order (kernel-level entry points without scratch).
 #define WL_THREADS 1024
 #define WL_TILE 4096
+#define WL_SORT_MAX 8192
 // a segment's length as every stage of the kernel sees it: never negative (a decreasing table -- reachable through the kernel-level
 // entry point, or under deferred validation before round 5 sanitised the tables -- made the item count negative)
 __device__ __forceinline__ int wl_len(const int32_t* __restrict__ cu, int s) { const int l = cu[s + 1] - cu[s]; return l > 0 ? l : 0; }
@@ -360,7 +361,12 @@ __global__ __launch_bounds__(WL_THREADS) void build_attn_worklist_kernel(const i
   __shared__ int partial[WL_THREADS];
   __shared__ int total_items;
   int32_t* order = sort_ws;            // [nseg]
-  // ---- ranks
+  // ---- ranks.  O(nseg^2 / 1024) compares per thread on ONE CU: fine for the hundreds of parts of a real batch, ~4 M per thread at the
+  // 65 535-part limit (milliseconds at the head of every call) -- above WL_SORT_MAX segments the items are emitted in
+  // segment order by the same parallel scan (such batches consist of many short segments: there is no long tail to hide)
+  if (nseg > WL_SORT_MAX) {
+    for (int s = tid; s < nseg; s += WL_THREADS) order[s] = s;
+  } else
   for (int s0 = 0; s0 < nseg; s0 += WL_THREADS) {          // segments owned by this thread in this pass: s0 + tid
     const int s = s0 + tid;
     const int my = s < nseg ? wl_len(cu, s) : -1;

@@ -47,6 +47,17 @@ __device__ __forceinline__ float gelu_erf_fast(float g) {
 // transposes its tile through a private LDS slab `stg` (the operand buffers are dead by now; the caller has
 // synchronised the block) and writes whole rows with 16-byte stores; the fp32 residual is read the same way.
 #define H16_STG_BYTES (64 * 144)   // largest slab: the V^T image of 64 tokens (64 d rows of 144 bytes)
+// RAP_MUTATION (scripts/mutation_check.sh only, never in the shipped library): a deliberately injected extra rounding to the OPERAND type
+// in the residual epilogues -- 1: of the epilogue's result (the new residual-stream value), 2: of the GEMM output before the residual is
+// added -- to show that the tightened 16-bit deviation bounds of the test-suite notice a precision regression.
+#ifdef RAP_MUTATION
+template <int DT> __device__ __forceinline__ float rap_mut_round(float x) { return h16_to_f32<DT>(h16_from_f32<DT>(x)); }
+#define RAP_MUT_OUT(DT, x) (RAP_MUTATION == 2 ? rap_mut_round<DT>(x) : (x))
+#define RAP_MUT_SUM(DT, x) (RAP_MUTATION == 1 ? rap_mut_round<DT>(x) : (x))
+#else
+#define RAP_MUT_OUT(DT, x) (x)
+#define RAP_MUT_SUM(DT, x) (x)
+#endif
 template <int EPI, int DT, int TM>
 __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (&acc)[TM][2], unsigned char* stg, int mw, int nw,
                                                   int lane) {
@@ -102,14 +113,15 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        sf[mfma32_crow(r, hi) * 64 + l31] = acc[i][0][r] + b0;
-        sf[mfma32_crow(r, hi) * 64 + 32 + l31] = acc[i][1][r] + b1;
+        sf[mfma32_crow(r, hi) * 64 + l31] = RAP_MUT_OUT(DT, acc[i][0][r] + b0);
+        sf[mfma32_crow(r, hi) * 64 + 32 + l31] = RAP_MUT_OUT(DT, acc[i][1][r] + b1);
       }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int row = it * 4 + (lane >> 4), col = (lane & 15) * 4;
         float4 v = *reinterpret_cast<const float4*>(sf + row * 64 + col);
         if (p.resid) { v.x += rr[it].x; v.y += rr[it].y; v.z += rr[it].z; v.w += rr[it].w; }
+        v.x = RAP_MUT_SUM(DT, v.x); v.y = RAP_MUT_SUM(DT, v.y); v.z = RAP_MUT_SUM(DT, v.z); v.w = RAP_MUT_SUM(DT, v.w);
         const int m = mw + i * 32 + row;
         if (m < p.M) *reinterpret_cast<float4*>(C + (size_t)m * p.ldc + nw + col) = v;
       }
@@ -145,8 +157,8 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        sf[mfma32_crow(r, hi) * 68 + l31] = acc[i][0][r] + b0;
-        sf[mfma32_crow(r, hi) * 68 + 32 + l31] = acc[i][1][r] + b1;
+        sf[mfma32_crow(r, hi) * 68 + l31] = RAP_MUT_OUT(DT, acc[i][0][r] + b0);
+        sf[mfma32_crow(r, hi) * 68 + 32 + l31] = RAP_MUT_OUT(DT, acc[i][1][r] + b1);
       }
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -155,8 +167,9 @@ __device__ __forceinline__ void gemm_h16_epilogue(const GemmParamsH& p, f32x16 (
         const float4 a1 = *reinterpret_cast<const float4*>(sf + row * 68 + col + 4);
         float rv[8];
         h16_unpack8<RAP_DT_F16>(rr[i][it], rv);
-        const typename H16<RAP_DT_F16>::T8 o8 = f16_pack8_sat(a0.x + rv[0], a0.y + rv[1], a0.z + rv[2], a0.w + rv[3],
-                                                             a1.x + rv[4], a1.y + rv[5], a1.z + rv[6], a1.w + rv[7]);
+        const typename H16<RAP_DT_F16>::T8 o8 = f16_pack8_sat(RAP_MUT_SUM(DT, a0.x + rv[0]), RAP_MUT_SUM(DT, a0.y + rv[1]), RAP_MUT_SUM(DT, a0.z + rv[2]),
+                                                             RAP_MUT_SUM(DT, a0.w + rv[3]), RAP_MUT_SUM(DT, a1.x + rv[4]), RAP_MUT_SUM(DT, a1.y + rv[5]),
+                                                             RAP_MUT_SUM(DT, a1.z + rv[6]), RAP_MUT_SUM(DT, a1.w + rv[7]));
         const int m = mw + i * 32 + row;
         if (m < p.M) *reinterpret_cast<uint4*>(C + (size_t)m * p.ldc + nw + col) = __builtin_bit_cast(uint4, o8);
       }
@@ -453,7 +466,10 @@ __device__ __forceinline__ void gemm_x2_qknorm_epilogue(const GemmParamsH& p, f3
   }
 }
 
-template <int EPI, int DT, int WM, int WN, int TM, int TN>
+// X2 (round 5, the residual GEMMs of few-token split-precision calls): the paired-operand product of the phase-split kernels (three MFMAs
+// per fragment pair, see gemm_h16_ph_kernel) on this kernel's 128 x 128 tiles -- the four fragment sets of a k-tile (head k-steps 0, 1 and
+// tail k-steps 0, 1) are read, then the six kept products issue.
+template <int EPI, int DT, int WM, int WN, int TM, int TN, bool X2 = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16_kernel(GemmParamsH p) {
   typedef typename H16<DT>::T8 T8;
   constexpr int NT = 64 * WM * WN;
@@ -556,6 +572,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
 
   HG_DMA(0, 0)
   HG_SYNC
+  if constexpr (X2) {
+    Frag f[4];
+    auto mma2 = [&](const Frag& fa_, const Frag& fb_) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, fa_.a[i]), __builtin_bit_cast(T8, fb_.b[j]), acc[i][j]);
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) { HG_DMA(kt + 1, cur ^ 1) }     // spare buffer: every wave finished reading it before the last barrier
+#pragma unroll
+      for (int g = 0; g < 4; ++g) read_frag(f[g], cur, g);
+      mma2(f[2], f[0]); mma2(f[0], f[2]); mma2(f[3], f[1]); mma2(f[1], f[3]);      // (tail, head), (head, tail) of both k-steps
+      mma2(f[0], f[0]); mma2(f[1], f[1]);                                          // (head, head)
+      HG_SYNC
+    }
+    static_assert(!X2 || EPI == EPI_H_BIAS_RESID_F32, "the 128 x 128 split-precision kernel serves the residual GEMMs");
+    gemm_x2_epilogue<EPI, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
+    return;
+  }
   read_frag(f0, 0, 0);
 
   int kt = 0;
@@ -1099,11 +1137,11 @@ static int launch_php(hipStream_t stream, const GemmParamsH& p) {
 rap_tuning_t g_rap_gemm_h16_variant = 14;
 rap_tuning_t g_rap_gemm_h16_persistent = 1;     // tuning key 11: the persistent phase-split kernel for full-tile shapes (1, default) or one tile per block (0)
 
-template <int EPI, int DT, int WM, int WN, int TM, int TN>
+template <int EPI, int DT, int WM, int WN, int TM, int TN, bool X2 = false>
 static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int LDS = 2 * (BM + BN) * 128;
-  auto kern = gemm_h16_kernel<EPI, DT, WM, WN, TM, TN>;
+  auto kern = gemm_h16_kernel<EPI, DT, WM, WN, TM, TN, X2>;
   // per device and cheap: set unconditionally (a process may drive several GPUs)
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
     rap_set_last_hip_error((int)hipGetLastError());
@@ -1256,7 +1294,11 @@ static int launch_x2_variant(hipStream_t stream, const GemmParamsH& p) {
 static int launch_x2(hipStream_t stream, int epilogue, const GemmParamsH& p) {
   if (p.N % 256 != 0 || p.K < 128 || p.K % 64 != 0) return RAP_ERR_INVALID;
   switch (epilogue) {
-    case EPI_H_BIAS_RESID_F32: return launch_x2_variant<EPI_H_BIAS_RESID_F32>(stream, p);
+    case EPI_H_BIAS_RESID_F32:
+      // fewer 256 x 256 tiles than CUs (the N = 512 residual GEMMs below ~32 k tokens: 64 tiles at 8 000 tokens): 128 x 128 tiles, two
+      // blocks per CU, fill the chip four times better
+      if ((long)((p.M + 255) / 256) * (p.N / 256) < 256) return launch_cfg<EPI_H_BIAS_RESID_F32, RAP_DT_F16, 2, 2, 2, 2, true>(stream, p);
+      return launch_x2_variant<EPI_H_BIAS_RESID_F32>(stream, p);
     case EPI_H_GEGLU:
       if (p.ldc & 7) return RAP_ERR_INVALID;
       return launch_x2_variant<EPI_H_GEGLU>(stream, p);

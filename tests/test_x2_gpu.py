@@ -23,14 +23,14 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, scope="module")
 def _split_precision_on_small_calls():
-    """By default a model in compute dtype "float32x2" runs calls below 4 096 token rows on the exact-fp32 kernels (tuning key 17: the
+    """By default a model in compute dtype "float32x2" runs calls below 3 072 token rows on the exact-fp32 kernels (tuning key 17: the
     few-token forms of the fp32 path are faster there).  The fixtures of this file ARE small: force the split-precision kernels so that
     they are what is tested (ragged row counts, one-tile launches); test_x2_small_calls_fall_back_to_exact_fp32 covers the default."""
     from rap_amd import _lib as _l
     lib = _l.load()
     assert lib.rap_set_tuning(17, 0) == 0
     yield
-    assert lib.rap_set_tuning(17, 4096) == 0
+    assert lib.rap_set_tuning(17, 3072) == 0
 
 
 @pytest.fixture(scope="module")
@@ -141,8 +141,9 @@ def test_pack_is_head_plus_tail_in_the_paired_layout(lib, dev):
 # ---------------------------------------------------------------------------------------------
 # GEMMs
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(300, 512, 512), (1024, 512, 2048), (256, 256, 64), (65536, 512, 512), (131072, 256, 128)],
-                         ids=["ragged-M", "ff2-shape", "one-k-tile-pair", "persistent-512-tiles", "persistent-short-K"])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 512), (1024, 512, 2048), (256, 256, 64), (40001, 512, 512), (65536, 512, 512), (131072, 256, 128)],
+                         ids=["ragged-M-128x128", "ff2-shape-128x128", "one-k-tile-pair", "ragged-M-one-256x256-tile-per-block", "persistent-512-tiles",
+                              "persistent-short-K"])
 def test_x2_gemm_residual_epilogue_is_fp32_accurate(lib, dev, M, N, K):
     """C = resid + A W^T + bias (out-projection / ff2 form) on paired operands with a scaled weight plane, against fp64 on the original
     fp32 operands; torch's own fp32 matmul on the same operands is the yardstick."""
@@ -409,7 +410,7 @@ def test_x2_model_forward_is_deterministic_and_close_to_exact_fp32(dev):
 
 
 def test_x2_small_calls_fall_back_to_exact_fp32(lib, dev):
-    """Tuning key 17 (default 4 096 token rows): a SMALL call of a split-precision model runs the exact-fp32 kernels -- both are
+    """Tuning key 17 (default 3 072 token rows): a SMALL call of a split-precision model runs the exact-fp32 kernels -- both are
     fp32-accurate, and below a few thousand tokens the fp32 path's few-token forms are faster (configs[0] geometry: 48 vs 53 ms).  With the
     default the result is bit-identical to compute_dtype="float32"; forced (key 17 = 0) it is the split kernels' (different bits, same
     accuracy class); a call above the threshold takes the split kernels whatever the key says."""
@@ -429,7 +430,7 @@ def test_x2_small_calls_fall_back_to_exact_fp32(lib, dev):
     big = S.make_inputs([[2500, 2400]], seed=6)                   # 4 900 tokens -> 5 120 rows
     ref_small, ref_big = run("float32", small), run("float32", big)
     try:
-        assert lib.rap_set_tuning(17, 4096) == 0
+        assert lib.rap_set_tuning(17, 3072) == 0
         assert torch.equal(run("float32x2", small), ref_small)                       # the fp32 kernels ran
         xb = run("float32x2", big)
         assert not torch.equal(xb, ref_big) and float((xb - ref_big).abs().max()) < 2e-5   # the split kernels ran: fp32-accurate, other bits
