@@ -138,7 +138,7 @@ def test_fp32_all_steps_match_the_reference(name, dtype, dev):
 TOL16 = {
     ("headline_c1_rigid", "bfloat16"): (1.6e-3, 4e-3, 1e-3), ("headline_c1_rigid", "float16"): (7e-4, 1.3e-3, 2.3e-4),
     ("headline_c3_rigid", "bfloat16"): (6e-3, 1.5e-2, 1.3e-3), ("headline_c3_rigid", "float16"): (2.1e-3, 5.6e-3, 3e-4),
-    ("headline_c2_rank1", "bfloat16"): (5.7e-3, 7.6e-3, 1.9e-3), ("headline_c2_rank1", "float16"): (7.3e-4, 9e-4, 1.5e-4),
+    ("headline_c2_rank1", "bfloat16"): (4.3e-3, 5.8e-3, 1.5e-3), ("headline_c2_rank1", "float16"): (7.3e-4, 9e-4, 1.5e-4),
     ("headline_c1_ragged", "bfloat16"): (9e-3, 2.2e-2, 2.5e-3), ("headline_c1_ragged", "float16"): (4.6e-4, 9e-4, 2.5e-4),
     ("headline_c1_rap16", "bfloat16"): (4.4e-3, 7.5e-3, 3.3e-3), ("headline_c1_rap16", "float16"): (2.5e-4, 1.6e-4, 1.9e-4),
     ("headline_c4_steps", "bfloat16"): (3.7e-3, 5.8e-3, 1.7e-3), ("headline_c4_steps", "float16"): (5e-4, 6e-4, 2e-4),
