@@ -538,9 +538,16 @@ def main():
             _lib.check(lib.rap_profile_collect_ex(prof_ms, prof_n, PROF_CLASSES), "rap_profile_collect_ex")
             if n_streams == 1:
                 run_mode.instrumented_over_clean = run_mode.prof_region_s / (local_elapsed / steps)
-        # the first timed call starts on an idle queue (barrier above) and carries no event records since round 5: it IS the
-        # "un-profiled call on an idle device" round 4 spent an extra call on
-        run_mode.host_idle_unprofiled_ms = run_mode.host_first_enqueue_ms if (idle_probe and not distributed) else None
+        run_mode.host_idle_unprofiled_ms = None
+        if idle_probe and not distributed:
+            # one extra call on an idle device after everything above: what a call costs the host once the process is warm and the HIP
+            # queue is empty (~2 900 launches; the call path has no synchronisation).  The FIRST timed call is not that figure: it follows
+            # the warm-up calls, during which the host ran a full call ahead of the GPU, and reads 0.5-2.6 s for the fp32 batch.
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            one_step()
+            run_mode.host_idle_unprofiled_ms = 1e3 * (time.perf_counter() - tq)
+            torch.cuda.synchronize()
         if distributed:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

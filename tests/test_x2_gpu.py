@@ -439,3 +439,26 @@ def test_x2_small_calls_fall_back_to_exact_fp32(lib, dev):
         assert not torch.equal(xs, ref_small) and float((xs - ref_small).abs().max()) < 2e-5
     finally:
         assert lib.rap_set_tuning(17, 0) == 0                     # (this module's fixture restores the default at the end)
+
+
+def test_x2_graph_replay_and_concurrent_shards_equal_the_eager_call(lib, dev):
+    """The split-precision call never synchronises or allocates inside the library either: it replays as one HIP graph and runs as
+    concurrent batch shards on several streams (own workspace per stream) with bit-identical results."""
+    import rap_amd
+    from rap_amd import synthetic as S
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    sd = S.make_weights(cfg, 3)
+    m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=2, num_heads=8, local_feat_dim=32, compute_dtype="float32x2")
+    m.load_state_dict(sd); m.to(dev)
+    kw = dict(flow_model=m, inference_sampling_steps=3, rigidity_forcing=True)
+    eager, graph, shards = rap_amd.RectifiedPointFlow(**kw), rap_amd.RectifiedPointFlow(graph_replay=True, **kw), rap_amd.RectifiedPointFlow(num_streams=2, **kw)
+    a = {k: v.to(dev) for k, v in S.make_inputs([[900, 1100], [1300, 700], [1000, 1000]], seed=1).items()}      # 6 000 tokens: the split kernels
+    b = {k: v.to(dev) for k, v in S.make_inputs([[900, 1100], [1300, 700], [1000, 1000]], seed=2).items()}
+    for src in (a, b, a):
+        want = eager.sample_and_register(src, x_1=src["x_1"])
+        got = graph.sample_and_register(src, x_1=src["x_1"])
+        par = shards.sample_and_register(src, x_1=src["x_1"])
+        for k in ("end_point_trajectory", "trajectory", "R", "t"):
+            assert torch.equal(got[k], want[k]), ("graph", k)
+            assert torch.equal(par[k], want[k]), ("shards", k)
+    assert len(graph._graphs) == 1
