@@ -442,8 +442,9 @@ def test_x2_small_calls_fall_back_to_exact_fp32(lib, dev):
 
 
 def test_x2_graph_replay_and_concurrent_shards_equal_the_eager_call(lib, dev):
-    """The split-precision call never synchronises or allocates inside the library either: it replays as one HIP graph and runs as
-    concurrent batch shards on several streams (own workspace per stream) with bit-identical results."""
+    """The split-precision call never synchronises or allocates inside the library either: it replays as one HIP graph (bit-identical) and
+    runs as concurrent batch shards on several streams, each with its own workspace (equal up to fp32 rounding: a shard is a smaller call, and
+    smaller calls may take other tile shapes / split-K in the fp32 embedding and head GEMMs -- as in tests/test_sample_gpu.py)."""
     import rap_amd
     from rap_amd import synthetic as S
     cfg = dict(S.RAP_12); cfg["num_layers"] = 2
@@ -460,5 +461,5 @@ def test_x2_graph_replay_and_concurrent_shards_equal_the_eager_call(lib, dev):
         par = shards.sample_and_register(src, x_1=src["x_1"])
         for k in ("end_point_trajectory", "trajectory", "R", "t"):
             assert torch.equal(got[k], want[k]), ("graph", k)
-            assert torch.equal(par[k], want[k]), ("shards", k)
+            assert float((par[k] - want[k]).abs().max()) < 2e-5, ("shards", k)
     assert len(graph._graphs) == 1
