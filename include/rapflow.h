@@ -356,7 +356,8 @@ int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t heads, const
  *     1  C fp32 (M,N) = resid + acc + bias (resid may be NULL / alias C);
  *     3  GEGLU on value/gate-interleaved W: C paired (M, ldc >= N) holds the N/2 outputs (h + bh) * gelu_erf(g + bg);
  *     5  QKV projection with MultiHeadRMSNorm fused (N = 3 * heads * 64): q, k -> C paired [2][heads][2 chunks][M][64 physical] (chunk c =
- *        head dims 32c .. 32c+31; q multiplied by q_mul, k by 8 as in rap_gemm_h16_qkvnorm), v -> vt paired
+ *        head dims 32c .. 32c+31; q multiplied by q_mul, k by 8 as in rap_gemm_h16_qkvnorm; gamma_q = gamma_k = NULL: no norm, q and k
+ *        leave as projected -- qk_norm = False), v -> vt paired
  *        [heads][vt_nblk][2 chunks][64 d][64 physical]: token t sits in block t >> 6, chunk (t >> 5) & 1, at in-chunk position
  *        p = (t & 19) | ((t & 4) << 1) | ((t & 8) >> 1) as head (column p) and tail (column 32 + p); vt_nblk * 64 >= M rounded up to 256.
  * rap_x2_attention: flash_attn_varlen_qkvpacked_func on those planes (online softmax in fp32): out paired (TP, 2 * heads * 64).
