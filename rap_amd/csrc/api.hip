@@ -508,7 +508,7 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
     w.astatic = (float*)w.ffmidh;
     // ff2: the one layer GEMM with K >= 1024.  Reserved by SHAPE alone (tuning key 6 only gates the launch), so that the size
     // rap_workspace_bytes reports cannot change between the query and the call
-    const int splits = x2 ? 1 : gemm_h16_splits_by_shape((int)T, (int)d, (int)(4 * d));     // (the split-precision GEMMs have no split-K form)
+    const int splits = gemm_h16_splits_by_shape((int)T, (int)d, (int)((x2 ? 8 : 4) * d));   // (split precision: the physical K of ff2 is 8 d)
     if (splits > 1) w.splitk_h = (float*)take((size_t)splits * T * d * 4);
   }
   w.ax = (float*)take(T * 64 * 4);
@@ -631,8 +631,12 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         if (rc) return rc;
         {
           ProfScope ps(stream, a);
-          rc = launch_attention_x2(stream, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch,
-                                   a == 0 ? w.max_items_part : w.max_items_batch);
+          // few-token calls: the keys of every work item over 2 / 4 blocks; the partial O planes (4 x TQ x d floats) live in the idle FFN
+          // buffer (16 TQ d bytes in this mode), the partial (max, row sum) pairs in the idle LayerNorm-output buffer
+          const int max_items = a == 0 ? w.max_items_part : w.max_items_batch;
+          const int splits = attention_x2_splits(max_items, H);
+          rc = launch_attention_x2(stream, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch, max_items,
+                                   reinterpret_cast<float*>(w.ffmidh), reinterpret_cast<float*>(w.xnh), splits, TP_valid);
         }
         if (rc) return rc;
         GemmParamsH o{};
@@ -651,6 +655,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       GemmParamsH f2{};
       f2.A = w.ffmidh; f2.lda = 8 * d; f2.W = lh.Wff2; f2.ldw = 8 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 8 * d;
       f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d; f2.acc_scale = lh.s_ff2;
+      f2.splitk_ws = w.splitk_h;               // few-token calls: the physical K = 8d split over 2 / 4 blocks per tile (null otherwise)
       { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, f2); }
       if (rc) return rc;
       continue;

@@ -42,10 +42,14 @@ __device__ __forceinline__ float x_max3(float a, float b, float c) {
 
 // WPE = waves per SIMD the register allocation aims at: 2 (144 VGPRs, one block per CU) or 4 (128 VGPRs and 5 spilled, two blocks per CU
 // -- the 64 KB of LDS allow both); tuning key 16 picks (A/B on the GPU: profiles/r05_*).
-template <int WPE>
+// SPLIT (few-token calls, round 5): gridDim.y blocks share the key tiles of a work item; each writes its UNNORMALISED partial O (fp32),
+// its running maximum and its row sum, and attention_x2_combine_kernel merges them (online-softmax partials: O = sum_y O_y 2^((m_y - m) c) /
+// sum_y l_y 2^((m_y - m) c)) and writes the head / tail planes.  One pair of 2 x 1024 points is 8 work items x 8 heads = 64 blocks for 256 CUs.
+template <int WPE, bool SPLIT = false>
 __global__ __launch_bounds__(512, WPE) void attention_x2_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt, int vt_nblk,
                                                               u16* __restrict__ out, int TP, int heads,
-                                                              const AttnWorkItem* __restrict__ items) {
+                                                              const AttnWorkItem* __restrict__ items, float* __restrict__ part_o,
+                                                              float* __restrict__ part_ml) {
   typedef x2_t8 T8;
   extern __shared__ __attribute__((aligned(1024))) u16 smem[];   // [2 stages][K c0 | K c1 | V c0 | V c1] = 64 KB; the 8 output slabs at the end
   const int tid = threadIdx.x;
@@ -83,8 +87,13 @@ __global__ __launch_bounds__(512, WPE) void attention_x2_kernel(const u16* __res
   float mrun = -1e30f, lsum = 0.f;
   const float c = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e)
 
-  const int b_first = seg0 >> 6;
-  const int ntile = ((seg1 - 1) >> 6) - b_first + 1;
+  const int b_first0 = seg0 >> 6;
+  const int ntile0 = ((seg1 - 1) >> 6) - b_first0 + 1;
+  // SPLIT: this block's share of the key tiles (an empty share leaves m = -1e30, l = 0, O = 0: weight 0 in the combine pass)
+  const int per = SPLIT ? (ntile0 + (int)gridDim.y - 1) / (int)gridDim.y : ntile0;
+  const int t_begin = SPLIT ? (int)blockIdx.y * per : 0;
+  const int b_first = b_first0 + t_begin;
+  const int ntile = SPLIT ? (ntile0 - t_begin < per ? ntile0 - t_begin : per) : ntile0;      // may be <= 0
   // ---- LDS-DMA: wave w stages rows 8w .. 8w+7 of each of the four sub-tiles; lane -> (row 8w + lane/8, physical slot lane%8)
   const int drow = wave * 8 + (lane >> 3);
   const int dls = ((lane & 7) ^ ((drow >> 1) & 7)) * 8;              // logical slot (in elements) this lane fetches
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(512, WPE) void attention_x2_kernel(const u16* __res
     XATT_DMA1(Vg + ((size_t)(2 * blk_ + 1) * 64 + drow) * 64 + dls, st_ + 3 * XSUB * 2)                       \
   }
 
-  XATT_DMA(0, 0)
+  if (ntile > 0) { XATT_DMA(0, 0) }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // the Q fragments have landed too -- tell the compiler (a use of every fragment), or it waits for them with vmcnt(n) inside the key
   // loop, where those waits would drain the DMA pieces of the NEXT tile it does not know about (attn_h16.hip)
@@ -220,6 +229,22 @@ __global__ __launch_bounds__(512, WPE) void attention_x2_kernel(const u16* __res
   }
 
   if (!wave_active) return;
+  if constexpr (SPLIT) {
+    // partial results of this key range: O^T unnormalised (relative to mrun), row-major (TP, heads * 64) fp32 per range; (m, l) per (token, head)
+    const int q = qw0 + l31;
+    if (q < len) {
+      const size_t tok = (size_t)blockIdx.y * TP + (size_t)(seg0 + q);
+      float* po = part_o + tok * ((size_t)heads * 64) + head * 64 + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(po + 8 * g) = float4{o0[4 * g + 0], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]};
+        *reinterpret_cast<float4*>(po + 32 + 8 * g) = float4{o1[4 * g + 0], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
+      }
+    }
+    const float lall = x_xhalf_sum(lsum);
+    if (q < len && hi == 0) *reinterpret_cast<float2*>(part_ml + (((size_t)blockIdx.y * TP + (size_t)(seg0 + q)) * heads + head) * 2) = float2{mrun, lall};
+    return;
+  }
   // ---- normalise, split and store.  Lane owns query l31; register r of tile e is head dim 32 e + crow(r, hi) (groups of 4 contiguous
   // dims), i.e. tile e IS chunk e of this head.  Every wave is past the last tile's barrier: the stages are free.  Slab of this wave:
   // [32 queries][72]: 32 heads | 32 tails of one chunk, written and drained once per chunk (LDS operations of a wave execute in order).
@@ -260,21 +285,79 @@ __global__ __launch_bounds__(512, WPE) void attention_x2_kernel(const u16* __res
 // faster either.  As for the bf16 kernel, every schedule lands on the same ~1.2 PFLOP/s of issued fp16 MFMA work: the
 // SQ counters (profiles/r05_c3_mfma_utilisation_x2.txt) show the clock the part sustains under this load, not the schedule, as the limit.
 rap_tuning_t g_rap_attn_x2_wpe = 2;      // tuning key 16: 2 / 4 = one / two blocks per CU
+extern rap_tuning_t g_rap_attn_split;    // attn_f32.hip, tuning key 5: split few-token attention launches over key ranges (1, default) or not (0)
 
+// one thread per (token, 8 consecutive head dims): merge the key-range partials, normalise, write the head / tail planes
+__global__ __launch_bounds__(256) void attention_x2_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                                   u16* __restrict__ out, int TP, int n_tokens, int heads, int splits) {
+  const int dmodel = heads * 64;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)n_tokens * (dmodel / 8)) return;
+  const long t = i / (dmodel / 8);
+  const int c = (int)(i % (dmodel / 8)) * 8;                  // logical column: head = c >> 6, dims (c & 63) .. +7 (inside one 32-dim chunk)
+  const int head = c >> 6;
+  const float cexp = 0.125f * 1.44269504088896340736f;
+  float m = -1e30f;
+  for (int s = 0; s < splits; ++s) m = fmaxf(m, part_ml[(((size_t)s * TP + t) * heads + head) * 2]);
+  float l = 0.f;
+  f32x8 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < splits; ++s) {
+    const float2 ml = *reinterpret_cast<const float2*>(part_ml + (((size_t)s * TP + t) * heads + head) * 2);
+    const float w = __builtin_amdgcn_exp2f((ml.x - m) * cexp);       // an empty range: m_y = -1e30 -> weight 0 (and l_y = 0, O_y = 0)
+    l += ml.y * w;
+    const float4 a0 = *reinterpret_cast<const float4*>(part_o + ((size_t)s * TP + t) * dmodel + c);
+    const float4 a1 = *reinterpret_cast<const float4*>(part_o + ((size_t)s * TP + t) * dmodel + c + 4);
+    acc += f32x8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w} * w;
+  }
+  const float inv = 1.0f / l;
+  x2_t8 h8, l8;
+  x2_split8_nosat(acc * inv, h8, l8);
+  u16* dst = out + (size_t)t * (heads * 128) + head * 128 + ((c & 63) >> 5) * 64 + (c & 31);
+  *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, h8);
+  *reinterpret_cast<uint4*>(dst + 32) = __builtin_bit_cast(uint4, l8);
+}
+
+// key ranges per work item of a few-token launch (1 = no split): work lists that leave most of the 256 one-block-per-CU slots empty
+int attention_x2_splits(int max_items, int heads) {
+  if (g_rap_attn_split == 0) return 1;
+  const long blocks = (long)max_items * heads;
+  return blocks <= 96 ? 4 : blocks <= 192 ? 2 : 1;
+}
+
+// part_o: splits x TP x heads*64 floats, part_ml: splits x TP x heads x 2 floats (splits > 1 only)
 int launch_attention_x2(hipStream_t stream, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP, int heads,
-                        const AttnWorkItem* items, int max_items) {
+                        const AttnWorkItem* items, int max_items, float* part_o, float* part_ml, int splits, int n_tokens) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0 || vt_nblk * 64 < TP) return RAP_ERR_INVALID;
   constexpr int LDS = 2 * 4 * XSUB * 2;      // 64 KB
   static_assert(8 * 32 * XLD * 2 <= LDS, "output slabs must fit the stages");
+  if (splits > 1) {
+    if (!part_o || !part_ml) return RAP_ERR_INVALID;
+    const void* fn = reinterpret_cast<const void*>(attention_x2_kernel<2, true>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      rap_set_last_hip_error((int)hipGetLastError());
+      return RAP_ERR_HIP;
+    }
+    hipLaunchKernelGGL((attention_x2_kernel<2, true>), dim3(max_items * heads, splits), dim3(512), LDS, stream, qk, vt, vt_nblk, out, TP, heads, items,
+                       part_o, part_ml);
+    RAP_LAUNCH_CHECK();
+    // only the rows that belong to a segment were written by a block: the filler rows of the padded buffers (n_tokens .. TP - 1) keep
+    // the zeros prepare_static put there (they must stay finite: masked keys multiply their V column by p = 0)
+    const int nt = n_tokens > 0 && n_tokens < TP ? n_tokens : TP;
+    const long n8 = (long)nt * heads * 8;
+    hipLaunchKernelGGL(attention_x2_combine_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, part_o, part_ml, out, TP, nt, heads, splits);
+    RAP_LAUNCH_CHECK();
+    return RAP_OK;
+  }
+  float* const no = nullptr;
   const bool two = g_rap_attn_x2_wpe == 4;
   const void* fn = two ? reinterpret_cast<const void*>(attention_x2_kernel<4>) : reinterpret_cast<const void*>(attention_x2_kernel<2>);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
     rap_set_last_hip_error((int)hipGetLastError());
     return RAP_ERR_HIP;
   }
-  if (two) hipLaunchKernelGGL(attention_x2_kernel<4>, dim3(max_items * heads), dim3(512), LDS, stream, qk, vt, vt_nblk, out, TP, heads, items);
-  else hipLaunchKernelGGL(attention_x2_kernel<2>, dim3(max_items * heads), dim3(512), LDS, stream, qk, vt, vt_nblk, out, TP, heads, items);
+  if (two) hipLaunchKernelGGL(attention_x2_kernel<4>, dim3(max_items * heads), dim3(512), LDS, stream, qk, vt, vt_nblk, out, TP, heads, items, no, no);
+  else hipLaunchKernelGGL(attention_x2_kernel<2>, dim3(max_items * heads), dim3(512), LDS, stream, qk, vt, vt_nblk, out, TP, heads, items, no, no);
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }

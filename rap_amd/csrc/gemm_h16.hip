@@ -573,25 +573,53 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
   HG_DMA(0, 0)
   HG_SYNC
   if constexpr (X2) {
-    Frag f[4];
-    auto mma2 = [&](const Frag& fa_, const Frag& fb_) {
+    // EPI_H_QKV_NORM: the q / k column tiles run the swapped product (a lane owns a token row: the row norm is lane-local), as in the
+    // phase-split kernels; a compile-time property of the k-loop copy that runs
+    const bool swp = EPI == EPI_H_QKV_NORM && (n0 + wn * 64) < 2 * p.heads * 64;
+    auto k_loop = [&](auto swp_c) __attribute__((always_inline)) {
+      constexpr bool SWP = decltype(swp_c)::value;
+      Frag f[4];
+      auto mma2 = [&](const Frag& fa_, const Frag& fb_) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, fa_.a[i]), __builtin_bit_cast(T8, fb_.b[j]), acc[i][j]);
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (SWP) acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, fb_.b[j]), __builtin_bit_cast(T8, fa_.a[i]), acc[i][j]);
+            else acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, fa_.a[i]), __builtin_bit_cast(T8, fb_.b[j]), acc[i][j]);
+          }
+      };
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) { HG_DMA(kt + 1, cur ^ 1) }     // spare buffer: every wave finished reading it before the last barrier
+#pragma unroll
+        for (int g = 0; g < 4; ++g) read_frag(f[g], cur, g);
+        mma2(f[2], f[0]); mma2(f[0], f[2]); mma2(f[3], f[1]); mma2(f[1], f[3]);      // (tail, head), (head, tail) of both k-steps
+        mma2(f[0], f[0]); mma2(f[1], f[1]);                                          // (head, head)
+        HG_SYNC
+      }
     };
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) { HG_DMA(kt + 1, cur ^ 1) }     // spare buffer: every wave finished reading it before the last barrier
-#pragma unroll
-      for (int g = 0; g < 4; ++g) read_frag(f[g], cur, g);
-      mma2(f[2], f[0]); mma2(f[0], f[2]); mma2(f[3], f[1]); mma2(f[1], f[3]);      // (tail, head), (head, tail) of both k-steps
-      mma2(f[0], f[0]); mma2(f[1], f[1]);                                          // (head, head)
-      HG_SYNC
+    if constexpr (EPI == EPI_H_QKV_NORM) {
+      if (swp) k_loop(std::true_type{}); else k_loop(std::false_type{});
+    } else {
+      k_loop(std::false_type{});
     }
-    static_assert(!X2 || EPI == EPI_H_BIAS_RESID_F32, "the 128 x 128 split-precision kernel serves the residual GEMMs");
-    gemm_x2_epilogue<EPI, TM>(p, acc, smem + wave * H16_STG_BYTES, m0 + wm * TM * 32, n0 + wn * 64, lane);
+    static_assert(!X2 || EPI == EPI_H_BIAS_RESID_F32 || EPI == EPI_H_GEGLU || EPI == EPI_H_QKV_NORM, "split precision: the three epilogues of the model path");
+    unsigned char* slab = smem + wave * H16_STG_BYTES;
+    const int mw = m0 + wm * TM * 32, nw = n0 + wn * 64;
+    if constexpr (EPI == EPI_H_QKV_NORM) {
+      if (swp) gemm_x2_qknorm_epilogue<TM>(p, acc, mw, nw, lane);
+      else gemm_x2_epilogue<EPI_H_QKV, TM>(p, acc, slab, mw, nw, lane);
+    } else if constexpr (EPI == EPI_H_BIAS_RESID_F32) {
+      if (gridDim.y > 1) {      // split-K: this block's share of the k-tiles, scaled, into plane blockIdx.y of the partial buffer
+        GemmParamsH q = p;
+        q.C = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.y * p.M * p.ldc;
+        gemm_x2_epilogue<EPI, TM>(q, acc, slab, mw, nw, lane);
+      } else {
+        gemm_x2_epilogue<EPI, TM>(p, acc, slab, mw, nw, lane);
+      }
+    } else {
+      gemm_x2_epilogue<EPI, TM>(p, acc, slab, mw, nw, lane);
+    }
     return;
   }
   read_frag(f0, 0, 0);
@@ -1291,19 +1319,49 @@ static int launch_x2_variant(hipStream_t stream, const GemmParamsH& p) {
   if (use_persistent_x2(p)) return launch_php<EPI, RAP_DT_F16, true>(stream, p);
   return launch_ph<EPI, RAP_DT_F16, 0, 1, true>(stream, p);
 }
+// Few-token split-precision calls.  Fewer 256 x 256 tiles than CUs: 128 x 128 tiles (two blocks per CU) fill the chip up to four times
+// better -- the N = 512 residual GEMMs below ~32 k tokens (64 tiles at 8 000 tokens), the QKV projection and ff1 below ~10 k / ~4 k.  The
+// long-K residual GEMM (ff2: 64 k-tiles of 64 physical columns) of a call with at most 128 such tiles is a latency-bound chain per block:
+// K is split over 2 / 4 blocks per tile that write scaled fp32 partial tiles, and the 16-bit path's combine pass forms
+// residual + (bias + partials) in a fixed order (gemm_h16_splits_by_shape on the physical K; tuning key 6).
+static bool x2_small(const GemmParamsH& p) { return (long)((p.M + 255) / 256) * (p.N / 256) < 256; }
+static int launch_x2_splitk(hipStream_t stream, const GemmParamsH& p, int splits) {
+  constexpr int LDS = 2 * (128 + 128) * 128;
+  auto kern = gemm_h16_kernel<EPI_H_BIAS_RESID_F32, RAP_DT_F16, 2, 2, 2, 2, true>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    rap_set_last_hip_error((int)hipGetLastError());
+    return RAP_ERR_HIP;
+  }
+  GemmParamsH q = p;
+  q.C = p.splitk_ws; q.ldc = p.N; q.bias = nullptr; q.resid = nullptr; q.splitk_ws = nullptr;      // (acc_scale stays: the partials are in true units)
+  hipLaunchKernelGGL(kern, dim3(((p.M + 127) / 128) * (p.N / 128), splits), dim3(256), LDS, stream, q);
+  RAP_LAUNCH_CHECK();
+  const long n8 = (long)p.M * (p.N / 8);
+  hipLaunchKernelGGL(gemm_h16_splitk_combine_kernel<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, p.splitk_ws, splits, p.M, p.N,
+                     p.bias, (const void*)p.resid, p.ldr, p.C, p.ldc);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}
 static int launch_x2(hipStream_t stream, int epilogue, const GemmParamsH& p) {
   if (p.N % 256 != 0 || p.K < 128 || p.K % 64 != 0) return RAP_ERR_INVALID;
   switch (epilogue) {
     case EPI_H_BIAS_RESID_F32:
-      // fewer 256 x 256 tiles than CUs (the N = 512 residual GEMMs below ~32 k tokens: 64 tiles at 8 000 tokens): 128 x 128 tiles, two
-      // blocks per CU, fill the chip four times better
-      if ((long)((p.M + 255) / 256) * (p.N / 256) < 256) return launch_cfg<EPI_H_BIAS_RESID_F32, RAP_DT_F16, 2, 2, 2, 2, true>(stream, p);
+      if (p.splitk_ws) {
+        const int splits = gemm_h16_splits(p.M, p.N, p.K);
+        if (splits > 1) {
+          if ((p.ldc & 7) || (p.ldr & 7)) return RAP_ERR_INVALID;
+          return launch_x2_splitk(stream, p, splits);
+        }
+      }
+      if (x2_small(p)) return launch_cfg<EPI_H_BIAS_RESID_F32, RAP_DT_F16, 2, 2, 2, 2, true>(stream, p);
       return launch_x2_variant<EPI_H_BIAS_RESID_F32>(stream, p);
     case EPI_H_GEGLU:
       if (p.ldc & 7) return RAP_ERR_INVALID;
+      if (x2_small(p)) return launch_cfg<EPI_H_GEGLU, RAP_DT_F16, 2, 2, 2, 2, true>(stream, p);
       return launch_x2_variant<EPI_H_GEGLU>(stream, p);
     case EPI_H_QKV_NORM:
       if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256 || ((p.gamma_q == nullptr) != (p.gamma_k == nullptr))) return RAP_ERR_INVALID;
+      if (x2_small(p)) return launch_cfg<EPI_H_QKV_NORM, RAP_DT_F16, 2, 2, 2, 2, true>(stream, p);
       return launch_x2_variant<EPI_H_QKV_NORM>(stream, p);
     default: return RAP_ERR_INVALID;
   }

@@ -176,8 +176,12 @@ int launch_x2_pack(hipStream_t stream, const float* src, long ld_src, long rows,
 int launch_x2_unpack(hipStream_t stream, const uint16_t* src, long rows, int cols, float inv_scale, float* dst);
 int launch_max_abs(hipStream_t stream, const float* x, size_t n, float* out);      // *out must be 0 before; non-negative result
 // q, k [2][H][2 chunks][TP][64 physical]; vt [H][vt_nblk][2 chunks][64 d][64 physical]; out paired (TP, 2 * H * 64); online softmax
+// splits > 1 (few-token calls): key ranges per work item, partial O in part_o [splits][TP][heads*64] fp32, (max, row sum) in part_ml
+// [splits][TP][heads][2], then one combine pass.  attention_x2_splits() picks the count for a work list (1, 2 or 4).
 int launch_attention_x2(hipStream_t stream, const uint16_t* qk, const uint16_t* vt, int vt_nblk, uint16_t* out, int TP, int heads,
-                        const AttnWorkItem* items, int max_items);
+                        const AttnWorkItem* items, int max_items, float* part_o = nullptr, float* part_ml = nullptr, int splits = 1,
+                        int n_tokens = 0);      // n_tokens: rows the combine pass covers (the real token count; 0 = TP)
+int attention_x2_splits(int max_items, int heads);
 
 // ---------------------------------------------------------------------------------------------
 // generation selection by rigidity (rigidity.hip; reference modeling.py:456-592, eval/metrics.py:511-622)

@@ -463,3 +463,38 @@ def test_x2_graph_replay_and_concurrent_shards_equal_the_eager_call(lib, dev):
             assert torch.equal(got[k], want[k]), ("graph", k)
             assert float((par[k] - want[k]).abs().max()) < 2e-5, ("shards", k)
     assert len(graph._graphs) == 1
+
+
+def test_x2_few_token_forms_match_the_plain_ones(lib, dev):
+    """Few-token split-precision calls: every attention work item over 2 / 4 key ranges (online-softmax partials merged by a combine pass)
+    and the long-K feed-forward down-projection over 2 / 4 k ranges (fp32 partial tiles + the 16-bit path's combine pass), all GEMMs on
+    128 x 128 tiles.  Same call with both splits disabled (tuning keys 5, 6): equal up to fp32 summation order; and against the oracle.
+    The filler rows of the padded buffers stay finite (the NaN-prefilled workspace gives the same bits)."""
+    import rap_amd
+    from oracle import rap_oracle as O
+    from rap_amd import flow_model as FM, synthetic as S
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    sd = S.make_weights(cfg, 5)
+    m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=2, num_heads=8, local_feat_dim=32, compute_dtype="float32x2")
+    m.load_state_dict(sd); m.to(dev)
+    inp = S.make_inputs([[700, 324], [130, 257]], seed=3)      # 1 411 tokens: 9 + 4 work items x 8 heads -> 2- / 4-way split
+    flow = rap_amd.RectifiedPointFlow(flow_model=m, inference_sampling_steps=3, rigidity_forcing=True)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    try:
+        assert lib.rap_set_tuning(5, 0) == 0 and lib.rap_set_tuning(6, 0) == 0
+        ref = flow.sample_and_register(d, x_1=d["x_1"])
+    finally:
+        assert lib.rap_set_tuning(5, 1) == 0 and lib.rap_set_tuning(6, 1) == 0
+    out = flow.sample_and_register(d, x_1=d["x_1"])
+    for k in ("end_point_trajectory", "trajectory", "R", "t"):
+        assert float((out[k] - ref[k]).abs().max()) < 5e-6, k
+    assert not torch.equal(out["trajectory"], ref["trajectory"])        # the split forms really ran (different summation order)
+    gold = O.sample(sd, cfg, inp, 3, True)
+    assert float((out["end_point_trajectory"].cpu() - gold["end_point_trajectory"]).abs().max()) < 5e-5
+    with torch.inference_mode():
+        for buf in FM._WORKSPACES.values():
+            buf.fill_(0xFF)                                              # NaN bit patterns everywhere, filler rows included
+    torch.cuda.synchronize()
+    again = flow.sample_and_register(d, x_1=d["x_1"])
+    for k in ("end_point_trajectory", "trajectory", "R", "t"):
+        assert torch.isfinite(again[k]).all() and torch.equal(again[k], out[k]), k
