@@ -435,7 +435,7 @@ int rap_profile_collect_ex(float* h_ms_out, int64_t* h_count_out, int32_t n_clas
  *   key 13 16-bit attention: K / V^T tiles by LDS-DMA      {1 (default), 0 = staged through registers}       16-bit path
  *   key 15 attention work lists of rap_sample / forward    {1 (default): longest segment first, 0: segment order}   both precisions
  *   key 16 split-precision attention: blocks per CU          {2 (default): one 8-wave block, 4: two}                 compute dtype 3
- *   key 17 split precision from this many token rows per call {2048 (default); 0 = always}: SMALLER calls of a model in compute dtype 3
+ *   key 17 split precision from this many token rows per call {1024 (default); 0 = always}: SMALLER calls of a model in compute dtype 3
  *          run the exact-fp32 kernels (both are fp32-accurate; below a few thousand tokens the fp32 path's few-token forms are faster)
  * Any other key returns RAP_ERR_INVALID.  (Keys 0-4 selected among the kernel variants of the round-1/2 experiments; those variants
  * are no longer in the tree, and what is left of the switch exists only in a library built with -DRAP_ABLATION_BUILD.) */

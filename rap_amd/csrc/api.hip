@@ -158,9 +158,11 @@ rap_tuning_t g_rap_attn_lpt = 1;               // tuning key 15: attention work 
 // floor, where the fp32 path's few-token forms (128 x 128 tiles, split-K, split-KV) are the faster ones (r05 call 3: configs[0] geometry,
 // one pair of 2 x 1024 points: 48.3 ms fp32 vs 52.6 ms on the 256 x 256-tile split kernels; call 4, one sample of 8 views, 20 steps:
 // 1 024 tokens 71 vs 89 ms, 2 048: 92 vs 99, 4 096: 197 vs 124, 8 000: 459 vs 197; call 5, with the residual GEMMs of few-token calls on
-// 128 x 128 split-precision tiles: 2 048 tokens 92 vs 81 ms, 2 560: 149 vs 86, 3 072: 169 vs 91 -- split precision wins from 2 048 rows).  The two layouts need the same workspace
+// 128 x 128 split-precision tiles: 2 048 tokens 92 vs 81 ms, 2 560: 149 vs 86, 3 072: 169 vs 91; call 9, with every few-token GEMM on
+// 128 x 128 tiles, split-K of ff2 and split-KV attention: 1 024 tokens 71 vs 46 ms, 2 048: 92 vs 54, configs[0] geometry 48.4 vs 28.0 ms --
+// split precision wins at every size measured; calls below 1 024 rows (not measured) stay on the fp32 kernels).  The two layouts need the same workspace
 // bytes (two 16-bit planes per value = one fp32).
-rap_tuning_t g_rap_x2_min_rows = 2048;
+rap_tuning_t g_rap_x2_min_rows = 1024;
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 // Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
 // fp32 summation order -- 5 split-KV for few-token calls (fp32 attention), 6 split-K for few-row calls (fp32 GEMMs and the 16-bit

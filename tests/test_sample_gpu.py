@@ -41,14 +41,14 @@ def get_model(num_layers, seed, dev, compute_dtype="float32"):
 
 @pytest.fixture(autouse=True, scope="module")
 def _split_precision_on_small_calls():
-    """By default a model in compute dtype "float32x2" runs calls below 2 048 token rows on the exact-fp32 kernels (tuning key 17: the
+    """By default a model in compute dtype "float32x2" runs calls below 1 024 token rows on the exact-fp32 kernels (tuning key 17: the
     few-token forms of the fp32 path are faster there).  The fixtures of this file ARE small: force the split-precision kernels so that
     they are what is tested (ragged row counts, one-tile launches); test_x2_small_calls_fall_back_to_exact_fp32 covers the default."""
     from rap_amd import _lib as _l
     lib = _l.load()
     assert lib.rap_set_tuning(17, 0) == 0
     yield
-    assert lib.rap_set_tuning(17, 2048) == 0
+    assert lib.rap_set_tuning(17, 1024) == 0
 
 
 @pytest.fixture(scope="module")
