@@ -723,6 +723,29 @@ def main():
                      "bit_identical_to_eager": bool(all(torch.equal(og[k], oe[k]) for k in ("end_point_trajectory", "trajectory", "R", "t")))}
         del mg, fg, fe, og, oe
 
+    # ---- few-token latency: the reference's own demo size (BASELINE configs[0] geometry: 1 pair x 2 x 1024 points, 10 flow steps), one call at a
+    # time, un-instrumented, in the three modes a user would pick from (the reference ships batch_size: 1)
+    few_token = None
+    if world == 1 and args.workload == "uniform" and args.dtype == "float32" and not args.no_secondary:
+        small = {k: v.to(dev) for k, v in S.make_uniform_inputs(1, 2, 1024, seed=1234).items()}
+        few_token = {"workload": "configs[0] geometry: 1 pair x 2 x 1024 points, 10 Euler flow steps, rap_%d, rigidity forcing on; one call at a time, "
+                                 "5 warm-up + 20 timed calls, un-instrumented" % args.layers, "ms_per_call": {}}
+        for dt_name in ("float32", "float32x2", "bfloat16"):
+            ms = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"], num_heads=cfg["num_heads"],
+                                       local_feat_dim=cfg["local_feat_dim"], attn_dtype=dt_name, compute_dtype=dt_name, residual_dtype=args.residual_dtype)
+            ms.load_state_dict(sd); ms.to(dev)
+            fs = rap_amd.RectifiedPointFlow(flow_model=ms, inference_sampling_steps=10, rigidity_forcing=True)
+            for _ in range(5):
+                fs.sample_and_register(small, x_1=small["x_1"])
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(20):
+                fs.sample_and_register(small, x_1=small["x_1"])
+            torch.cuda.synchronize()
+            few_token["ms_per_call"][DTYPE_TAG[dt_name]] = 1e3 * (time.perf_counter() - ts) / 20
+            del ms, fs
+        del small
+
     # ---- the RAGGED reference-regime batch through the same path: fp32 (1 warm-up + 1 timed call) and bf16
     ragged = None
     uniform_call_flops = call_flops(parts, args.layers, args.flow_steps)
@@ -845,6 +868,8 @@ def main():
             result["roofline_online_softmax"] = online
         if graph_leg:
             result["graph_replay"] = graph_leg
+        if few_token:
+            result["few_token_latency"] = few_token
         if ragged:
             for tag in ("f32", "f32x2", "bf16"):
                 if tag in ragged:
