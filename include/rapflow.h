@@ -425,8 +425,8 @@ int rap_poison_on_flag(const int32_t* flag, float* buf, int64_t n, void* stream)
 int rap_profile_enable(int on);
 int rap_profile_collect_ex(float* h_ms_out, int64_t* h_count_out, int32_t n_classes);
 /* Production switches between two SHIPPED code paths that compute the same function (process-global, atomic; not per model):
- *   key 5  split-KV attention for few-token calls        {0 off, 1 on (default)}       fp32 path
- *   key 6  split-K of the bias + residual GEMM, few rows  {0 off, 1 on (default)}       both precisions (16-bit: K >= 1024, i.e. ff2)
+ *   key 5  split-KV attention for few-token calls        {0 off, 1 on (default)}       fp32 path and split precision
+ *   key 6  split-K of the bias + residual GEMM, few rows  {0 off, 1 on (default)}       every precision (16-bit / split precision: K >= 1024, i.e. ff2)
  *   key 7  qk-norm fused into the QKV GEMM epilogue       {1 (default), 0 = own kernel} both precisions
  *   key 9  GEGLU's Phi                                    {1 (default): erfc polynomial, |error| <= 1.5e-7; 0: erff}   fp32 path
  *   key 11 persistent 16-bit GEMM (one block per CU walks {1 (default), 0 = one 256 x 256 tile per block}   16-bit path

@@ -18,6 +18,7 @@
 // FOUR 8 KB sub-tiles (K chunk 0 / 1, V^T chunk 0 / 1), each byte-for-byte a K or V^T tile of the 16-bit kernel (64 rows x 128 B,
 // slot ^ ((row >> 1) & 7) swizzle), so a wave issues 4 LDS-DMA pieces per tile and the fragment of contraction step s lies in
 // sub-tile s >> 1 at slots 2 (s & 1) + hi (heads) and 4 + 2 (s & 1) + hi (tails).  64 KB of LDS, one 8-wave block per CU.
+// Few-token launches split every work item over 2 / 4 key ranges (SPLIT; attention_x2_combine_kernel merges the online-softmax partials).
 #include "half.h"
 #include "kernels.h"
 
