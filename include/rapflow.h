@@ -351,10 +351,11 @@ int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t heads, const
  * its fp16 head, and 32 columns further as its fp16 tail -- every 32-column chunk is one 128-byte line [32 heads | 32 tails].  K % 32 == 0.
  * rap_x2_pack:   dst = split(src * scale)  (src fp32 (rows, cols), row stride ld_src; scale a power of two for weights, 1 otherwise).
  * rap_x2_unpack: dst fp32 (rows, cols) = (head + tail) * inv_scale.
- * rap_x2_gemm:   C = A (M,K) W(N,K)^T from paired A (M, lda) and W (N, ldw), K_physical = 2 K (>= 128, % 64 == 0), N % 256 == 0; the accumulators are
+ * rap_x2_gemm:   C = A (M,K) W(N,K)^T from paired A (M, lda) and W (N, ldw), K_physical = 2 K (>= 128, % 64 == 0), lda, ldw >= K_physical and % 8 == 0,
+ *   N % 256 == 0 (anything else: RAP_ERR_INVALID before any launch); the accumulators are
  *   multiplied by acc_scale (the inverse of the weight planes' scale) before the epilogue:
- *     1  C fp32 (M,N) = resid + acc + bias (resid may be NULL / alias C);
- *     3  GEGLU on value/gate-interleaved W: C paired (M, ldc >= N) holds the N/2 outputs (h + bh) * gelu_erf(g + bg);
+ *     1  C fp32 (M,N) = resid + acc + bias (resid may be NULL / alias C; ldc, ldr >= N and % 4 == 0: rows move as 16-byte pieces);
+ *     3  GEGLU on value/gate-interleaved W: C paired (M, ldc >= N, ldc % 8 == 0) holds the N/2 outputs (h + bh) * gelu_erf(g + bg);
  *     5  QKV projection with MultiHeadRMSNorm fused (N = 3 * heads * 64): q, k -> C paired [2][heads][2 chunks][M][64 physical] (chunk c =
  *        head dims 32c .. 32c+31; q multiplied by q_mul, k by 8 as in rap_gemm_h16_qkvnorm; gamma_q = gamma_k = NULL: no norm, q and k
  *        leave as projected -- qk_norm = False), v -> vt paired

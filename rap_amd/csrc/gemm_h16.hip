@@ -1370,7 +1370,10 @@ static int launch_x2(hipStream_t stream, int epilogue, const GemmParamsH& p) {
 int launch_gemm_h16(hipStream_t stream, int dtype, int epilogue, const GemmParamsH& p) {
   if (p.M <= 0) return RAP_OK;
   if (p.N % 128 != 0 || p.K % 64 != 0 || p.K <= 0) return RAP_ERR_INVALID;      // K % 64: two 32-wide ring slices / one 64-wide tile
-  if ((p.lda & 7) || (p.ldw & 7)) return RAP_ERR_INVALID;
+  if ((p.lda & 7) || (p.ldw & 7) || p.lda < p.K || p.ldw < p.K) return RAP_ERR_INVALID;
+  // output / residual rows are stored as whole 16-byte pieces: four fp32 or eight 16-bit columns
+  if (epilogue == EPI_H_BIAS_RESID_F32 && ((p.ldc & 3) || p.ldc < p.N || (p.resid && ((p.ldr & 3) || p.ldr < p.N)))) return RAP_ERR_INVALID;
+  if ((epilogue == EPI_H_BIAS || epilogue == EPI_H_GEGLU) && (p.ldc & 7)) return RAP_ERR_INVALID;
   if (dtype == RAP_DT_F32X2) return launch_x2(stream, epilogue, p);
   if (dtype == RAP_DT_BF16) return launch_dt<RAP_DT_BF16>(stream, epilogue, p);
   if (dtype == RAP_DT_F16) return launch_dt<RAP_DT_F16>(stream, epilogue, p);

@@ -117,6 +117,31 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
     assert lib.rap_model_bounded_attention_launches(N) < 0
 
 
+def test_split_precision_entry_points_refuse_bad_shapes_without_a_gpu():
+    """rap_x2_gemm / rap_x2_pack / rap_x2_attention validate on the host, before any launch: strides that would break the 16-byte row
+    pieces of the epilogues, shapes outside the tile rules, and missing planes come back as RAP_ERR_INVALID (-1) / workspace (-2)."""
+    import ctypes
+    from rap_amd import _lib
+    lib = _lib.load()
+    N, one = ctypes.c_void_p(0), ctypes.c_void_p(256)      # a non-NULL sentinel: every call below fails before the pointer is used
+    def gemm(epi, lda=1024, ldw=1024, ldc=512, M=256, Nn=512, K=1024, ldr=512, resid=one, heads=0, vt=N, nblk=0, A=one):
+        return lib.rap_x2_gemm(epi, A, lda, one, ldw, one, ldc, M, Nn, K, one, resid, ldr, 1.0, heads, N, N, 8.0, vt, nblk, N)
+    assert gemm(1, A=N) == -1                               # NULL operand
+    assert gemm(1, ldc=514) == -1 and gemm(1, ldr=513) == -1 and gemm(1, ldc=256) == -1      # fp32 rows leave as float4 pieces; ldc >= N
+    assert gemm(1, lda=1000) == -1 and gemm(1, lda=512) == -1                                  # 16-byte operand rows; lda >= K_physical
+    assert gemm(1, K=96) == -1 and gemm(1, K=64) == -1 and gemm(1, Nn=384) == -1              # K_physical % 64, >= 128; N % 256
+    assert gemm(3, ldc=4100) == -1                                                             # paired fp16 GEGLU rows: 8-element pieces
+    assert gemm(5, Nn=1536, heads=8, vt=N) == -1 and gemm(5, Nn=1536, heads=8, vt=one, nblk=3) == -1   # V^T image missing / too small
+    assert gemm(5, Nn=1024, heads=8, vt=one, nblk=4) == -1                                     # N != 3 * heads * 64
+    assert gemm(0) == -1 and gemm(7) == -1                                                     # epilogues the split path does not have
+    assert lib.rap_x2_pack(N, 64, 4, 64, 1.0, one, N) == -1 and lib.rap_x2_pack(one, 32, 4, 64, 1.0, one, N) == -1
+    assert lib.rap_x2_unpack(one, -1, 64, 1.0, one, N) == -1
+    assert lib.rap_x2_attention(N, one, 4, one, 1, one, 256, 8, one, 1 << 20, N) == -1
+    assert lib.rap_x2_attention(one, one, 4, one, 1, one, 256, 8, one, 8, N) == -2             # workspace smaller than the work list
+    # the 16-bit entry point shares the stride rules
+    assert lib.rap_gemm_h16(1, 1, one, 512, one, 512, one, 514, 256, 512, 512, one, one, 512, 0, N, 0, N) == -1
+
+
 def test_splitk_rule_of_the_16bit_residual_gemm_is_host_arithmetic():
     """rap_gemm_h16_splitk_workspace_bytes states the few-token split-K rule of the 16-bit residual GEMMs (gemm_h16.hip:
     gemm_h16_splits): K >= 1024 with K / 64 a multiple of 4, at most 64 tiles of 128 x 128 -> 4 partial planes, at most 128 -> 2,
