@@ -273,3 +273,28 @@ def test_constructor_switches_map_onto_the_native_weight_layout():
     m = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=2, num_heads=8, local_feat_dim=32, qk_norm=False)
     with pytest.raises(RuntimeError):
         m.load_state_dict(S.make_weights(cfg, 1))          # carries q / k gains this configuration does not have
+
+
+def test_checkpoint_script_reads_lightning_and_bare_state_dicts(tmp_path):
+    """scripts/check_checkpoint.py: the checkpoint reader (host-side) takes the reference's Lightning file layout
+    (`torch.load(path)["state_dict"]` with `flow_model.*` keys next to other modules' tensors, utils/checkpoint.py:64-71), a bare
+    PointCloudDiT state_dict, and names what is missing instead of loading a partial model."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_checkpoint", os.path.join(ROOT, "scripts", "check_checkpoint.py"))
+    cc = importlib.util.module_from_spec(spec); spec.loader.exec_module(cc)
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    sd = S.make_weights(cfg, 9)
+    lightning = str(tmp_path / "lightning.ckpt"); bare = str(tmp_path / "bare.pt"); part = str(tmp_path / "part.pt")
+    torch.save({"state_dict": {**{"flow_model." + k: v.half() for k, v in sd.items()}, "feature_extractor.stem.weight": torch.zeros(3)},
+                "epoch": 3}, lightning)
+    torch.save(sd, bare)
+    torch.save({k: v for k, v in sd.items() if "final_mlp" not in k}, part)
+    got = cc.load_weights(lightning, cfg)
+    assert set(got) == set(sd) and all(v.dtype == torch.float32 for v in got.values())
+    assert all(torch.equal(got[k], sd[k].half().float()) for k in sd)
+    got = cc.load_weights(bare, cfg)
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    with pytest.raises(SystemExit, match="lacks"):
+        cc.load_weights(part, cfg)
+    with pytest.raises(SystemExit, match="lacks"):                           # a 12-layer model asked of a 2-layer checkpoint
+        cc.load_weights(bare, dict(S.RAP_12))
