@@ -30,12 +30,20 @@ extern "C" {
  * round 5, version 5: compute dtype 3 (split precision) and the rap_x2_* entry points are new, nothing was removed or re-numbered). */
 #define RAPFLOW_ABI_VERSION 5
 
+/* return codes of every int-returning entry point */
+#define RAP_OK 0
+#define RAP_ERR_INVALID (-1)
+#define RAP_ERR_WORKSPACE (-2)
+#define RAP_ERR_HIP (-3)
+#define RAP_ERR_ALLOC (-4)
+
 typedef struct rap_model rap_model;
 
 /* PointCloudDiT hyper-parameters (reference config/model/flow_model/point_cloud_dit_12.yaml,
  * flow_model/point_cloud_dit.py:20-36).  head_dim is fixed at 64 (embed_dim == 64 * num_heads),
- * embed_dim a multiple of 256, local_feat_dim a multiple of 4 and <= 40, in_dim == 0,
- * scale_emb_on == local_feat_concat_on == true, qk_norm == true (config/RAP_inference.yaml:65). */
+ * embed_dim a multiple of 256, local_feat_dim a multiple of 4 and <= 40, in_dim == 0.  The native embedding layout is the one of
+ * scale_emb_on == local_feat_concat_on == true (config/RAP_inference.yaml:65); a model built with either switch off maps onto it with
+ * zero weight columns / unit gains (rap_amd/flow_model.py _native_tensors), qk_norm == false through rap_model_set_qk_norm. */
 typedef struct rap_model_desc {
   int32_t embed_dim;      /* 512 */
   int32_t num_layers;     /* 10 / 12 / 16 */

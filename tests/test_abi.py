@@ -37,6 +37,23 @@ def test_every_declared_symbol_is_exported_and_bound(lib_path):
     _lib.load()   # sets argtypes on every symbol; raises if one is missing
 
 
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(lib_path, tmp_path):
+    """The boundary is a C ABI, not a Python one: include/rapflow.h compiles as pedantic C99 (and as C++), and a C program
+    (tests/host/c_consumer.c) linked against librapflow.so gets the version, the workspace arithmetic and the argument checks --
+    without torch, without Python, without a GPU."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "host", "c_consumer.c")
+    inc = os.path.join(ROOT, "include")
+    exe = str(tmp_path / "c_consumer")
+    libdir = os.path.dirname(lib_path)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, src, "-L", libdir, "-lrapflow",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", src])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failure(s), ABI version 5" in r.stdout
+
+
 def test_weight_count_matches_reference_parameter_count(lib_path):
     from rap_amd import _lib
     from rap_amd.synthetic import RAP_12, weight_spec
