@@ -298,3 +298,59 @@ def test_checkpoint_script_reads_lightning_and_bare_state_dicts(tmp_path):
         cc.load_weights(part, cfg)
     with pytest.raises(SystemExit, match="lacks"):                           # a 12-layer model asked of a 2-layer checkpoint
         cc.load_weights(bare, dict(S.RAP_12))
+
+
+def test_bench_line_is_small():
+    """the round-5 line had grown to 28 KB and the driver recorded `parsed: null`.  bench.py now prints
+    `compact_line(full)` and writes the full record to a side file: feed it the very 28 KB record of round 5 (and a copy with every
+    string inflated) and require a parseable line under 6 KB that still carries the contract's keys, `roofline` and `cpu_baseline`."""
+    import json
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05_c12_bench_driver_cmd_final_tree.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000                       # the record that broke the driver's parser
+    inflated = json.loads(json.dumps(full))
+    inflated["config"]["workload"] = "w" * 5000
+    inflated["cpu_baseline"]["sample"] = "s" * 5000
+    inflated["roofline"]["traffic_source"] = "t" * 5000
+    inflated["ragged"] = {t: {"points_per_s": 1.0 / 3.0} for t in ("f32", "f32x2", "bf16")}
+    for rec in (full, inflated):
+        text = json.dumps(bench.compact_line(rec, "gpurun_out/bench_detail.json"))
+        assert "\n" not in text and len(text) < 6144, len(text)
+        line = json.loads(text)
+        for k in bench.REQUIRED_LINE_KEYS:
+            assert k in line, k
+        assert line["value"] == pytest.approx(full["value"], rel=1e-5) and line["metric"] == full["metric"]
+        assert isinstance(line["config"]["workload"], str)
+        for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches"):
+            assert k in line["roofline"], k
+        assert line["roofline"]["frac"] == pytest.approx(line["roofline"]["achieved"] / line["roofline"]["peak"], rel=1e-4)
+        for k in ("value", "unit", "cores", "kind", "sample", "steps_timed", "extrapolated"):
+            assert k in line["cpu_baseline"], k
+        assert set(line["parity_vs_reference_golden"]) >= {"final_cloud_max_abs", "R_frob_max", "t_max_abs"}
+        assert all(isinstance(v, float) for v in line["hbm_kernels"].values())
+        assert set(line["points_per_s_by_mode"]) == {"f32", "f32x2", "bf16", "f16"}
+
+
+def test_bench_presets_label_the_workload_by_geometry_not_dtype():
+    """a configs[4] run in split precision was labelled 'configs[2] per-GPU shard'."""
+    import types
+    import bench
+
+    def ns(**kw):
+        d = dict(batch=32, views=2, points=4096, flow_steps=20, dtype="float32", rigidity=1); d.update(kw)
+        return types.SimpleNamespace(**d)
+    assert bench.preset_of(ns()) == 1 and bench.workload_label(ns()).startswith("configs[1]:")
+    assert bench.preset_of(ns(dtype="float32x2")) == 1
+    assert bench.preset_of(ns(dtype="bfloat16")) == 2 and "configs[2] per-GPU shard" in bench.workload_label(ns(dtype="bfloat16"))
+    c3 = dict(batch=16, views=8, points=2048, flow_steps=30)
+    c4 = dict(batch=4, views=2, points=32768, flow_steps=50)
+    for dt in ("float32", "float32x2", "bfloat16"):
+        assert bench.preset_of(ns(dtype=dt, **c3)) == 3 and bench.workload_label(ns(dtype=dt, **c3)).startswith("configs[3]")
+    assert bench.preset_of(ns(dtype="bfloat16", **c4)) == 4 and bench.workload_label(ns(dtype="bfloat16", **c4)).startswith("configs[4]")
+    lab = bench.workload_label(ns(dtype="float32x2", **c4))                 # the round-5 mislabel: 'configs[2] per-GPU shard'
+    assert bench.preset_of(ns(dtype="float32x2", **c4)) == 4 and lab.startswith("configs[4]") and "geometry only" in lab and "configs[2]" not in lab
+    assert bench.preset_of(ns(batch=7)) is None and bench.workload_label(ns(batch=7)).startswith("custom shape")
+    for n, p in bench.PRESETS.items():                                       # every preset round-trips through the label function
+        a = ns(**{k: p[k] for k in ("batch", "views", "points", "flow_steps", "dtype", "rigidity")})
+        assert bench.preset_of(a) == n
