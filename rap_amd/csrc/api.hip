@@ -163,6 +163,8 @@ rap_tuning_t g_rap_attn_lpt = 1;               // tuning key 15: attention work 
 // split precision wins at every size measured; calls below 1 024 rows (not measured) stay on the fp32 kernels).  The two layouts need the same workspace
 // bytes (two 16-bit planes per value = one fp32).
 rap_tuning_t g_rap_x2_min_rows = 1024;
+rap_tuning_t g_rap_small_fused = 1;            // tuning key 19: few-token 16-bit / split-precision calls fold every residual GEMM's combine pass into the following LayerNorm (1, default)
+extern rap_tuning_t g_rap_ring_blocks;         // gemm_h16.hip, tuning key 18: launches of the 128 x 128 16-bit GEMM with at most this many blocks take the four-stage ring
 rap_tuning_t g_rap_fuse_qknorm = 1;            // tuning key 7: qk-norm fused into the QKV GEMM epilogue (1, default; both precisions) or as its own kernel (0)
 // Production switches (process-global, atomics): each selects between two SHIPPED code paths that produce the same result up to
 // fp32 summation order -- 5 split-KV for few-token calls (fp32 attention), 6 split-K for few-row calls (fp32 GEMMs and the 16-bit
@@ -185,6 +187,8 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 13 && (value == 0 || value == 1)) { g_rap_attn_h16_dma = value; return RAP_OK; }
   if (key == 15 && (value == 0 || value == 1)) { g_rap_attn_lpt = value; return RAP_OK; }
   if (key == 17 && value >= 0) { g_rap_x2_min_rows = value; return RAP_OK; }   // split precision from this many token rows per call (smaller calls: exact fp32)
+  if (key == 18 && value >= 0) { g_rap_ring_blocks = value; return RAP_OK; }      // four-stage ring of the 128 x 128 16-bit GEMM up to this many blocks per launch (0 = never)
+  if (key == 19 && (value == 0 || value == 1)) { g_rap_small_fused = value; return RAP_OK; }      // combine + LayerNorm fusion of few-token calls
   if (key == 16 && (value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: 1 / 2 blocks per CU
   return RAP_ERR_INVALID;
 }
@@ -614,6 +618,13 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
   const void* hres = w.h16 ? (const void*)w.h16 : (const void*)w.h;      // the residual stream as the 16-bit LayerNorms read it
   const int hres_f16 = w.h16 ? 1 : 0;
   const int epi_resid = w.h16 ? EPI_H_BIAS_RESID_H16 : EPI_H_BIAS_RESID_F32;
+  // Few-token calls of the 16-bit / split-precision blocks (round 6; the reference's everyday batch_size: 1, RAP_inference.yaml:30-36): every
+  // residual GEMM leaves fp32 partial planes (split-K where gemm_h16_splits says so, one plane otherwise) and ONE kernel forms the new
+  // residual-stream value and the LayerNorm that follows it (launch_resid_combine_ln_h16) -- 11 launches per layer instead of 14.  The planes
+  // live in the split-K buffer, which exists exactly for the calls this is meant for (<= 128 tiles of 128 x 128 in the N = d GEMMs).
+  const bool fused = g_rap_small_fused && dt != RAP_DT_F32 && w.splitk_h != nullptr && g_rap_gemm_splitk;
+  auto fused_splits = [](const GemmParamsH& g) { const int sp = gemm_h16_splits(g.M, g.N, g.K); return sp > 1 ? sp : 1; };
+  bool xn_ready = false;                    // the LayerNorm output the next QKV projection reads is already in xnh
   for (int i = 0; i < m->L; ++i) {
     const LayerW& lw = m->layers[i];
     if (dt == RAP_DT_F32X2) {
@@ -623,7 +634,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       const LayerWH& lh = m->half[dt].layers[i];
       for (int a = 0; a < 2; ++a) {
         const int j = 2 * i + a;
-        { ProfScope ps(stream, 3); rc = launch_layernorm_mod_h16(stream, dt, w.h, 0, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row); }
+        if (!xn_ready) { ProfScope ps(stream, 3); rc = launch_layernorm_mod_h16(stream, dt, w.h, 0, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row); }
         if (rc) return rc;
         GemmParamsH g{};
         g.A = w.xnh; g.lda = 2 * d; g.W = lh.Wqkv[a]; g.ldw = 2 * d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = 2 * d; g.heads = H;
@@ -644,10 +655,18 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         GemmParamsH o{};
         o.A = w.atth; o.lda = 2 * d; o.W = lh.Wout[a]; o.ldw = 2 * d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = 2 * d;
         o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d; o.acc_scale = lh.s_out[a];
+        if (fused) { o.splitk_ws = w.splitk_h; o.defer_combine = 1; }
         { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, o); }
         if (rc) return rc;
+        if (fused) {      // combine pass + the NEXT LayerNorm in one kernel: adaLN of the per-sample branch after a = 0, the FFN's affine LN after a = 1
+          ProfScope ps(stream, 3);
+          rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, fused_splits(o), o.bias, w.h, 0, w.xnh, TP, d,
+                                           a == 0 ? mod + (size_t)(j + 1) * 2 * d : nullptr, mod_stride, token_row, lw.ffn_g, lw.ffn_b);
+          if (rc) return rc;
+          xn_ready = true;
+        }
       }
-      { ProfScope ps(stream, 3); rc = launch_layernorm_affine_h16(stream, dt, w.h, 0, w.xnh, TP, d, lw.ffn_g, lw.ffn_b); }
+      if (!fused) { ProfScope ps(stream, 3); rc = launch_layernorm_affine_h16(stream, dt, w.h, 0, w.xnh, TP, d, lw.ffn_g, lw.ffn_b); }
       if (rc) return rc;
       GemmParamsH f1{};
       f1.A = w.xnh; f1.lda = 2 * d; f1.W = lh.Wff1p; f1.ldw = 2 * d; f1.C = w.ffmidh; f1.ldc = 8 * d; f1.M = TP; f1.N = 8 * d; f1.K = 2 * d;
@@ -658,8 +677,18 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       f2.A = w.ffmidh; f2.lda = 8 * d; f2.W = lh.Wff2; f2.ldw = 8 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 8 * d;
       f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d; f2.acc_scale = lh.s_ff2;
       f2.splitk_ws = w.splitk_h;               // few-token calls: the physical K = 8d split over 2 / 4 blocks per tile (null otherwise)
+      const bool f2_fused = fused && i + 1 < m->L;      // ... and its combine pass is the first LayerNorm of the next layer
+      if (f2_fused) f2.defer_combine = 1;
       { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, f2); }
       if (rc) return rc;
+      xn_ready = false;
+      if (f2_fused) {
+        ProfScope ps(stream, 3);
+        rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, fused_splits(f2), f2.bias, w.h, 0, w.xnh, TP, d,
+                                         mod + (size_t)(2 * i + 2) * 2 * d, mod_stride, token_row, nullptr, nullptr);
+        if (rc) return rc;
+        xn_ready = true;
+      }
       continue;
     }
     if (dt != RAP_DT_F32) {
@@ -667,18 +696,16 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       const LayerWH& lh = m->half[dt].layers[i];
       for (int a = 0; a < 2; ++a) {
         const int j = 2 * i + a;
-        { ProfScope ps(stream, 3); rc = launch_layernorm_mod_h16(stream, dt, hres, hres_f16, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row); }
+        if (!xn_ready) { ProfScope ps(stream, 3); rc = launch_layernorm_mod_h16(stream, dt, hres, hres_f16, w.xnh, TP, d, mod + (size_t)j * 2 * d, mod_stride, token_row); }
         if (rc) return rc;
         GemmParamsH g{};
         g.A = w.xnh; g.lda = d; g.W = lh.Wqkv[a]; g.ldw = d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = d; g.heads = H;
         g.vt = w.vth; g.vt_nblk = w.vt_nblk;
         const bool bnd = w.qk_norm && m->bounded[j] != 0;                // this launch's softmax kernel (per layer and branch)
         const bool prescale = attention_h16_wants_prescaled_q(dt, bnd);
-        // few-token calls (fewer 256 x 256 tiles than CUs): the 128 x 128 kernel fills the chip better than the fused epilogue's 256 x 256
-        // tiles save (it exists only in the phase-split kernels), so the projection and qk-norm run as two kernels there
-        // (r03 call 32: one pair of 2 x 1024 points, 10 steps, bf16: 21.3 -> 18.5 ms; at 2 x 4096 -- 192 tiles -- the fused form is still ahead)
-        const bool few_tiles = (long)((TP + 255) / 256) * (3 * d / 256) < 128;
-        if (g_rap_fuse_qknorm && !few_tiles && w.qk_norm) {
+        // (few-token calls: the fused epilogue exists on 128 x 128 tiles too since round 6 -- launch_gemm_h16 picks the tile; until then
+        // such calls ran the projection and qk-norm as two kernels, r03 call 32)
+        if (g_rap_fuse_qknorm && w.qk_norm) {
           // qk-norm in the QKV epilogue: one kernel, q / k normalised from the fp32 accumulators (no 16-bit round trip through HBM)
           g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; g.q_mul = prescale ? RAP_QMUL_PRESCALED : 8.0f;
           { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV_NORM, g); }
@@ -699,10 +726,18 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         o.A = w.atth; o.lda = d; o.W = lh.Wout[a]; o.ldw = d; o.ldc = d; o.M = TP; o.N = d; o.K = d;
         o.bias = lw.bout[a]; o.ldr = d;
         if (w.h16) { o.C = w.h16; o.resid_h = w.h16; } else { o.C = w.h; o.resid = w.h; }
+        if (fused) { o.splitk_ws = w.splitk_h; o.defer_combine = 1; }
         { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, epi_resid, o); }
         if (rc) return rc;
+        if (fused) {      // combine pass + the NEXT LayerNorm in one kernel (see the split-precision block)
+          ProfScope ps(stream, 3);
+          rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, fused_splits(o), o.bias, w.h16 ? (void*)w.h16 : (void*)w.h, hres_f16, w.xnh, TP, d,
+                                           a == 0 ? mod + (size_t)(j + 1) * 2 * d : nullptr, mod_stride, token_row, lw.ffn_g, lw.ffn_b);
+          if (rc) return rc;
+          xn_ready = true;
+        }
       }
-      { ProfScope ps(stream, 3); rc = launch_layernorm_affine_h16(stream, dt, hres, hres_f16, w.xnh, TP, d, lw.ffn_g, lw.ffn_b); }
+      if (!fused) { ProfScope ps(stream, 3); rc = launch_layernorm_affine_h16(stream, dt, hres, hres_f16, w.xnh, TP, d, lw.ffn_g, lw.ffn_b); }
       if (rc) return rc;
       GemmParamsH f1{};
       f1.A = w.xnh; f1.lda = d; f1.W = lh.Wff1p; f1.ldw = d; f1.C = w.ffmidh; f1.ldc = 4 * d; f1.M = TP; f1.N = 8 * d; f1.K = d;
@@ -714,8 +749,18 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       f2.bias = lw.bff2; f2.ldr = d;
       f2.splitk_ws = w.splitk_h;               // few-token calls: K = 4d split over 2 / 4 blocks per tile (null otherwise)
       if (w.h16) { f2.C = w.h16; f2.resid_h = w.h16; } else { f2.C = w.h; f2.resid = w.h; }
+      const bool f2_fused = fused && i + 1 < m->L;
+      if (f2_fused) f2.defer_combine = 1;
       { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, epi_resid, f2); }
       if (rc) return rc;
+      xn_ready = false;
+      if (f2_fused) {
+        ProfScope ps(stream, 3);
+        rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, fused_splits(f2), f2.bias, w.h16 ? (void*)w.h16 : (void*)w.h, hres_f16, w.xnh, TP, d,
+                                         mod + (size_t)(2 * i + 2) * 2 * d, mod_stride, token_row, nullptr, nullptr);
+        if (rc) return rc;
+        xn_ready = true;
+      }
       continue;
     }
     for (int a = 0; a < 2; ++a) {   // a = 0: per-part attention, a = 1: per-sample attention (layer.py:152-160)

@@ -469,14 +469,23 @@ __device__ __forceinline__ void gemm_x2_qknorm_epilogue(const GemmParamsH& p, f3
 // X2 (round 5, the residual GEMMs of few-token split-precision calls): the paired-operand product of the phase-split kernels (three MFMAs
 // per fragment pair, see gemm_h16_ph_kernel) on this kernel's 128 x 128 tiles -- the four fragment sets of a k-tile (head k-steps 0, 1 and
 // tail k-steps 0, 1) are read, then the six kept products issue.
-template <int EPI, int DT, int WM, int WN, int TM, int TN, bool X2 = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16_kernel(GemmParamsH p) {
+//
+// NS (round 6, few-token calls): LDS stages.  2 = the double-buffered loop above (two blocks per CU).  4 = a ring of four stages with
+// the DMA of tile t + 3 issued while tile t multiplies and COUNTED waits (vmcnt(2 tiles)): when a launch has no more blocks than the part
+// has CUs (one pair of 2 x 1024 points: 64 ... 512 blocks) a block has the CU to itself, the second block of the two-stage form hides
+// nothing, and the k-loop is one L2 round trip (~1 us) per k-tile against 0.25-0.4 us of MFMA issue (profiles/r05_c13_*).  Three tiles
+// in flight cover the latency.  Same k order per accumulator: results are bit-identical to NS = 2.
+// EPI_H_QKV_NORM without X2 (round 6): the q / k column tiles run the swapped product and leave through gemm_h16_qknorm_epilogue, the
+// V tiles through the EPI_H_QKV epilogue -- the fused form used to exist only in the 256 x 256 phase-split kernels.
+template <int EPI, int DT, int WM, int WN, int TM, int TN, bool X2 = false, int NS = 2>
+__global__ __launch_bounds__(64 * WM * WN, (NS > 2 ? 1 : 2)) void gemm_h16_kernel(GemmParamsH p) {
   typedef typename H16<DT>::T8 T8;
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;   // 16-byte chunks per thread per k-tile
   constexpr int ABYTES = BM * 128, BBYTES = BN * 128;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [A0 A1 B0 B1]
+  static_assert(NS == 2 || NS == 4, "two stages (two blocks per CU) or a ring of four (one block per CU)");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [A0 .. A(NS-1) B0 .. B(NS-1)]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
   _Pragma("unroll") for (int i = 0; i < CA; ++i)                                                              \
     HG_DMA1(a_src[i] + (size_t)(KT) * 64, lds_wave + (unsigned)((BUF) * ABYTES + i * NT * 16))                \
   _Pragma("unroll") for (int i = 0; i < CB; ++i)                                                              \
-    HG_DMA1(w_src[i] + (size_t)(KT) * 64, lds_wave + (unsigned)(2 * ABYTES + (BUF) * BBYTES + i * NT * 16))
+    HG_DMA1(w_src[i] + (size_t)(KT) * 64, lds_wave + (unsigned)(NS * ABYTES + (BUF) * BBYTES + i * NT * 16))
 #define HG_SYNC asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
 #define HG_FENCE __builtin_amdgcn_sched_barrier(0);
 
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
       f.a[i] = *reinterpret_cast<const uint4*>(smem + buf * ABYTES + a_row + i * 32 * 128 + co);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      f.b[j] = *reinterpret_cast<const uint4*>(smem + 2 * ABYTES + buf * BBYTES + b_row + j * 32 * 128 + co);
+      f.b[j] = *reinterpret_cast<const uint4*>(smem + NS * ABYTES + buf * BBYTES + b_row + j * 32 * 128 + co);
   };
   auto mma = [&](const Frag& f) {
 #pragma unroll
@@ -570,6 +579,81 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
         acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, f.a[i]), __builtin_bit_cast(T8, f.b[j]), acc[i][j]);
   };
 
+  if constexpr (NS > 2 || (EPI == EPI_H_QKV_NORM && !X2)) {
+    // ---- ring of NS stages (NS = 2: the plain double buffer, for the non-X2 fused QKV tiles), swapped product on q / k column tiles
+    const bool swp = EPI == EPI_H_QKV_NORM && (n0 + wn * 64) < 2 * p.heads * 64;      // (block-uniform: a 128-column tile is all q / k or all v)
+    auto ring = [&](auto swp_c) __attribute__((always_inline)) {
+      constexpr bool SWP = decltype(swp_c)::value;
+      auto mm = [&](const Frag& fa_, const Frag& fb_) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (SWP) acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, fb_.b[j]), __builtin_bit_cast(T8, fa_.a[i]), acc[i][j]);
+            else acc[i][j] = H16<DT>::mfma(__builtin_bit_cast(T8, fa_.a[i]), __builtin_bit_cast(T8, fb_.b[j]), acc[i][j]);
+          }
+      };
+#pragma unroll
+      for (int s_ = 0; s_ < NS - 1; ++s_)
+        if (s_ < nk) { HG_DMA(s_, s_) }
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & (NS - 1);
+        // tile kt has landed once at most the NS - 2 younger tiles are outstanding (loads retire in order); near the end fewer are in flight
+        if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (CA + CB)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                    // tile kt visible to every wave; every wave is done with tile kt - 1, whose buffer the next DMA takes
+        if (kt + NS - 1 < nk) { HG_DMA(kt + NS - 1, (kt + NS - 1) & (NS - 1)) }
+        if constexpr (X2) {
+          Frag f[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) read_frag(f[g], cur, g);
+          mm(f[2], f[0]); mm(f[0], f[2]); mm(f[3], f[1]); mm(f[1], f[3]);      // (tail, head), (head, tail) of both k-steps
+          mm(f[0], f[0]); mm(f[1], f[1]);                                      // (head, head)
+        } else {
+          read_frag(f0, cur, 0);
+          read_frag(f1, cur, 1);
+          HG_FENCE
+          mm(f0, f0);
+          HG_FENCE
+          read_frag(f0, cur, 2);
+          HG_FENCE
+          mm(f1, f1);
+          HG_FENCE
+          read_frag(f1, cur, 3);
+          HG_FENCE
+          mm(f0, f0);
+          HG_FENCE
+          mm(f1, f1);
+        }
+      }
+    };
+    if constexpr (EPI == EPI_H_QKV_NORM) {
+      if (swp) ring(std::true_type{}); else ring(std::false_type{});
+    } else {
+      ring(std::false_type{});
+    }
+    __syncthreads();                        // the operand buffers become the epilogue slabs
+    unsigned char* slab = smem + wave * H16_STG_BYTES;
+    const int mw = m0 + wm * TM * 32, nw = n0 + wn * 64;
+    GemmParamsH q = p;
+    if constexpr (EPI == EPI_H_BIAS_RESID_F32) {
+      if (gridDim.y > 1) q.C = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.y * p.M * p.ldc;      // split-K: plane blockIdx.y of the partial buffer
+    }
+    if constexpr (X2) {
+      if constexpr (EPI == EPI_H_QKV_NORM) {
+        if (swp) gemm_x2_qknorm_epilogue<TM>(q, acc, mw, nw, lane);
+        else gemm_x2_epilogue<EPI_H_QKV, TM>(q, acc, slab, mw, nw, lane);
+      } else {
+        gemm_x2_epilogue<EPI, TM>(q, acc, slab, mw, nw, lane);
+      }
+    } else if constexpr (EPI == EPI_H_QKV_NORM) {
+      if (swp) gemm_h16_qknorm_epilogue<DT, TM>(q, acc, mw, nw, lane);
+      else gemm_h16_epilogue<EPI_H_QKV, DT, TM>(q, acc, slab, mw, nw, lane);
+    } else {
+      gemm_h16_epilogue<EPI, DT, TM>(q, acc, slab, mw, nw, lane);
+    }
+    return;
+  }
   HG_DMA(0, 0)
   HG_SYNC
   if constexpr (X2) {
@@ -665,7 +749,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 2)) void gemm_h16
 
   // ---------------- epilogue ----------------
   static_assert(TN == 2, "wave tiles are 64 columns wide: one head / one GEGLU value+gate group");
-  static_assert(WM * WN * H16_STG_BYTES + 1024 <= 2 * (BM + BN) * 128, "staging slabs (+ the LN statistics) must fit the operand buffers");
+  static_assert(WM * WN * H16_STG_BYTES + 1024 <= NS * (BM + BN) * 128, "staging slabs (+ the LN statistics) must fit the operand buffers");
   __syncthreads();
   if constexpr (EPI == EPI_H_BIAS_RESID_F32) {
     if (gridDim.y > 1) {
@@ -1165,20 +1249,30 @@ static int launch_php(hipStream_t stream, const GemmParamsH& p) {
 rap_tuning_t g_rap_gemm_h16_variant = 14;
 rap_tuning_t g_rap_gemm_h16_persistent = 1;     // tuning key 11: the persistent phase-split kernel for full-tile shapes (1, default) or one tile per block (0)
 
-template <int EPI, int DT, int WM, int WN, int TM, int TN, bool X2 = false>
-static int launch_cfg(hipStream_t stream, const GemmParamsH& p) {
+template <int EPI, int DT, int WM, int WN, int TM, int TN, bool X2 = false, int NS = 2>
+static int launch_cfg(hipStream_t stream, const GemmParamsH& p, int splits = 1) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  constexpr int LDS = 2 * (BM + BN) * 128;
-  auto kern = gemm_h16_kernel<EPI, DT, WM, WN, TM, TN, X2>;
+  constexpr int LDS = NS * (BM + BN) * 128;
+  auto kern = gemm_h16_kernel<EPI, DT, WM, WN, TM, TN, X2, NS>;
   // per device and cheap: set unconditionally (a process may drive several GPUs)
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
     rap_set_last_hip_error((int)hipGetLastError());
     return RAP_ERR_HIP;
   }
   const int mt = (p.M + BM - 1) / BM;
-  hipLaunchKernelGGL(kern, dim3(mt * (p.N / BN)), dim3(64 * WM * WN), LDS, stream, p);
+  hipLaunchKernelGGL(kern, dim3(mt * (p.N / BN), splits), dim3(64 * WM * WN), LDS, stream, p);
   RAP_LAUNCH_CHECK();
   return RAP_OK;
+}
+
+// The 128 x 128 kernel for few-token calls (round 6): a launch with at most g_rap_ring_blocks blocks (tuning key 18; 0 = never) takes the
+// four-stage ring, one block per CU; larger launches keep two stages and two blocks per CU, whose second block is what hides the latency.
+rap_tuning_t g_rap_ring_blocks = 512;
+template <int EPI, int DT, bool X2 = false>
+static int launch_small(hipStream_t stream, const GemmParamsH& p, int splits = 1) {
+  const long blocks = (long)((p.M + 127) / 128) * (p.N / 128) * splits;
+  if (blocks <= (long)g_rap_ring_blocks) return launch_cfg<EPI, DT, 2, 2, 2, 2, X2, 4>(stream, p, splits);
+  return launch_cfg<EPI, DT, 2, 2, 2, 2, X2, 2>(stream, p, splits);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1234,16 +1328,10 @@ int gemm_h16_splits(int M, int N, int K) { return g_rap_gemm_splitk ? gemm_h16_s
 
 template <int DT>
 static int launch_splitk(hipStream_t stream, int epilogue, const GemmParamsH& p, int splits) {
-  constexpr int LDS = 2 * (128 + 128) * 128;
-  auto kern = gemm_h16_kernel<EPI_H_BIAS_RESID_F32, DT, 2, 2, 2, 2>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-    rap_set_last_hip_error((int)hipGetLastError());
-    return RAP_ERR_HIP;
-  }
   GemmParamsH q = p;
   q.C = p.splitk_ws; q.ldc = p.N; q.bias = nullptr; q.resid = nullptr; q.resid_h = nullptr; q.splitk_ws = nullptr;
-  hipLaunchKernelGGL(kern, dim3(((p.M + 127) / 128) * (p.N / 128), splits), dim3(256), LDS, stream, q);
-  RAP_LAUNCH_CHECK();
+  if (int rc = launch_small<EPI_H_BIAS_RESID_F32, DT>(stream, q, splits)) return rc;
+  if (p.defer_combine) return RAP_OK;      // the caller's combine + LayerNorm pass consumes the planes (launch_resid_combine_ln_h16)
   const long n8 = (long)p.M * (p.N / 8);
   const dim3 grid((unsigned)((n8 + 255) / 256));
   if (epilogue == EPI_H_BIAS_RESID_H16)
@@ -1278,14 +1366,15 @@ static int launch_variant(hipStream_t stream, const GemmParamsH& p) {
   // fewer 256 x 256 tiles than CUs (few-token calls): 128 x 128 tiles, two blocks per CU, fill the chip better -- one pair of
   // 2 x 1024 points x 10 steps 26.6 -> 21.6 ms in bf16, 2 x 4096 x 20 steps 102.5 -> 94.0 ms, unchanged from 4 pairs up (r03 call 31)
   if (big && (long)((p.M + 255) / 256) * (p.N / 256) >= 256) return launch_ph<EPI, DT, 0, 1>(stream, p);
-  return launch_cfg<EPI, DT, 2, 2, 2, 2>(stream, p);
+  return launch_small<EPI, DT>(stream, p);
 }
 
 template <int DT>
 static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
   if ((epilogue == EPI_H_BIAS_RESID_F32 || epilogue == EPI_H_BIAS_RESID_H16) && p.splitk_ws) {
-    const int splits = gemm_h16_splits(p.M, p.N, p.K);
-    if (splits > 1) {
+    const int splits = p.force_splits > 0 ? p.force_splits : gemm_h16_splits(p.M, p.N, p.K);
+    if (splits < 1 || (p.K / 64) % splits != 0) return RAP_ERR_INVALID;
+    if (splits > 1 || p.defer_combine) {      // (defer_combine: partial planes -- one when there is no split -- for the caller's combine + LayerNorm pass)
       if ((p.ldc & 7) || (p.ldr & 7) || (epilogue == EPI_H_BIAS_RESID_H16 && !p.resid_h)) return RAP_ERR_INVALID;
       return launch_splitk<DT>(stream, epilogue, p, splits);
     }
@@ -1300,6 +1389,9 @@ static int launch_dt(hipStream_t stream, int epilogue, const GemmParamsH& p) {
     case EPI_H_QKV_NORM:
       if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256 || !p.gamma_q || !p.gamma_k || p.K < 128) return RAP_ERR_INVALID;
       if (use_persistent(p)) return launch_php<EPI_H_QKV_NORM, DT>(stream, p);
+      // few-token calls (fewer 256 x 256 tiles than CUs): the fused epilogue on 128 x 128 tiles (round 6; the r03 note in api.hip: GEMM + qk-norm as
+      // two kernels used to win there because the fused form existed only in the 256 x 256 kernels)
+      if ((long)((p.M + 255) / 256) * (p.N / 256) < 256) return launch_small<EPI_H_QKV_NORM, DT>(stream, p);
       return launch_ph<EPI_H_QKV_NORM, DT, 0, 1>(stream, p);
     case EPI_H_QKV:
       if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256) return RAP_ERR_INVALID;
@@ -1326,16 +1418,10 @@ static int launch_x2_variant(hipStream_t stream, const GemmParamsH& p) {
 // residual + (bias + partials) in a fixed order (gemm_h16_splits_by_shape on the physical K; tuning key 6).
 static bool x2_small(const GemmParamsH& p) { return (long)((p.M + 255) / 256) * (p.N / 256) < 256; }
 static int launch_x2_splitk(hipStream_t stream, const GemmParamsH& p, int splits) {
-  constexpr int LDS = 2 * (128 + 128) * 128;
-  auto kern = gemm_h16_kernel<EPI_H_BIAS_RESID_F32, RAP_DT_F16, 2, 2, 2, 2, true>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-    rap_set_last_hip_error((int)hipGetLastError());
-    return RAP_ERR_HIP;
-  }
   GemmParamsH q = p;
   q.C = p.splitk_ws; q.ldc = p.N; q.bias = nullptr; q.resid = nullptr; q.splitk_ws = nullptr;      // (acc_scale stays: the partials are in true units)
-  hipLaunchKernelGGL(kern, dim3(((p.M + 127) / 128) * (p.N / 128), splits), dim3(256), LDS, stream, q);
-  RAP_LAUNCH_CHECK();
+  if (int rc = launch_small<EPI_H_BIAS_RESID_F32, RAP_DT_F16, true>(stream, q, splits)) return rc;
+  if (p.defer_combine) return RAP_OK;
   const long n8 = (long)p.M * (p.N / 8);
   hipLaunchKernelGGL(gemm_h16_splitk_combine_kernel<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, p.splitk_ws, splits, p.M, p.N,
                      p.bias, (const void*)p.resid, p.ldr, p.C, p.ldc);
@@ -1347,21 +1433,22 @@ static int launch_x2(hipStream_t stream, int epilogue, const GemmParamsH& p) {
   switch (epilogue) {
     case EPI_H_BIAS_RESID_F32:
       if (p.splitk_ws) {
-        const int splits = gemm_h16_splits(p.M, p.N, p.K);
-        if (splits > 1) {
+        const int splits = p.force_splits > 0 ? p.force_splits : gemm_h16_splits(p.M, p.N, p.K);
+        if (splits < 1 || (p.K / 64) % splits != 0) return RAP_ERR_INVALID;
+        if (splits > 1 || p.defer_combine) {
           if ((p.ldc & 7) || (p.ldr & 7)) return RAP_ERR_INVALID;
           return launch_x2_splitk(stream, p, splits);
         }
       }
-      if (x2_small(p)) return launch_cfg<EPI_H_BIAS_RESID_F32, RAP_DT_F16, 2, 2, 2, 2, true>(stream, p);
+      if (x2_small(p)) return launch_small<EPI_H_BIAS_RESID_F32, RAP_DT_F16, true>(stream, p);
       return launch_x2_variant<EPI_H_BIAS_RESID_F32>(stream, p);
     case EPI_H_GEGLU:
       if (p.ldc & 7) return RAP_ERR_INVALID;
-      if (x2_small(p)) return launch_cfg<EPI_H_GEGLU, RAP_DT_F16, 2, 2, 2, 2, true>(stream, p);
+      if (x2_small(p)) return launch_small<EPI_H_GEGLU, RAP_DT_F16, true>(stream, p);
       return launch_x2_variant<EPI_H_GEGLU>(stream, p);
     case EPI_H_QKV_NORM:
       if (p.N != 3 * p.heads * 64 || !p.vt || p.vt_nblk * 64 < (p.M + 255) / 256 * 256 || ((p.gamma_q == nullptr) != (p.gamma_k == nullptr))) return RAP_ERR_INVALID;
-      if (x2_small(p)) return launch_cfg<EPI_H_QKV_NORM, RAP_DT_F16, 2, 2, 2, 2, true>(stream, p);
+      if (x2_small(p)) return launch_small<EPI_H_QKV_NORM, RAP_DT_F16, true>(stream, p);
       return launch_x2_variant<EPI_H_QKV_NORM>(stream, p);
     default: return RAP_ERR_INVALID;
   }

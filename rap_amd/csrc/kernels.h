@@ -135,6 +135,10 @@ struct GemmParamsH {
   // gemm_h16_splits() > 1, K is split over that many blocks per 128 x 128 tile (gridDim.y) writing fp32 partial tiles to splitk_ws, and a
   // combine pass forms residual + (bias + partials) in a fixed order (deterministic; differs from the unsplit sum in fp32 rounding only)
   float* splitk_ws = nullptr;
+  // round 6, few-token calls: leave the `splits` (>= 1: force_splits, else gemm_h16_splits) partial planes in splitk_ws and skip the combine
+  // pass -- the caller's launch_resid_combine_ln_h16 forms the new residual-stream value AND the following LayerNorm from them
+  int defer_combine = 0;
+  int force_splits = 0;
   // RAP_DT_F32X2 (split precision): the weight planes are stored multiplied by a power of two (their tails stay normal fp16 numbers);
   // every epilogue multiplies the accumulators by acc_scale = its inverse (exact) first
   float acc_scale = 1.0f;
@@ -160,6 +164,9 @@ int launch_layernorm_mod_h16(hipStream_t stream, int dtype, const void* x, int x
                              long mod_stride, const int32_t* token_row);
 int launch_layernorm_affine_h16(hipStream_t stream, int dtype, const void* x, int x_f16, uint16_t* out, int TP, int d,
                                 const float* gain, const float* shift);
+int launch_resid_combine_ln_h16(hipStream_t stream, int dtype, const float* part, int splits, const float* bias, void* h, int h_f16, uint16_t* out,
+                                int rows, int d, const float* mod, long mod_stride, const int32_t* token_row, const float* gain,
+                                const float* shift);
 int launch_convert_f16_to_f32(hipStream_t stream, const uint16_t* src, float* dst, size_t n);
 int launch_convert_f16_sat(hipStream_t stream, const float* src, uint16_t* dst, size_t n);    // fp32 -> fp16, saturating at +-65504
 // q_mul: factor of the q plane (8 = the reference's sqrt(Dh); RAP_QMUL_PRESCALED = log2(e) for the pre-scaled attention path)
