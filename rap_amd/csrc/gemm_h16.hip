@@ -495,7 +495,8 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 2 ? 1 : 2)) void gemm_h16_kerne
   const int wm = wave / WN, wn = wave % WN;
 
   const int nt = p.N / BN;
-  const int mt = (p.M + BM - 1) / BM;
+  // (the fused QKV epilogue owns the V^T image up to align_up(M, 256) token rows -- zeros beyond M, as the 256-row kernels leave it)
+  const int mt = EPI == EPI_H_QKV_NORM ? ((p.M + 255) / 256) * (256 / BM) : (p.M + BM - 1) / BM;
   const int logical = xcd_remap(blockIdx.x, mt * nt);
   const int m0 = (logical / nt) * BM;
   const int n0 = (logical % nt) * BN;
@@ -596,11 +597,49 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 2 ? 1 : 2)) void gemm_h16_kerne
 #pragma unroll
       for (int s_ = 0; s_ < NS - 1; ++s_)
         if (s_ < nk) { HG_DMA(s_, s_) }
+      if constexpr (NS > 2) {
+        // The fragments of tile t + 1 are read while tile t multiplies (two register sets, the loop unrolled by two): with one wave per SIMD
+        // and one barrier per k-tile all four waves would otherwise read (16 ds_read_b128 each) and multiply in lockstep, LDS pipe and
+        // matrix pipe taking turns (r06 call 1: 0.65 us per split-precision k-tile against 0.37 us of MFMA issue).  At the barrier of
+        // iteration t tile t + 1 is visible, tile t is in registers (its reads may still be in flight: its buffer is not reused before the
+        // NEXT barrier), tile t - 1 is consumed and its buffer takes the DMA of tile t + NS - 1; NS - 3 younger tiles stay in flight.
+        if (NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (CA + CB)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        Frag fa[4], fb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) read_frag(fa[g], 0, g);
+        auto mul = [&](Frag (&fc)[4]) __attribute__((always_inline)) {
+          if constexpr (X2) {
+            mm(fc[2], fc[0]); mm(fc[0], fc[2]); mm(fc[3], fc[1]); mm(fc[1], fc[3]);      // (tail, head), (head, tail) of both k-steps
+            mm(fc[0], fc[0]); mm(fc[1], fc[1]);                                          // (head, head)
+          } else {
+            mm(fc[0], fc[0]); mm(fc[1], fc[1]); mm(fc[2], fc[2]); mm(fc[3], fc[3]);
+          }
+        };
+        // a step with a successor tile (the last tile is peeled off below: a step whose barrier is conditional makes the compiler's
+        // waitcnt pass wait for the NEW fragment reads in front of the MFMAs on the path that has them)
+        auto step = [&](Frag (&fc)[4], Frag (&fn)[4], int kt) __attribute__((always_inline)) {
+          if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * (CA + CB)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (kt + NS - 1 < nk) { HG_DMA(kt + NS - 1, (kt + NS - 1) & (NS - 1)) }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) read_frag(fn[g], (kt + 1) & (NS - 1), g);
+          mul(fc);
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; kt += 2) {
+          step(fa, fb, kt);
+          step(fb, fa, kt + 1);
+        }
+        if (kt + 1 < nk) { step(fa, fb, kt); mul(fb); }
+        else mul(fa);
+        return;
+      }
       for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & (NS - 1);
-        // tile kt has landed once at most the NS - 2 younger tiles are outstanding (loads retire in order); near the end fewer are in flight
-        if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (CA + CB)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // NS == 2: tile kt is the only one outstanding
         __syncthreads();                    // tile kt visible to every wave; every wave is done with tile kt - 1, whose buffer the next DMA takes
         if (kt + NS - 1 < nk) { HG_DMA(kt + NS - 1, (kt + NS - 1) & (NS - 1)) }
         if constexpr (X2) {
@@ -1259,7 +1298,7 @@ static int launch_cfg(hipStream_t stream, const GemmParamsH& p, int splits = 1) 
     rap_set_last_hip_error((int)hipGetLastError());
     return RAP_ERR_HIP;
   }
-  const int mt = (p.M + BM - 1) / BM;
+  const int mt = EPI == EPI_H_QKV_NORM ? ((p.M + 255) / 256) * (256 / BM) : (p.M + BM - 1) / BM;
   hipLaunchKernelGGL(kern, dim3(mt * (p.N / BN), splits), dim3(64 * WM * WN), LDS, stream, p);
   RAP_LAUNCH_CHECK();
   return RAP_OK;
@@ -1267,7 +1306,7 @@ static int launch_cfg(hipStream_t stream, const GemmParamsH& p, int splits = 1) 
 
 // The 128 x 128 kernel for few-token calls (round 6): a launch with at most g_rap_ring_blocks blocks (tuning key 18; 0 = never) takes the
 // four-stage ring, one block per CU; larger launches keep two stages and two blocks per CU, whose second block is what hides the latency.
-rap_tuning_t g_rap_ring_blocks = 512;
+rap_tuning_t g_rap_ring_blocks = 256;
 template <int EPI, int DT, bool X2 = false>
 static int launch_small(hipStream_t stream, const GemmParamsH& p, int splits = 1) {
   const long blocks = (long)((p.M + 127) / 128) * (p.N / 128) * splits;

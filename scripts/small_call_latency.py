@@ -23,9 +23,9 @@ def arg(name, default):
     return default
 
 
-VARIANTS = {"r6": {18: 512, 19: 1, 7: 1}, "r5": {18: 0, 19: 0, 7: 1}, "ring-only": {18: 512, 19: 0, 7: 1}, "fused-only": {18: 0, 19: 1, 7: 1},
-            "ring256": {18: 256, 19: 1, 7: 1}, "ring1024": {18: 1024, 19: 1, 7: 1}, "ring4096": {18: 4096, 19: 1, 7: 1},
-            "unfused-qknorm": {18: 512, 19: 1, 7: 0}}
+VARIANTS = {"r6": {18: 256, 19: 1, 7: 1}, "r5": {18: 0, 19: 0, 7: 0}, "ring-only": {18: 256, 19: 0, 7: 1}, "fused-only": {18: 0, 19: 1, 7: 1},
+            "ring512": {18: 512, 19: 1, 7: 1}, "ring1024": {18: 1024, 19: 1, 7: 1}, "ring4096": {18: 4096, 19: 1, 7: 1},
+            "unfused-qknorm": {18: 256, 19: 1, 7: 0}}
 dev = torch.device("cuda:0")
 lib = _lib.load()
 cfg = dict(S.RAP_12)

@@ -48,15 +48,20 @@ def test_ring_and_fused_combine_layernorm_are_bit_identical_to_the_round5_launch
     outs = {}
     try:
         assert lib.rap_set_tuning(17, 0) == 0                      # split precision at every size (small calls default to exact fp32)
-        for tag, ring, fused in (("r6", 512, 1), ("ring-only", 512, 0), ("fused-only", 0, 1), ("r5", 0, 0)):
+        for tag, ring, fused in (("r6", 256, 1), ("ring-only", 256, 0), ("fused-only", 0, 1), ("r5", 0, 0)):
             assert lib.rap_set_tuning(18, ring) == 0 and lib.rap_set_tuning(19, fused) == 0
             outs[tag], ctx = _sample(dev, cdt, rdt, parts)
     finally:
-        assert lib.rap_set_tuning(18, 512) == 0 and lib.rap_set_tuning(19, 1) == 0 and lib.rap_set_tuning(17, 1024) == 0
+        assert lib.rap_set_tuning(18, 256) == 0 and lib.rap_set_tuning(19, 1) == 0 and lib.rap_set_tuning(17, 1024) == 0
     for tag in ("r6", "ring-only", "fused-only"):
         for k, v in outs["r5"].items():
             assert not torch.isnan(v).any()
-            assert torch.equal(outs[tag][k], v), (tag, k, float((outs[tag][k] - v).abs().max()))
+            if cdt == "float32x2" and tag != "ring-only":
+                # split precision: the fused sequence ALSO splits K of the out-projection (physical K = 1024; round 5 split ff2 only), so the
+                # k-sum is re-associated there: fp32-class agreement instead of bit identity
+                assert float((outs[tag][k] - v).abs().max()) < 5e-6, (tag, k)
+            else:
+                assert torch.equal(outs[tag][k], v), (tag, k, float((outs[tag][k] - v).abs().max()))
     # ... and the result is the function the oracle computes (fp32 class for split precision, the 16-bit deviation class otherwise)
     sd, cfg, inp = ctx
     ref = O.sample(sd, cfg, inp, 3, True)
