@@ -468,9 +468,16 @@ def launcher_selftest(args, world, rank, json_out):
     dist.init_process_group(backend="gloo")
     assert dist.get_world_size() == args.gpus == world
     strong = getattr(args, "scaling", "weak") == "strong"
+    ragged = strong and args.workload == "ragged"
     if strong:
+        from rap_amd import synthetic as S
         from rap_amd.parallel import shard_by_cost
-        mine = shard_by_cost([[args.points] * args.views for _ in range(args.batch)], world)[rank]
+        job = S.ragged_regime_parts(args.ragged_points, seed=4321) if ragged else [[args.points] * args.views for _ in range(args.batch)]
+        job_points = [sum(p) for p in job]
+        assignment = shard_by_cost(job, world)
+        mine = assignment[rank]
+        if not mine:
+            raise SystemExit(f"rank {rank}: the job has {len(job)} samples for {world} ranks -- nothing to do on this rank")
         nb = len(mine)
     else:
         mine = shard_range(args.batch * world, world, rank)
@@ -479,27 +486,31 @@ def launcher_selftest(args, world, rank, json_out):
     per = args.views * args.points
     n = nb * per
     t0 = time.perf_counter()
+    pmax = max(len(p) for p in job) if strong else args.views          # parts per sample (pose rows are padded to it, as the collate does)
     for _ in range(args.warmup + args.steps):
-        final = torch.cat([torch.full((per, 3), float(i)) for i in mine]) if strong else torch.full((n, 3), float(rank))
-        R = torch.eye(3).repeat(nb, args.views, 1, 1) * (rank + 1)
-        t = torch.full((nb, args.views, 3), float(rank))
-        if strong:
-            cu = torch.arange(nb + 1, dtype=torch.int64) * per
-            g = gather_registrations(final, R, t, sample_ids=list(mine), cu_seqlens=cu)
+        final = torch.cat([torch.full((job_points[i], 3), float(i)) for i in mine]) if strong else torch.full((n, 3), float(rank))
+        R = torch.eye(3).repeat(nb, pmax, 1, 1) * (rank + 1)
+        t = torch.full((nb, pmax, 3), float(rank))
+        if strong:      # the shard plan is known on every rank: ONE collective, no size / id exchange
+            g = gather_registrations(final, R, t, plan=(assignment, job_points))
         else:
             g = gather_registrations(final, R, t, equal_shapes=True)
     dist.barrier()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     allt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(allt, elapsed)
-    if strong:      # the gathered job is in SAMPLE order whatever the assignment: pair i's rows carry the value i
-        ok = g[0].shape[0] == args.batch * per and all(bool((g[0][i * per:(i + 1) * per] == float(i)).all()) for i in range(args.batch))
+    if strong:      # the gathered job is in SAMPLE order whatever the assignment: sample i's rows carry the value i
+        starts = [0]
+        for c in job_points:
+            starts.append(starts[-1] + c)
+        ok = g[0].shape[0] == starts[-1] and g[1].shape[0] == len(job) and all(bool((g[0][starts[i]:starts[i + 1]] == float(i)).all()) for i in range(len(job)))
     else:
         ok = all(bool((g[0][r * n:(r + 1) * n] == float(r)).all()) for r in range(world)) and g[0].shape[0] == n * world
     if rank == 0:
         print(json.dumps({"metric": "launcher-selftest (stub sampler, gloo, CPU): NOT a measurement", "value": None, "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "stub": True, "rccl_ranks": world,
-                          "pairs_total": args.batch if strong else args.batch * world, "scaling": "strong" if strong else "weak",
+                          "pairs_total": len(job) if strong else args.batch * world, "scaling": "strong" if strong else "weak",
+                          "workload": "ragged" if ragged else "uniform", "samples_per_rank": [len(a) for a in assignment] if strong else [args.batch] * world,
                           "gather_ok": ok, "per_rank": {"elapsed_s": [float(x) for x in allt]}}), file=json_out, flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -556,7 +567,7 @@ def main():
             if strong:
                 job = S.ragged_regime_parts(args.ragged_points, seed=4321)
                 assign = shard_by_cost(job, world, num_layers=args.layers)
-                shard_info.update(job_parts=job, assignment=assign, imbalance=cost_imbalance(job, assign, args.layers))
+                shard_info.update(job_parts=job, assignment=assign, imbalance=cost_imbalance(job, assign, args.layers), job_points=[sum(p) for p in job])
                 mine = assign[rank]
                 if not mine:
                     raise SystemExit(f"rank {rank}: the ragged job has {len(job)} samples for {world} ranks -- nothing to do on this rank")
@@ -568,7 +579,7 @@ def main():
         elif strong:
             job = [[args.points] * args.views for _ in range(args.batch)]
             assign = shard_by_cost(job, world, num_layers=args.layers)
-            shard_info.update(job_parts=job, assignment=assign, imbalance=cost_imbalance(job, assign, args.layers))
+            shard_info.update(job_parts=job, assignment=assign, imbalance=cost_imbalance(job, assign, args.layers), job_points=[sum(p) for p in job])
             mine = assign[rank]
             if not mine:
                 raise SystemExit(f"rank {rank}: --batch {args.batch} pairs for {world} ranks -- nothing to do on this rank")
@@ -629,7 +640,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 if strong:      # ranks hold different sample sets (cost-balanced, not contiguous): gather back into the job's sample order
-                    g = gather_registrations(final, out["R"], out["t"], sample_ids=shard_info["assignment"][rank], cu_seqlens=data["cu_seqlens"])
+                    g = gather_registrations(final, out["R"], out["t"], plan=(shard_info["assignment"], shard_info["job_points"]))
                 else:
                     g = gather_registrations(final, out["R"], out["t"], equal_shapes=True)
                 e1.record()

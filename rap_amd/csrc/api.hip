@@ -160,8 +160,8 @@ rap_tuning_t g_rap_attn_lpt = 1;               // tuning key 15: attention work 
 // 1 024 tokens 71 vs 89 ms, 2 048: 92 vs 99, 4 096: 197 vs 124, 8 000: 459 vs 197; call 5, with the residual GEMMs of few-token calls on
 // 128 x 128 split-precision tiles: 2 048 tokens 92 vs 81 ms, 2 560: 149 vs 86, 3 072: 169 vs 91; call 9, with every few-token GEMM on
 // 128 x 128 tiles, split-K of ff2 and split-KV attention: 1 024 tokens 71 vs 46 ms, 2 048: 92 vs 54, configs[0] geometry 48.4 vs 28.0 ms --
-// split precision wins at every size measured; calls below 1 024 rows (not measured) stay on the fp32 kernels).  The two layouts need the same workspace
-// bytes (two 16-bit planes per value = one fp32).
+// split precision wins at every size measured; calls below 1 024 rows (not measured) stay on the fp32 kernels).  rap_workspace_bytes of a
+// split-precision model covers both layouts, so the key may change between the size query and the call.
 rap_tuning_t g_rap_x2_min_rows = 1024;
 rap_tuning_t g_rap_small_fused = 1;            // tuning key 19: few-token 16-bit / split-precision calls fold every residual GEMM's combine pass into the following LayerNorm (1, default)
 extern rap_tuning_t g_rap_ring_blocks;         // gemm_h16.hip, tuning key 18: launches of the 128 x 128 16-bit GEMM with at most this many blocks take the four-stage ring
@@ -362,9 +362,11 @@ static int build_x2_weights(rap_model* m, hipStream_t stream) {
   std::vector<const u16*> planes(nt);
   std::vector<float> inv(nt);
   for (int k = 0; k < nt && rc == RAP_OK; ++k) {
-    // largest magnitude * 2^e in (2^11, 2^12]; an all-zero (or non-finite) tensor keeps e = 0
+    // largest magnitude * 2^e in (2^11, 2^12]; an all-zero tensor keeps e = 0
+    // a NaN / Inf weight would silently become +-65 504 in the planes (saturating split): refuse the model instead
+    if (!(hmax[k] < 3.0e38f)) return fail(RAP_ERR_INVALID);
     int e = 0;
-    if (hmax[k] > 0.f && hmax[k] < 3.0e38f) { int ex; (void)frexpf(hmax[k], &ex); e = 12 - ex; }
+    if (hmax[k] > 0.f) { int ex; (void)frexpf(hmax[k], &ex); e = 12 - ex; }
     e = e > 60 ? 60 : e < -60 ? -60 : e;
     inv[k] = ldexpf(1.0f, -e);
     planes[k] = q;
@@ -468,12 +470,14 @@ struct Workspace {
   double* proc_partials;
   int32_t *token_sample, *part_offsets, *attn_sort;
   int32_t *cu_batch_s, *cu_part_s;      // sanitised copies of the caller's segment tables (clamped to [0, TP], non-decreasing)
+  const int32_t* cu_part_live;          // the part table the attention work lists were built from (part_offsets in rap_sample, cu_part_s in rap_dit_forward)
+  int nseg_part, nseg_batch;            // segments in the two tables
   AttnWorkItem *items_batch, *items_part;
   int max_items_batch, max_items_part;
   size_t total;
 };
 
-static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg_part, int rows, char* basep) {
+static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg_part, int rows, char* basep, int force_dtype = -1) {
   Workspace w;
   const size_t d = m->d, L = m->L;
   size_t off = 0;
@@ -484,7 +488,7 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   // ranges stop at the true segment ends).  See forward_step.
   const size_t T = align_up((size_t)TP, 256);
   w.rows = (int)T;
-  const int dtype = w.dtype = eff_dtype(m, T);
+  const int dtype = w.dtype = force_dtype >= 0 ? force_dtype : eff_dtype(m, T);
   w.qk_norm = m->qk_norm;
   w.base = (float*)take(T * d * 4);
   const bool x2 = dtype == RAP_DT_F32X2;    // split precision: fp32 residual stream, every 16-bit activation buffer holds heads AND tails
@@ -527,6 +531,7 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   w.part_offsets = (int32_t*)take(((size_t)nseg_part + 1) * 4);
   w.cu_batch_s = (int32_t*)take(((size_t)B + 1) * 4);
   w.cu_part_s = (int32_t*)take(((size_t)nseg_part + 1) * 4);
+  w.cu_part_live = w.part_offsets; w.nseg_part = nseg_part; w.nseg_batch = B;
   w.max_items_batch = (int)(TP / RAP_ATTN_BQ) + B + 1;
   w.max_items_part = (int)(TP / RAP_ATTN_BQ) + nseg_part + 1;
   w.items_batch = (AttnWorkItem*)take((size_t)w.max_items_batch * sizeof(AttnWorkItem));
@@ -542,6 +547,15 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
 extern "C" size_t rap_workspace_bytes(const rap_model* m, int64_t TP, int32_t B, int32_t nseg_part, int32_t rows) {
   if (!m || TP < 0 || B < 0 || nseg_part < 0 || rows < 0) return 0;
   std::lock_guard<std::mutex> lock(m->cfg_mu);
+  // A split-precision model runs calls below tuning key 17's threshold on the exact-fp32 kernels, and the two layouts differ in size (the
+  // split layout adds the split-K planes of few-token calls).  The size reported covers BOTH, so that a change of the process-global
+  // threshold between this query and the call -- __graft_entry__.smoke() and the tests do toggle it -- cannot turn a valid call into
+  // RAP_ERR_WORKSPACE (the comment here used to claim the two layouts need the same bytes).
+  if (m->dtype == RAP_DT_F32X2) {
+    const size_t a = carve_workspace(m, TP, B, nseg_part, rows, nullptr, RAP_DT_F32).total;
+    const size_t b = carve_workspace(m, TP, B, nseg_part, rows, nullptr, RAP_DT_F32X2).total;
+    return a > b ? a : b;
+  }
   return carve_workspace(m, TP, B, nseg_part, rows, nullptr).total;
 }
 
@@ -649,7 +663,8 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
           const int max_items = a == 0 ? w.max_items_part : w.max_items_batch;
           const int splits = attention_x2_splits(max_items, H);
           rc = launch_attention_x2(stream, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch, max_items,
-                                   reinterpret_cast<float*>(w.ffmidh), reinterpret_cast<float*>(w.xnh), splits, TP_valid);
+                                   reinterpret_cast<float*>(w.ffmidh), reinterpret_cast<float*>(w.xnh), splits, TP_valid,
+                                   a == 0 ? w.cu_part_live : w.cu_batch_s, a == 0 ? w.nseg_part : w.nseg_batch);
         }
         if (rc) return rc;
         GemmParamsH o{};
@@ -782,7 +797,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         const int max_items = a == 0 ? w.max_items_part : w.max_items_batch;
         const int splits = attention_f32_splits(max_items, H, bound != nullptr);
         rc = launch_attention_f32(stream, w.qkv, w.att, TP, H, a == 0 ? w.items_part : w.items_batch, max_items, bound, w.ffmid, w.xn,
-                                  splits);
+                                  splits, a == 0 ? w.cu_part_live : w.cu_batch_s, a == 0 ? w.nseg_part : w.nseg_batch);
       }
       if (rc) return rc;
       GemmParams o{};
@@ -846,6 +861,7 @@ extern "C" int rap_dit_forward(const rap_model* m, const float* x_t, const float
   Workspace w;
   { std::lock_guard<std::mutex> lock(m->cfg_mu); w = carve_workspace(m, TP, B, VP, B, (char*)ws); }
   if (w.total > ws_bytes) return RAP_ERR_WORKSPACE;
+  w.cu_part_live = w.cu_part_s;             // prepare_static sanitises the caller's part table into it
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
   if ((rc = prepare_static(m, w, stream, cond, feat, scales, anchor, cu_batch, cu_part, B, VP, (int)TP))) return rc;
@@ -1002,8 +1018,17 @@ extern "C" int rap_geglu_interleave(const float* W, const float* b, float* Wp, f
   return launch_geglu_interleave((hipStream_t)stream, W, b, Wp, bp, inner, K);
 }
 
+// [work items | sanitised copy of the caller's cu_seqlens]: the kernel-level attention entry points index with the copy only (ADVICE r05:
+// an entry above TP in the caller's table made seg_start + q run past the planes; the model path has sanitised its tables since round 5)
+static size_t attn_items_bytes(int64_t TP, int32_t nseg) { return align_up(((size_t)(TP / RAP_ATTN_BQ) + (size_t)nseg + 1) * sizeof(AttnWorkItem), 256); }
 extern "C" size_t rap_attention_workspace_bytes(int64_t TP, int32_t nseg) {
-  return ((size_t)(TP / RAP_ATTN_BQ) + (size_t)nseg + 1) * sizeof(AttnWorkItem);
+  return attn_items_bytes(TP, nseg) + align_up(((size_t)nseg + 1) * sizeof(int32_t), 256);
+}
+// -> device pointer to the clamped, non-decreasing copy of cu_seqlens inside ws
+static int attn_ws_sanitize(hipStream_t stream, const int32_t* cu_seqlens, int32_t nseg, int64_t TP, void* ws, const int32_t** cu_out) {
+  int32_t* cu_s = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + attn_items_bytes(TP, nseg));
+  *cu_out = cu_s;
+  return launch_sanitize_cu(stream, cu_seqlens, nseg + 1, (long)TP, cu_s);
 }
 
 // the work list of one attention launch as rap_sample / rap_dit_forward build it: one {seg_start, seg_len, q0, 0} item per
@@ -1023,6 +1048,7 @@ extern "C" int rap_attention_f32(const float* qkv_headmajor, const int32_t* cu_s
   const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
+  if ((rc = attn_ws_sanitize(stream, cu_seqlens, nseg, TP, ws, &cu_seqlens))) return rc;
   if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, 0))) return rc;
   return launch_attention_f32(stream, qkv_headmajor, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound, nullptr, nullptr, 1);
 }
@@ -1101,6 +1127,7 @@ extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16
   const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
+  if ((rc = attn_ws_sanitize(stream, cu_seqlens, nseg, TP, ws, &cu_seqlens))) return rc;
   if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, attention_h16_block_queries(dtype)))) return rc;
   return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound, 0);
 }
@@ -1146,6 +1173,7 @@ extern "C" int rap_x2_attention(const uint16_t* qk, const uint16_t* vt, int32_t 
   const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
+  if ((rc = attn_ws_sanitize(stream, cu_seqlens, nseg, TP, ws, &cu_seqlens))) return rc;
   if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, 256))) return rc;
   return launch_attention_x2(stream, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items);
 }

@@ -426,12 +426,17 @@ int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, in
 
 // out[t][c] = sum_s part_o[s][t][c] / sum_s part_l[s][t][head(c)]   (one thread per 4 columns)
 __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_l,
-                                                                float* __restrict__ out, int TP, int heads, int splits) {
+                                                                float* __restrict__ out, int TP, int heads, int splits,
+                                                                const int32_t* __restrict__ cover_cu, int cover_nseg) {
   const int dmodel = heads * 64;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;           // float4 index
   if (i >= (long)TP * dmodel / 4) return;
   const long t = i / (dmodel / 4);
   const int c = (int)(i % (dmodel / 4)) * 4;
+  if (cover_cu && (t < cover_cu[0] || t >= cover_cu[cover_nseg])) {      // no block wrote partials for this row (filler rows, rows outside every segment)
+    *reinterpret_cast<float4*>(out + t * dmodel + c) = float4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
   float4 acc = {0.f, 0.f, 0.f, 0.f};
   float l = 0.f;
   for (int s = 0; s < splits; ++s) {
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __r
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     l += part_l[((size_t)s * TP + t) * heads + (c >> 6)];
   }
-  const float inv = 1.0f / l;
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
   acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
   *reinterpret_cast<float4*>(out + t * dmodel + c) = acc;
 }
@@ -453,7 +458,8 @@ int attention_f32_splits(int max_items, int heads, bool bounded) {
 }
 
 int launch_attention_f32(hipStream_t stream, const float* qkv, float* out, int TP, int heads, const AttnWorkItem* items,
-                         int max_items, const float* bound, float* part_o, float* part_l, int splits) {
+                         int max_items, const float* bound, float* part_o, float* part_l, int splits, const int32_t* cover_cu,
+                         int cover_nseg) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0) return RAP_ERR_INVALID;
   if (splits > 1) {
@@ -476,7 +482,7 @@ int launch_attention_f32(hipStream_t stream, const float* qkv, float* out, int T
     RAP_LAUNCH_CHECK();
     const long n4 = (long)TP * heads * 16;
     hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, part_o, part_l, out, TP,
-                       heads, splits);
+                       heads, splits, cover_cu, cover_nseg);
     RAP_LAUNCH_CHECK();
     return RAP_OK;
   }

@@ -290,13 +290,22 @@ extern rap_tuning_t g_rap_attn_split;    // attn_f32.hip, tuning key 5: split fe
 
 // one thread per (token, 8 consecutive head dims): merge the key-range partials, normalise, write the head / tail planes
 __global__ __launch_bounds__(256) void attention_x2_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                                   u16* __restrict__ out, int TP, int n_tokens, int heads, int splits) {
+                                                                   u16* __restrict__ out, int TP, int n_tokens, int heads, int splits,
+                                                                   const int32_t* __restrict__ cover_cu, int cover_nseg) {
   const int dmodel = heads * 64;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)n_tokens * (dmodel / 8)) return;
   const long t = i / (dmodel / 8);
   const int c = (int)(i % (dmodel / 8)) * 8;                  // logical column: head = c >> 6, dims (c & 63) .. +7 (inside one 32-dim chunk)
   const int head = c >> 6;
+  u16* dst = out + (size_t)t * (heads * 128) + head * 128 + ((c & 63) >> 5) * 64 + (c & 31);
+  // a token outside every segment (an inconsistent table whose sanitised copy ends below n_tokens) has no partials: zeros, as the
+  // unsplit kernel leaves such rows (the stale bytes of the aliased buffers used to be normalised by 1 / l = 1 / garbage)
+  if (cover_cu && (t < cover_cu[0] || t >= cover_cu[cover_nseg])) {
+    *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(dst + 32) = make_uint4(0, 0, 0, 0);
+    return;
+  }
   const float cexp = 0.125f * 1.44269504088896340736f;
   float m = -1e30f;
   for (int s = 0; s < splits; ++s) m = fmaxf(m, part_ml[(((size_t)s * TP + t) * heads + head) * 2]);
@@ -310,10 +319,9 @@ __global__ __launch_bounds__(256) void attention_x2_combine_kernel(const float* 
     const float4 a1 = *reinterpret_cast<const float4*>(part_o + ((size_t)s * TP + t) * dmodel + c + 4);
     acc += f32x8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w} * w;
   }
-  const float inv = 1.0f / l;
+  const float inv = l > 0.f ? 1.0f / l : 0.f;      // (every key range of a covered token saw at least one key: l > 0 there)
   x2_t8 h8, l8;
   x2_split8_nosat(acc * inv, h8, l8);
-  u16* dst = out + (size_t)t * (heads * 128) + head * 128 + ((c & 63) >> 5) * 64 + (c & 31);
   *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, h8);
   *reinterpret_cast<uint4*>(dst + 32) = __builtin_bit_cast(uint4, l8);
 }
@@ -327,7 +335,8 @@ int attention_x2_splits(int max_items, int heads) {
 
 // part_o: splits x TP x heads*64 floats, part_ml: splits x TP x heads x 2 floats (splits > 1 only)
 int launch_attention_x2(hipStream_t stream, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP, int heads,
-                        const AttnWorkItem* items, int max_items, float* part_o, float* part_ml, int splits, int n_tokens) {
+                        const AttnWorkItem* items, int max_items, float* part_o, float* part_ml, int splits, int n_tokens,
+                        const int32_t* cover_cu, int cover_nseg) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0 || vt_nblk * 64 < TP) return RAP_ERR_INVALID;
   constexpr int LDS = 2 * 4 * XSUB * 2;      // 64 KB
@@ -346,7 +355,8 @@ int launch_attention_x2(hipStream_t stream, const u16* qk, const u16* vt, int vt
     // the zeros prepare_static put there (they must stay finite: masked keys multiply their V column by p = 0)
     const int nt = n_tokens > 0 && n_tokens < TP ? n_tokens : TP;
     const long n8 = (long)nt * heads * 8;
-    hipLaunchKernelGGL(attention_x2_combine_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, part_o, part_ml, out, TP, nt, heads, splits);
+    hipLaunchKernelGGL(attention_x2_combine_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, part_o, part_ml, out, TP, nt, heads, splits,
+                       cover_cu, cover_nseg);
     RAP_LAUNCH_CHECK();
     return RAP_OK;
   }

@@ -53,8 +53,11 @@ int launch_build_attn_worklist(hipStream_t stream, const int32_t* cu_seqlens, in
 // bound: optional per-head upper bounds (device, H floats) on the logits q.k/8 -> bounded-softmax instantiation
 // splits > 1 (few-token calls, needs bound): key ranges per work item, partial O in part_o [splits][TP][heads*64] and partial row
 // sums in part_l [splits][TP][heads], then one combine pass.  attention_f32_splits() picks the count for a work list (1-4).
+// cover_cu / cover_nseg (splits > 1): the (sanitised) segment table the work list was built from -- the combine pass writes ZEROS for
+// rows outside [cu[0], cu[nseg]), which no block produced partials for (it used to normalise stale workspace bytes there)
 int launch_attention_f32(hipStream_t stream, const float* qkv_headmajor, float* out, int TP, int heads,
-                         const AttnWorkItem* items, int max_items, const float* bound, float* part_o, float* part_l, int splits);
+                         const AttnWorkItem* items, int max_items, const float* bound, float* part_o, float* part_l, int splits,
+                         const int32_t* cover_cu = nullptr, int cover_nseg = 0);
 int attention_f32_splits(int max_items, int heads, bool bounded);
 
 // ---------------------------------------------------------------------------------------------
@@ -187,7 +190,8 @@ int launch_max_abs(hipStream_t stream, const float* x, size_t n, float* out);   
 // [splits][TP][heads][2], then one combine pass.  attention_x2_splits() picks the count for a work list (1, 2 or 4).
 int launch_attention_x2(hipStream_t stream, const uint16_t* qk, const uint16_t* vt, int vt_nblk, uint16_t* out, int TP, int heads,
                         const AttnWorkItem* items, int max_items, float* part_o = nullptr, float* part_ml = nullptr, int splits = 1,
-                        int n_tokens = 0);      // n_tokens: rows the combine pass covers (the real token count; 0 = TP)
+                        int n_tokens = 0,       // n_tokens: rows the combine pass covers (the real token count; 0 = TP)
+                        const int32_t* cover_cu = nullptr, int cover_nseg = 0);      // as launch_attention_f32
 int attention_x2_splits(int max_items, int heads);
 
 // ---------------------------------------------------------------------------------------------

@@ -89,13 +89,13 @@ def plan_batches(parts: Sequence[Sequence[int]], world_size: int, max_points_per
     plan = [pack_batches(counts, max_points_per_batch, indices=s, drop_last=drop_last) for s in shards]
     n_max = max((len(b) for b in plan), default=0)
     for r, b in enumerate(plan):
+        if n_max and not b and not shards[r]:
+            # a rank with nothing to do would skip the collectives of the other ranks' steps and dead-lock them: fewer samples
+            # than ranks is a job for fewer ranks, not something to paper over with a donor batch whose result nobody asked for
+            raise ValueError(f"plan_batches: rank {r} of {world_size} gets no sample ({len(parts)} samples in the job): every rank has to take part "
+                             "in every step's gather -- run the job on at most as many ranks as it has samples")
         while len(b) < n_max:
-            if b:
-                b.append(list(b[-1]))
-            elif shards[r]:
-                b.append([shards[r][0]])
-            else:
-                break
+            b.append(list(b[-1]) if b else [shards[r][0]])
     return plan
 
 
@@ -109,7 +109,8 @@ def shard_range(n_items: int, world_size: int, rank: int) -> range:
 
 
 def gather_registrations(final_points: torch.Tensor, R: torch.Tensor, t: torch.Tensor, group=None, equal_shapes: bool = False,
-                         sample_ids: Sequence[int] | None = None, cu_seqlens: torch.Tensor | None = None):
+                         sample_ids: Sequence[int] | None = None, cu_seqlens: torch.Tensor | None = None,
+                         plan: tuple[Sequence[Sequence[int]], Sequence[int]] | None = None):
     """All-gather per-rank results (TPr,3), (Br,P,3,3), (Br,P,3) -> (sum TPr,3), (sum Br,P,3,3), (sum Br,P,3) in rank order.
 
     ``sample_ids`` (with the rank's ``cu_seqlens`` (Br+1,)): the GLOBAL indices of this rank's samples (a `shard_by_cost` assignment is
@@ -120,9 +121,26 @@ def gather_registrations(final_points: torch.Tensor, R: torch.Tensor, t: torch.T
     together.  Ranks may hold DIFFERENT numbers of points and samples (`shard_range` hands the first ranks one more pair, and
     real scans are ragged): a 3-integer all-gather of (TPr, Br, P) precedes the data collective, every rank pads its buffer
     to the largest payload and the padding is sliced away after the gather.  `equal_shapes=True` skips that exchange (and the
-    host read it needs): the caller guarantees identical shapes on every rank -- bench.py's fixed synthetic batch."""
+    host read it needs): the caller guarantees identical shapes on every rank -- bench.py's fixed synthetic batch.
+
+    ``plan = (assignment, point_counts)`` (round 6): the job's shard plan, identical on every rank -- assignment[r] = the global sample
+    indices rank r holds (a `shard_by_cost` result), point_counts[i] = points of global sample i.  Every size and every sample id is then
+    known on the host of every rank: NO size exchange, no (sample id, point count) exchange, no host read of a device tensor -- the data
+    collective is the only one, and the result comes back in ascending global sample index as with ``sample_ids``."""
     if (sample_ids is None) != (cu_seqlens is None):
         raise ValueError("sample_ids and cu_seqlens go together")
+    if plan is not None and (sample_ids is not None or equal_shapes):
+        raise ValueError("plan replaces sample_ids / cu_seqlens / equal_shapes")
+    if plan is not None:
+        assignment, point_counts = plan
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            ids = [int(i) for a in assignment for i in a]
+            return _reorder_samples(final_points, R, t, ids, [int(point_counts[i]) for i in ids])
+        if len(assignment) != dist.get_world_size(group):
+            raise ValueError(f"plan has {len(assignment)} shards for {dist.get_world_size(group)} ranks")
+        me = dist.get_rank(group)
+        if final_points.shape[0] != sum(int(point_counts[i]) for i in assignment[me]) or R.shape[0] != len(assignment[me]):
+            raise ValueError("this rank's tensors do not match its shard of the plan")
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         if sample_ids is not None:
             return _reorder_samples(final_points, R, t, [int(i) for i in sample_ids],
@@ -133,7 +151,10 @@ def gather_registrations(final_points: torch.Tensor, R: torch.Tensor, t: torch.T
     if R.shape[0] != t.shape[0] or t.shape[1] != P or final_points.dim() != 2 or final_points.shape[1] != 3:
         raise ValueError("expected final_points (TPr,3), R (Br,P,3,3), t (Br,P,3)")
     dev = final_points.device
-    if equal_shapes:
+    if plan is not None:
+        tp_all = [sum(int(point_counts[i]) for i in a) for a in assignment]
+        b_all = [len(a) for a in assignment]
+    elif equal_shapes:
         tp_all, b_all = [final_points.shape[0]] * world, [R.shape[0]] * world
     else:
         mine = torch.tensor([final_points.shape[0], R.shape[0], P], dtype=torch.int64, device=dev)
@@ -163,6 +184,9 @@ def gather_registrations(final_points: torch.Tensor, R: torch.Tensor, t: torch.T
         Rs.append(out[r, a0:a1].reshape(b, P, 3, 3))
         ts.append(out[r, a1:a1 + b * P * 3].reshape(b, P, 3))
     gp, gR, gt = torch.cat(pts), torch.cat(Rs), torch.cat(ts)
+    if plan is not None:
+        ids = [int(i) for a in assignment for i in a]
+        return _reorder_samples(gp, gR, gt, ids, [int(point_counts[i]) for i in ids])
     if sample_ids is None:
         return gp, gR, gt
     # (sample id, point count) of every gathered sample, in gather order: one small padded all-gather

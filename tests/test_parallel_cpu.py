@@ -262,3 +262,50 @@ def test_two_rank_ragged_cost_sharded_job_equals_the_single_process_batch(tmp_pa
         assert got["final"].shape == ref["end_point_trajectory"][-1].shape
         assert (got["final"] - ref["end_point_trajectory"][-1]).abs().max().item() < 1e-5
         assert (got["R"] - ref["R"]).abs().max().item() < 1e-5 and (got["t"] - ref["t"]).abs().max().item() < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# round 6: first-run insurance for the 8-GPU node nobody has been able to lease
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("extra,expect", [
+    (["--scaling", "weak", "--batch", "2", "--points", "16"], {"pairs_total": 16, "scaling": "weak", "workload": "uniform"}),
+    (["--scaling", "strong", "--workload", "ragged", "--ragged-points", "262144"], {"scaling": "strong", "workload": "ragged"}),
+], ids=["weak-uniform", "strong-ragged"])
+def test_bench_launcher_with_eight_ranks(extra, expect):
+    """`python bench.py --gpus 8 ...` end to end on 8 gloo CPU ranks (launcher self-test: stub sampler): the driver's weak-scaling command
+    and the strong ragged job -- launch, rendezvous on 127.0.0.1, cost sharding, ONE collective per step (the strong gather takes its
+    sizes and sample order from the shard plan), max-over-ranks timing, one JSON line with n_gpus = rccl_ranks = 8."""
+    import json
+    r = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1"] + extra, {"RAP_BENCH_LAUNCHER_SELFTEST": "1", "OMP_NUM_THREADS": "1"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["gather_ok"] is True and len(j["per_rank"]["elapsed_s"]) == 8
+    for k, v in expect.items():
+        assert j[k] == v, (k, j[k])
+    assert len(j["samples_per_rank"]) == 8 and min(j["samples_per_rank"]) >= 1 and sum(j["samples_per_rank"]) == j["pairs_total"]
+
+
+def test_plan_batches_refuses_a_rank_without_samples():
+    """with fewer samples than ranks a rank used to end up with FEWER batches than the others (it would skip their collectives
+    and dead-lock them); now that is an error when the plan is made."""
+    from rap_amd.parallel import plan_batches
+    parts = [[100, 50], [80, 80], [30]]
+    with pytest.raises(ValueError, match="gets no sample"):
+        plan_batches(parts, 4, 1000)
+    plan = plan_batches(parts, 3, 1000)
+    assert [len(b) for b in plan] == [1, 1, 1] and sorted(i for b in plan for batch in b for i in batch) == [0, 1, 2]
+
+
+def test_gather_with_the_shard_plan_needs_no_exchange_single_process():
+    """gather_registrations(plan=...) on one process: pure reorder into the job's sample order from host-side knowledge."""
+    from rap_amd.parallel import gather_registrations
+    counts = [3, 5, 2]
+    assignment = [[2, 0, 1]]
+    pts = torch.cat([torch.full((counts[i], 3), float(i)) for i in assignment[0]])
+    R = torch.stack([torch.eye(3)[None] * (i + 1) for i in assignment[0]]); t = torch.stack([torch.full((1, 3), float(i)) for i in assignment[0]])
+    gp, gR, gt = gather_registrations(pts, R, t, plan=(assignment, counts))
+    assert gp[:, 0].tolist() == [0.0] * 3 + [1.0] * 5 + [2.0] * 2 and gt[:, 0, 0].tolist() == [0.0, 1.0, 2.0] and gR[:, 0, 0, 0].tolist() == [1.0, 2.0, 3.0]
+    with pytest.raises(ValueError):
+        gather_registrations(pts, R, t, plan=(assignment, counts), equal_shapes=True)
