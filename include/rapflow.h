@@ -27,8 +27,10 @@ extern "C" {
 /* ABI version of this header.  rap_version() returns the value the LIBRARY was built with; a caller compiled against another
  * value must not use the library (round 4, version 4: rap_spinnet_describe gained `flags` and three entry points were removed in
  * round 3 without a bump; the fp16-residual epilogue of rap_gemm_h16 moved from 6 to 7 and 6 is refused; rap_poison_on_flag is new;
- * round 5, version 5: compute dtype 3 (split precision) and the rap_x2_* entry points are new, nothing was removed or re-numbered). */
-#define RAPFLOW_ABI_VERSION 5
+ * round 5, version 5: compute dtype 3 (split precision) and the rap_x2_* entry points are new, nothing was removed or re-numbered;
+ * round 6, version 6: additive -- the *_latent entry points (in_dim > 0), rap_transform_errors, tuning keys 18 / 19; the scratch of the
+ * kernel-level attention entry points grew by a sanitised copy of cu_seqlens (rap_attention_workspace_bytes reports it)). */
+#define RAPFLOW_ABI_VERSION 6
 
 /* return codes of every int-returning entry point */
 #define RAP_OK 0
@@ -64,6 +66,15 @@ int64_t rap_weight_count(const rap_model_desc* desc);
  * projection, stacked adaLN weights, value/gate-interleaved GEGLU projection).  Allocates. */
 int rap_model_create(const rap_model_desc* desc, const float* d_weights, int64_t n_floats, void* stream,
                      rap_model** out);
+/* in_dim > 0 (round 6; reference flow_model/embedding.py:107-118,163-166, point_cloud_dit.py:56,86): the model concatenates `in_dim`
+ * LATENT point features (the PTv3 encoder output of encoder_on = true; modeling.py:788 builds one with in_dim = 64) into the embedding
+ * input.  They are step-invariant like the condition cloud, so they become in_dim more columns of the hoisted embedding GEMM.  The blob's
+ * emb_proj.weight is (embed_dim, 147 + local_feat_dim + in_dim) with the latent columns LAST ([cond 63 | x_t 63 | scale 21 | feat F |
+ * latent in_dim]; rap_amd/flow_model.py re-orders the reference's [cond | x_t | latent | scale | feat]).  in_dim a multiple of 4, <= 512.
+ * in_dim = 0 is rap_weight_count / rap_model_create.  A model with in_dim > 0 must be driven through the *_latent entry points below. */
+int64_t rap_weight_count_latent(const rap_model_desc* desc, int32_t in_dim);
+int rap_model_create_latent(const rap_model_desc* desc, int32_t in_dim, const float* d_weights, int64_t n_floats, void* stream,
+                            rap_model** out);
 void rap_model_destroy(rap_model* m);
 
 /* Arithmetic type of the transformer blocks (qkv / out / feed-forward GEMMs and attention) for subsequent calls on `m`:
@@ -121,6 +132,12 @@ int rap_dit_forward(const rap_model* m, const float* x_t, const float* timesteps
                     const float* scales, const uint8_t* anchor, const int32_t* cu_batch, const int32_t* cu_part,
                     int32_t B, int32_t VP, int64_t TP, float* v_out, float* feats_out, void* ws, size_t ws_bytes,
                     void* stream);
+/* ... with latent (TP, in_dim) fp32 for a model created with in_dim > 0 (`latent_features` of point_cloud_dit.py:146, embedding.py:163-166);
+ * latent must be NULL exactly when the model's in_dim is 0. */
+int rap_dit_forward_latent(const rap_model* m, const float* x_t, const float* timesteps, const float* cond, const float* feat,
+                           const float* latent, const float* scales, const uint8_t* anchor, const int32_t* cu_batch, const int32_t* cu_part,
+                           int32_t B, int32_t VP, int64_t TP, float* v_out, float* feats_out, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* Replaces euler_step's tensor update (reference sampler.py:88-90): x0_hat = x_t - v*t ; x_next = x_t - dt*v.
  * n = number of floats (3*TP).  x_next may alias x_t.  traj_xt_slot may be NULL. */
@@ -154,6 +171,11 @@ int rap_sample(const rap_model* m, const float* cond, const float* feat, const f
                const int64_t* points_per_part, const int32_t* cu_batch, const float* x_1, int32_t B, int32_t P,
                int64_t TP, int32_t num_steps, int32_t rigidity_forcing, float* traj_x0, float* traj_xt, float* R_out,
                float* t_out, float* feats_out, void* ws, size_t ws_bytes, void* stream);
+/* ... with the `latent_features` argument of sample_rectified_flow (modeling.py:636): (TP, in_dim) fp32, NULL exactly when in_dim is 0 */
+int rap_sample_latent(const rap_model* m, const float* cond, const float* feat, const float* latent, const float* scales,
+                      const uint8_t* anchor, const int64_t* points_per_part, const int32_t* cu_batch, const float* x_1, int32_t B,
+                      int32_t P, int64_t TP, int32_t num_steps, int32_t rigidity_forcing, float* traj_x0, float* traj_xt, float* R_out,
+                      float* t_out, float* feats_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- generation selection by rigidity (the caller side of the path) ----
  * Replaces compute_rigidity_rmse (reference eval/metrics.py:511-622): per sample, the RMS of |cond_p R_p^T + t_p - pred_p|
@@ -175,6 +197,17 @@ int rap_trajectory_rigidity_rmse(const float* cond, const float* traj, const int
 int rap_select_generation(const float* rmse, int32_t G, int32_t B, int32_t P, int64_t TP, const int32_t* cu_batch,
                           const float* clouds, const float* R, const float* t, int32_t pick_largest, int32_t* best_out,
                           float* cloud_out, float* R_out, float* t_out, void* stream);
+/* ---- registration errors (the RRE / RTE that BASELINE.json's "SE(3) err" is defined by) ----
+ * Replaces compute_transform_errors(..., use_icp=False) (reference eval/metrics.py:165-303): per sample, every non-anchor, non-empty part's
+ * ground-truth and predicted pose relative to the (first) anchor part's, delta_R = R_gt_rel^T R_pred_rel, delta_t = (t_pred_rel -
+ * t_gt_rel) * scale[b];  rot_err = deg(acos(clamp((tr delta_R - 1) / 2, -1, 1))), trans_err = |delta_t|.  R_* (B,P,3,3), t_* (B,P,3),
+ * points_per_part (B,P) int64, anchor_part (B,P) uint8, matched_part_ids (B,P) int64 or NULL (re-orders the PREDICTED poses, :223-227),
+ * scale (B,) or NULL (= 1).  Outputs: per-part errors (B,P) (0 for anchor / empty parts) and their means over the valid parts (B,)
+ * (NaN for a sample without one, as the reference's 0 / 0).  No workspace, no synchronisation. */
+int rap_transform_errors(const float* R_gt, const float* t_gt, const float* R_pred, const float* t_pred, const int64_t* points_per_part,
+                         const uint8_t* anchor_part, const int64_t* matched_part_ids, const float* scale, int32_t B, int32_t P,
+                         float* rot_err_per_part, float* trans_err_per_part, float* rot_err_mean, float* trans_err_mean, void* stream);
+
 /* Replaces compute_overlap_ratio (reference eval/metrics.py:625-691): per sample the fraction of points that have a point of
  * a DIFFERENT part of the same sample within distance tau, for n_taus (<= 8) thresholds given as a HOST array.
  * ratios_out (n_taus, B) device; min_dist_out (TP,) device or NULL (distance to the nearest other-part point, inf if none).

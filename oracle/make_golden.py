@@ -7,6 +7,7 @@ oracle/ref_loader.py; fp32, CPU).  They travel to the GPU box, where /root/refer
 """
 from __future__ import annotations
 
+import math
 import os
 import sys
 
@@ -34,10 +35,12 @@ CASES = [
     ("l2_noqknorm_rigid", 2, [[60, 41], [130, 20, 77]], 51, 4, 3, True),
     ("l2_noscale_free", 2, [[37, 64, 100], [50, 129]], 53, 5, 3, False),
     ("l2_nofeat_rigid", 2, [[90, 33], [45, 45, 45]], 55, 6, 3, True),
+    # round 6: in_dim = 64 -- latent point features concatenated into the embedding (embedding.py:107-118,163-166; modeling.py:788)
+    ("l2_latent64_rigid", 2, [[70, 51], [40, 120, 33]], 57, 7, 3, True),
 ]
 # name -> PointCloudDiT keyword overrides
 CASE_SWITCHES = {"l2_noqknorm_rigid": {"qk_norm": False}, "l2_noscale_free": {"scale_emb_on": False},
-                 "l2_nofeat_rigid": {"local_feat_concat_on": False}}
+                 "l2_nofeat_rigid": {"local_feat_concat_on": False}, "l2_latent64_rigid": {"in_dim": 64}}
 
 
 def weights_checksum(sd) -> float:
@@ -55,6 +58,8 @@ def main():
         cfg.update(CASE_SWITCHES.get(name, {}))
         sd = S.make_weights(cfg, wseed)
         inp = S.make_inputs(parts, seed=iseed)
+        if cfg.get("in_dim", 0):      # latent point features as a PTv3 encoder would hand them over: (TP, in_dim), O(1) values
+            inp["latent_features"] = torch.randn(inp["x_1"].shape[0], cfg["in_dim"], generator=torch.Generator().manual_seed(1000 + iseed))
         ref = ref_loader.reference_sample(cfg, sd, inp, steps, rigid)
         # one stand-alone forward of the reference PointCloudDiT with a different t per sample
         model = ref_loader.build_reference_dit(cfg, sd)
@@ -63,7 +68,7 @@ def main():
         ts = torch.linspace(0.15, 0.9, B)
         with torch.inference_mode():
             fw = model(x=inp["x_1"], timesteps=ts, cond_coord=inp["pointclouds"], local_features=inp["features"],
-                       latent_features=None, scales=inp["scales"], anchor_indices=inp["anchor_indices"],
+                       latent_features=inp.get("latent_features"), scales=inp["scales"], anchor_indices=inp["anchor_indices"],
                        cu_seqlens_batch=cu_b, cu_seqlens_part=cu_p, return_transformer_features=True)
         out = {
             "num_layers": np.int64(L), "weight_seed": np.int64(wseed), "num_steps": np.int64(steps),
@@ -135,6 +140,84 @@ def make_overlap_golden():
     np.savez_compressed(path, pred=pred.numpy(), points_per_part=ppp.numpy(), cu_seqlens=cu.numpy(), taus=np.array(taus),
                         ratios=ratios.numpy())
     print("overlap_ratio", os.path.getsize(path) // 1024, "KiB", ratios)
+
+
+def make_envelope_goldens():
+    """the envelope of the split-precision mode and of the per-launch softmax selection against the REFERENCE, not just the
+    kernels.  Three L = 2 fixtures of the unmodified reference (fp32, CPU) on weights from rap_amd.synthetic.envelope_weights; the fixture also
+    records how large the GEGLU output actually gets (read off the oracle's evaluation of the same weights)."""
+    cfg = dict(S.RAP_12); cfg["num_layers"] = 2
+    parts, iseed, wseed, steps = [[300, 211], [64, 500, 33]], 61, 8, 3
+    inp = S.make_inputs(parts, seed=iseed)
+    cu_b, cu_p = O.prepare_cu_seqlens(inp)
+    for kind in S.ENVELOPE_KINDS:
+        sd = S.envelope_weights(cfg, wseed, kind)
+        ref = ref_loader.reference_sample(cfg, sd, inp, steps, True)
+        model = ref_loader.build_reference_dit(cfg, sd)
+        ts = torch.linspace(0.15, 0.9, len(parts))
+        with torch.inference_mode():
+            fw = model(x=inp["x_1"], timesteps=ts, cond_coord=inp["pointclouds"], local_features=inp["features"], latent_features=None,
+                       scales=inp["scales"], anchor_indices=inp["anchor_indices"], cu_seqlens_batch=cu_b, cu_seqlens_part=cu_p)
+        # magnitude of the GEGLU output of layer 0 at the forward's inputs (oracle arithmetic; information only)
+        taps = {}
+        O.dit_forward(sd, cfg, inp["x_1"], ts, inp["pointclouds"], inp["features"], inp["scales"], inp["anchor_indices"], cu_b, cu_p, taps=taps)
+        p0 = "transformer_layers.0."
+        x = torch.nn.functional.layer_norm(taps["l0_after_global_attn"], (512,), sd[p0 + "ff_norm.weight"], sd[p0 + "ff_norm.bias"], eps=1e-5)
+        u = torch.nn.functional.linear(x, sd[p0 + "ff.net.0.proj.weight"], sd[p0 + "ff.net.0.proj.bias"])
+        hh, gg = u.chunk(2, dim=-1)
+        ge = (hh * torch.nn.functional.gelu(gg)).abs()
+        out = {"num_layers": np.int64(2), "weight_seed": np.int64(wseed), "num_steps": np.int64(steps), "weights_checksum": np.float64(weights_checksum(sd)),
+               "fwd_timesteps": ts.numpy(), "fwd_velocity": fw.numpy(), "end_point_trajectory": ref["end_point_trajectory"].numpy(),
+               "trajectory": ref["trajectory"].numpy(), "R": ref["R"].numpy(), "t": ref["t"].numpy(),
+               "geglu_abs_max": np.float64(ge.max()), "geglu_abs_median": np.float64(ge.median()), "geglu_abs_p01": np.float64(ge.flatten().kthvalue(max(1, ge.numel() // 100)).values)}
+        for k, v in inp.items():
+            out["in_" + k] = v.numpy()
+        path = os.path.join(GOLDEN_DIR, f"envelope_{kind}.npz")
+        np.savez_compressed(path, **out)
+        print(f"envelope_{kind}", os.path.getsize(path) // 1024, "KiB; |GEGLU| max", float(ge.max()), "median", float(ge.median()), "; max|v|", float(fw.abs().max()))
+
+
+def make_transform_errors_golden():
+    """compute_transform_errors, no-ICP branch (eval/metrics.py:165-303): the reference's OWN function on 6
+    samples x 5 parts -- random proper rotations with errors from a fraction of a degree to ~170 degrees, a sample whose anchor is not
+    part 0, trailing empty parts, a sample with two anchors (the first counts), one WITHOUT an anchor (identity frame), one with only
+    the anchor (0 / 0 = NaN), with and without matched_part_ids and scale."""
+    g = torch.Generator().manual_seed(77)
+    B, P = 6, 5
+
+    def rot(angle_deg=None):
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+        if torch.det(q) < 0:
+            q[:, 0] *= -1
+        if angle_deg is None:
+            return q
+        axis = torch.randn(3, generator=g, dtype=torch.float64); axis /= axis.norm()
+        K = torch.tensor([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]], dtype=torch.float64)
+        a = math.radians(angle_deg)
+        return torch.eye(3, dtype=torch.float64) + math.sin(a) * K + (1 - math.cos(a)) * (K @ K)
+    ppp = torch.tensor([[400, 300, 50, 0, 0], [500, 120, 0, 0, 0], [257, 1, 130, 64, 9], [64, 64, 64, 0, 0], [100, 0, 0, 0, 0], [30, 40, 50, 60, 0]])
+    anchor = torch.zeros(B, P, dtype=torch.bool)
+    anchor[0, 0] = True; anchor[1, 1] = True; anchor[2, 2] = True; anchor[2, 4] = True; anchor[4, 0] = True      # sample 3 and 5: no anchor at all (5) / none (3)
+    anchor[5, 3] = True
+    R_gt = torch.stack([torch.stack([rot() for _ in range(P)]) for _ in range(B)]).float()
+    t_gt = torch.randn(B, P, 3, generator=g)
+    angles = [0.3, 2.0, 11.0, 45.0, 90.0, 170.0]
+    R_pred = torch.stack([torch.stack([(rot(angles[(b + p) % len(angles)]) @ R_gt[b, p].double()) for p in range(P)]) for b in range(B)]).float()
+    t_pred = t_gt + 0.05 * torch.randn(B, P, 3, generator=g)
+    scale = torch.rand(B, generator=g) * 3 + 0.5
+    matched = torch.stack([torch.randperm(P, generator=g) for _ in range(B)])
+    cu = torch.cat([torch.zeros(1, dtype=torch.long), ppp.sum(1).cumsum(0)])
+    pts = torch.randn(int(cu[-1]), 3, generator=g)
+    ref = ref_loader.load_reference()
+    out = {"R_gt": R_gt.numpy(), "t_gt": t_gt.numpy(), "R_pred": R_pred.numpy(), "t_pred": t_pred.numpy(), "points_per_part": ppp.numpy(),
+           "anchor_part": anchor.numpy(), "scale": scale.numpy(), "matched_part_ids": matched.numpy(), "cu_seqlens": cu.numpy()}
+    for tag, mid, sc in (("plain", None, None), ("scaled", None, scale), ("matched", matched, scale)):
+        re, te = ref.metrics.compute_transform_errors(pts, pts, R_gt, t_gt, R_pred, t_pred, ppp, anchor, matched_part_ids=mid, scale=sc,
+                                                      cu_seqlens_batch=cu, use_icp=False)
+        out[f"{tag}_rot"] = re.numpy(); out[f"{tag}_trans"] = te.numpy()
+    path = os.path.join(GOLDEN_DIR, "transform_errors.npz")
+    np.savez_compressed(path, **out)
+    print("transform_errors", os.path.getsize(path) // 1024, "KiB", out["plain_rot"], out["plain_trans"])
 
 
 def make_spinnet_golden():
@@ -388,6 +471,10 @@ if __name__ == "__main__":
         make_transform_golden()
     if not only or "--overlap-only" in only:
         make_overlap_golden()
+    if not only or "--envelope-only" in only:
+        make_envelope_goldens()
+    if not only or "--transform-errors-only" in only:
+        make_transform_errors_golden()
     if not only or "--spinnet-only" in only:
         make_spinnet_golden()
     if not only or "--nn-only" in only:

@@ -71,10 +71,13 @@ def posenc(x: torch.Tensor, num_freqs: int = 10) -> torch.Tensor:
     return torch.cat(outs, -1)
 
 
-def encoding_manager(sd, x, cond, feats, scales_pt, cfg=None):
-    """embedding.py:131-179: cat[PE63(cond), PE63(x), PE21(scale) if scale_emb_on, feat if local_feat_concat_on] -> emb_proj."""
+def encoding_manager(sd, x, cond, feats, scales_pt, cfg=None, latent=None):
+    """embedding.py:131-179: cat[PE63(cond), PE63(x), latent (TP, in_dim) if given, PE21(scale) if scale_emb_on, feat if
+    local_feat_concat_on] -> emb_proj."""
     cfg = cfg or {}
     cols = [posenc(cond), posenc(x)]
+    if latent is not None:                                                    # embedding.py:163-166
+        cols.append(latent.view(x.shape[0], -1))
     if cfg.get("scale_emb_on", True):                                         # embedding.py:169-172
         cols.append(posenc(scales_pt.unsqueeze(-1)))
     if cfg.get("local_feat_concat_on", True) and feats is not None:           # embedding.py:175-177
@@ -227,10 +230,10 @@ def dit_layer(sd, i, h, t, cu_batch, cu_part, H, taps=None):
 # flow_model/point_cloud_dit.py
 # ----------------------------------------------------------------------------
 def dit_forward(sd, cfg, x, timesteps, cond, feats, scales, anchor, cu_batch, cu_part,
-                return_transformer_features: bool = False, taps: dict | None = None):
-    """PointCloudDiT.forward (point_cloud_dit.py:141-191)."""
+                return_transformer_features: bool = False, taps: dict | None = None, latent=None):
+    """PointCloudDiT.forward (point_cloud_dit.py:141-191); ``latent`` = its latent_features argument (models with in_dim > 0)."""
     scales_pt = repeat_by_cu_seqlens(scales, cu_batch)                        # :174
-    h = encoding_manager(sd, x, cond, feats, scales_pt, cfg)                  # :175
+    h = encoding_manager(sd, x, cond, feats, scales_pt, cfg, latent)          # :175
     emb = sd["anchor_part_emb.weight"]
     h = h + torch.where(anchor[:, None], emb[1][None, :], emb[0][None, :])    # :119-139
     if taps is not None:
@@ -362,6 +365,7 @@ def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.
     feats = inputs["features"].to(device=device, dtype=dtype)
     scales = inputs["scales"].to(device=device, dtype=dtype)
     x_1 = inputs["x_1"].to(device=device, dtype=dtype)
+    latent = inputs["latent_features"].to(device=device, dtype=dtype) if inputs.get("latent_features") is not None else None   # modeling.py:636
     anchor = inputs["anchor_indices"].to(device)
     ppp = inputs["points_per_part"].cpu()
     cu_batch, cu_part = prepare_cu_seqlens({"points_per_part": ppp, "cu_seqlens": inputs["cu_seqlens"].cpu()})
@@ -378,11 +382,11 @@ def sample(sd, cfg, inputs, num_steps: int, rigidity_forcing: bool, dtype=torch.
         ts = torch.full((B,), t, dtype=dtype, device=device)                   # modeling.py:674
         is_last_call = (t < 1e-6) or (call_count[0] >= num_steps - 1)          # modeling.py:678
         if is_last_call and captured["features"] is None:                      # modeling.py:680-695
-            r = dit_forward(sd, cfg, x, ts, cond, feats, scales, anchor, cu_batch, cu_part, return_transformer_features=True)
+            r = dit_forward(sd, cfg, x, ts, cond, feats, scales, anchor, cu_batch, cu_part, return_transformer_features=True, latent=latent)
             captured["features"] = r["transformer_features"]
             return r["velocity"]
         call_count[0] += 1                                                     # modeling.py:697
-        return dit_forward(sd, cfg, x, ts, cond, feats, scales, anchor, cu_batch, cu_part)
+        return dit_forward(sd, cfg, x, ts, cond, feats, scales, anchor, cu_batch, cu_part, latent=latent)
 
     if max_steps is None:
         res = flow_sampler(fn, x_1, num_steps, ppp, cu_batch, cond, rigidity_forcing)
@@ -550,6 +554,38 @@ def rotation_error_deg(R_a: torch.Tensor, R_b: torch.Tensor) -> torch.Tensor:
     """acos((trace(R_a^T R_b) - 1) / 2) in degrees, clamped (metrics.py:289-291)."""
     tr = torch.einsum("...ij,...ij->...", R_a, R_b)
     return torch.rad2deg(torch.acos(((tr - 1) / 2).clamp(-1, 1)))
+
+
+def compute_transform_errors(rotations_gt, translations_gt, rotations_pred, translations_pred, points_per_part, anchor_part,
+                             matched_part_ids=None, scale=None):
+    """eval/metrics.py:165-303 with use_icp=False: rotation error (degrees) and translation error of every non-anchor, non-empty part
+    relative to the sample's FIRST anchor part (:239-257; identity when the sample has none, :258-263), means over those parts
+    (:298-301; 0 / 0 = NaN).  -> (rot_mean (B,), trans_mean (B,), rot (B,P), trans (B,P))."""
+    B, P = points_per_part.shape
+    dt = rotations_gt.dtype
+    if matched_part_ids is not None:                                            # :223-227: re-orders the PREDICTED poses
+        bi = torch.arange(B)[:, None]
+        rotations_pred, translations_pred = rotations_pred[bi, matched_part_ids], translations_pred[bi, matched_part_ids]
+    scale = torch.ones(B, dtype=dt) if scale is None else scale.to(dt)
+    rot = torch.zeros(B, P, dtype=dt); trans = torch.zeros(B, P, dtype=dt)
+    for b in range(B):
+        idx = anchor_part[b].nonzero().squeeze(1)
+        if idx.numel() > 0:
+            a = int(idx[0])
+            Rg_inv, Rp_inv = rotations_gt[b, a].T, rotations_pred[b, a].T      # :250-256
+            tg_inv, tp_inv = -Rg_inv @ translations_gt[b, a], -Rp_inv @ translations_pred[b, a]
+        else:
+            Rg_inv = Rp_inv = torch.eye(3, dtype=dt); tg_inv = tp_inv = torch.zeros(3, dtype=dt)
+        for p in range(P):
+            if points_per_part[b, p] == 0 or anchor_part[b, p]:                 # :266-267
+                continue
+            Rg_rel, tg_rel = Rg_inv @ rotations_gt[b, p], Rg_inv @ translations_gt[b, p] + tg_inv          # :282-286
+            Rp_rel, tp_rel = Rp_inv @ rotations_pred[b, p], Rp_inv @ translations_pred[b, p] + tp_inv
+            dR = Rg_rel.T @ Rp_rel                                              # :289
+            rot[b, p] = torch.rad2deg(torch.acos(torch.clamp(0.5 * (torch.trace(dR) - 1), -1.0, 1.0)))     # :294-296
+            trans[b, p] = torch.norm((tp_rel - tg_rel) * scale[b])              # :290, :299
+    n = ((points_per_part != 0) & (~anchor_part)).sum(dim=1)
+    return rot.sum(1) / n, trans.sum(1) / n, rot, trans
 
 
 def voxel_down_sample(points, voxel_size):

@@ -406,7 +406,7 @@ def reference_generation_selection(cond, trajectories, points_per_part, cu_seqle
 def build_reference_dit(cfg, state_dict, dtype=torch.float32):
     """Instantiate the reference's PointCloudDiT and load ``state_dict`` into it."""
     ns = load_reference()
-    m = ns.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
+    m = ns.PointCloudDiT(in_dim=int(cfg.get("in_dim", 0)), out_dim=3, embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
                          num_heads=cfg["num_heads"], attn_dtype="float32", qk_norm=cfg.get("qk_norm", True),
                          local_feat_dim=cfg["local_feat_dim"], scale_emb_on=cfg.get("scale_emb_on", True),
                          local_feat_concat_on=cfg.get("local_feat_concat_on", True))
@@ -431,6 +431,7 @@ def reference_sample(cfg, state_dict, inputs, num_steps, rigidity_forcing, dtype
     anchor = inputs["anchor_indices"]
     ppp = inputs["points_per_part"]
     x_1 = inputs["x_1"].to(dtype)
+    latent = inputs["latent_features"].to(dtype) if inputs.get("latent_features") is not None else None     # modeling.py:636 (in_dim > 0)
     valid = ppp > 0
     cu_part = F.pad(torch.cumsum(ppp[valid], 0), (1, 0)).to(torch.int32)   # modeling.py:219-222
     cu_batch = inputs["cu_seqlens"].to(torch.int32)                          # modeling.py:223
@@ -442,7 +443,7 @@ def reference_sample(cfg, state_dict, inputs, num_steps, rigidity_forcing, dtype
     def run():
         def fn(x, t):                                                        # modeling.py:672-708
             ts = torch.full((B,), t, dtype=dtype)
-            kw = dict(x=x, timesteps=ts, cond_coord=cond, local_features=feats, latent_features=None, scales=scales,
+            kw = dict(x=x, timesteps=ts, cond_coord=cond, local_features=feats, latent_features=latent, scales=scales,
                       anchor_indices=anchor, cu_seqlens_batch=cu_batch, cu_seqlens_part=cu_part)
             is_last_call = (t < 1e-6) or (call_count[0] >= num_steps - 1)    # modeling.py:678
             if is_last_call and captured["features"] is None:                # modeling.py:680-695

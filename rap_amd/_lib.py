@@ -13,7 +13,7 @@ from ctypes import c_float, c_int32, c_int64, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librapflow.so")
 
-ABI_VERSION = 5        # RAPFLOW_ABI_VERSION of include/rapflow.h this binding was written against
+ABI_VERSION = 6        # RAPFLOW_ABI_VERSION of include/rapflow.h this binding was written against
 EPI_H_BIAS_RESID_H16 = 7   # rap_gemm_h16's fp16-residual epilogue (6 before ABI version 4; 6 is refused now)
 # "float32x2" (round 5): split precision -- fp32-ACCURATE transformer blocks on the fp16 matrix pipe (include/rapflow.h, compute dtype 3)
 DTYPES = {"float32": 0, "fp32": 0, "bfloat16": 1, "bf16": 1, "float16": 2, "fp16": 2, "float32x2": 3, "f32x2": 3}
@@ -36,6 +36,8 @@ SIGNATURES = {
     "rap_last_hip_error": (c_int32, []),
     "rap_weight_count": (c_int64, [ctypes.POINTER(ModelDesc)]),
     "rap_model_create": (c_int32, [ctypes.POINTER(ModelDesc), _P, c_int64, _P, ctypes.POINTER(_P)]),
+    "rap_weight_count_latent": (c_int64, [ctypes.POINTER(ModelDesc), c_int32]),
+    "rap_model_create_latent": (c_int32, [ctypes.POINTER(ModelDesc), c_int32, _P, c_int64, _P, ctypes.POINTER(_P)]),
     "rap_model_destroy": (None, [_P]),
     "rap_model_set_compute_dtype": (c_int32, [_P, c_int32, _P]),
     "rap_model_compute_dtype": (c_int32, [_P]),
@@ -46,6 +48,9 @@ SIGNATURES = {
     "rap_model_residual_dtype": (c_int32, [_P]),
     "rap_workspace_bytes": (c_size_t, [_P, c_int64, c_int32, c_int32, c_int32]),
     "rap_dit_forward": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, c_size_t, _P]),
+    "rap_dit_forward_latent": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, c_size_t, _P]),
+    "rap_sample_latent": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32, _P, _P, _P, _P,
+                                    _P, _P, c_size_t, _P]),
     "rap_euler_step": (c_int32, [_P, _P, c_float, c_float, _P, _P, _P, c_int64, _P]),
     "rap_procrustes_workspace_bytes": (c_size_t, [c_int32]),
     "rap_fit_transformations": (c_int32, [_P, _P, _P, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
@@ -57,6 +62,7 @@ SIGNATURES = {
     "rap_rigidity_rmse": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _P, _P, c_size_t, _P]),
     "rap_trajectory_rigidity_rmse": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P]),
     "rap_select_generation": (c_int32, [_P, c_int32, c_int32, c_int32, c_int64, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
+    "rap_transform_errors": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "rap_overlap_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "rap_overlap_ratio": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, _P, c_int32, _P, _P, _P, c_size_t, _P]),
     "rap_relative_transforms": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),

@@ -107,6 +107,8 @@ struct HalfWeights {
 struct rap_model {
   rap_model_desc desc;
   int d, L, H, F, E;
+  int Din = 0;                // in_dim: width of the latent point features concatenated into the embedding (embedding.py:163-166; 0 in every shipped config)
+  int Ks = 128;               // columns of the step-invariant embedding input: 128 + align_up(Din, 32)
   int dtype = RAP_DT_F32;     // arithmetic type of the transformer blocks (rap_model_set_compute_dtype)
   bool qk_norm = true;        // MultiHeadRMSNorm on q / k (rap_model_set_qk_norm; every shipped configuration has it on)
   int resid_dtype = RAP_DT_F32;   // storage type of the residual stream in the 16-bit modes (rap_model_set_residual_dtype): fp32 or fp16
@@ -121,7 +123,7 @@ struct rap_model {
   float* derived = nullptr;   // packed arrays
   const float* anchor_emb;    // (2,d)
   const float* emb_bias;      // (d)
-  const float* Wstatic;       // (d,128): [cond PE63 | scale PE21 | feat F | 0]
+  const float* Wstatic;       // (d,Ks): [cond PE63 | scale PE21 | feat F | 0 .. 128 | latent Din | 0]
   const float* Wx;            // (d,64):  [x_t PE63 | 0]
   const float *adaW1, *adab1, *adaW2, *adab2, *adaW3, *adab3;  // stacked over j = 2*layer + {0 self, 1 global}
   std::vector<LayerW> layers;
@@ -196,9 +198,11 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
 extern "C" int rap_version(void) { return RAPFLOW_ABI_VERSION; }
 extern "C" int rap_last_hip_error(void) { return g_last_hip_error; }
 
-extern "C" int64_t rap_weight_count(const rap_model_desc* desc) {
-  if (!desc_ok(desc)) return -1;
-  const int64_t d = desc->embed_dim, L = desc->num_layers, H = desc->num_heads, E = 147 + desc->local_feat_dim;
+static bool in_dim_ok(int32_t in_dim) { return in_dim >= 0 && in_dim <= 512 && in_dim % 4 == 0; }
+extern "C" int64_t rap_weight_count(const rap_model_desc* desc) { return rap_weight_count_latent(desc, 0); }
+extern "C" int64_t rap_weight_count_latent(const rap_model_desc* desc, int32_t in_dim) {
+  if (!desc_ok(desc) || !in_dim_ok(in_dim)) return -1;
+  const int64_t d = desc->embed_dim, L = desc->num_layers, H = desc->num_heads, E = 147 + desc->local_feat_dim + in_dim;
   int64_t n = 2 * d + d * E + d;
   const int64_t attn = (d * 256 + d) + (d * d + d) + (2 * d * d + 2 * d) + 3 * d * d + (d * d + d) + 2 * H * 64;
   const int64_t layer = 2 * attn + 2 * d + (8 * d * d + 8 * d) + (4 * d * d + d);
@@ -211,21 +215,27 @@ static int ensure_logit_bounds(rap_model* m, hipStream_t stream);
 
 extern "C" int rap_model_create(const rap_model_desc* desc, const float* d_weights, int64_t n_floats, void* stream_,
                                 rap_model** out) {
+  return rap_model_create_latent(desc, 0, d_weights, n_floats, stream_, out);
+}
+extern "C" int rap_model_create_latent(const rap_model_desc* desc, int32_t in_dim, const float* d_weights, int64_t n_floats, void* stream_,
+                                       rap_model** out) {
   if (!out) return RAP_ERR_INVALID;
   *out = nullptr;
-  if (!desc_ok(desc) || !d_weights) return RAP_ERR_INVALID;
-  if (n_floats != rap_weight_count(desc)) return RAP_ERR_INVALID;
+  if (!desc_ok(desc) || !in_dim_ok(in_dim) || !d_weights) return RAP_ERR_INVALID;
+  if (n_floats != rap_weight_count_latent(desc, in_dim)) return RAP_ERR_INVALID;
   hipStream_t stream = (hipStream_t)stream_;
   rap_model* m = new (std::nothrow) rap_model();
   if (!m) return RAP_ERR_ALLOC;
   m->desc = *desc;
   const int d = m->d = desc->embed_dim, L = m->L = desc->num_layers, H = m->H = desc->num_heads;
   m->F = desc->local_feat_dim;
-  const int E = m->E = 147 + m->F;
+  m->Din = in_dim;
+  const int Ks = m->Ks = 128 + (in_dim + 31) / 32 * 32;
+  const int E = m->E = 147 + m->F + m->Din;      // native column order: [cond 63 | x_t 63 | scale 21 | feat F | latent Din]
   if (hipMalloc((void**)&m->raw, (size_t)n_floats * sizeof(float)) != hipSuccess) { delete m; return RAP_ERR_ALLOC; }
   const size_t n_ada = (size_t)2 * L * ((size_t)d * 256 + d + (size_t)d * d + d + (size_t)2 * d * d + 2 * d);
   const size_t n_ff1 = (size_t)L * ((size_t)8 * d * d + 8 * d);
-  const size_t n_derived = (size_t)d * 128 + (size_t)d * 64 + n_ada + n_ff1;
+  const size_t n_derived = (size_t)d * Ks + (size_t)d * 64 + n_ada + n_ff1;
   if (hipMalloc((void**)&m->derived, n_derived * sizeof(float)) != hipSuccess) {
     (void)hipFree(m->raw); delete m; return RAP_ERR_ALLOC;
   }
@@ -243,7 +253,7 @@ extern "C" int rap_model_create(const rap_model_desc* desc, const float* d_weigh
 
   float* q = m->derived;
   auto carve = [&](size_t n) { float* r = q; q += n; return r; };
-  float* Wstatic = carve((size_t)d * 128);
+  float* Wstatic = carve((size_t)d * Ks);
   float* Wx = carve((size_t)d * 64);
   float* aW1 = carve((size_t)2 * L * d * 256); float* ab1 = carve((size_t)2 * L * d);
   float* aW2 = carve((size_t)2 * L * d * d);   float* ab2 = carve((size_t)2 * L * d);
@@ -252,11 +262,12 @@ extern "C" int rap_model_create(const rap_model_desc* desc, const float* d_weigh
   m->adaW1 = aW1; m->adab1 = ab1; m->adaW2 = aW2; m->adab2 = ab2; m->adaW3 = aW3; m->adab3 = ab3;
 
   // embedding projection columns (embedding.py:161-177): [0,63) cond | [63,126) x_t | [126,147) scale | [147,E) feat
-  if ((rc = launch_fill_zero(stream, Wstatic, (size_t)d * 128))) return fail(rc);
+  if ((rc = launch_fill_zero(stream, Wstatic, (size_t)d * Ks))) return fail(rc);
   if ((rc = launch_fill_zero(stream, Wx, (size_t)d * 64))) return fail(rc);
-  if ((rc = launch_copy_cols(stream, embW, E, 0, Wstatic, 128, 0, d, 63))) return fail(rc);
-  if ((rc = launch_copy_cols(stream, embW, E, 126, Wstatic, 128, 63, d, 21))) return fail(rc);
-  if ((rc = launch_copy_cols(stream, embW, E, 147, Wstatic, 128, 84, d, m->F))) return fail(rc);
+  if ((rc = launch_copy_cols(stream, embW, E, 0, Wstatic, Ks, 0, d, 63))) return fail(rc);
+  if ((rc = launch_copy_cols(stream, embW, E, 126, Wstatic, Ks, 63, d, 21))) return fail(rc);
+  if ((rc = launch_copy_cols(stream, embW, E, 147, Wstatic, Ks, 84, d, m->F))) return fail(rc);
+  if ((rc = launch_copy_cols(stream, embW, E, 147 + m->F, Wstatic, Ks, 128, d, m->Din))) return fail(rc);      // latent columns: one more k-range of the hoisted GEMM
   if ((rc = launch_copy_cols(stream, embW, E, 63, Wx, 64, 0, d, 63))) return fail(rc);
 
   m->layers.resize(L);
@@ -573,7 +584,7 @@ static int zero_rows(hipStream_t stream, void* base, size_t row_bytes, int row0,
 
 static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t stream, const float* cond, const float* feat,
                           const float* scales, const uint8_t* anchor, const int32_t* cu_batch, const int32_t* cu_part,
-                          int B, int nseg_part, int TP) {
+                          int B, int nseg_part, int TP, const float* latent = nullptr) {
   int rc;
   // the caller's tables are only ever read through sanitised copies: every index derived from them stays inside [0, TP]
   if ((rc = launch_sanitize_cu(stream, cu_batch, B + 1, TP, w.cu_batch_s))) return rc;
@@ -601,10 +612,21 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
   // base = [PE63(cond) | PE21(scale) | feat | 0] Wstatic^T + emb bias + anchor embedding   (embedding.py:155-179,
   // point_cloud_dit.py:119-139) -- everything in the embedding that does not depend on x_t.
   float* astatic = w.astatic;
-  if ((rc = launch_posenc_static(stream, cond, scales, w.token_sample, feat, m->F, astatic, TP))) return rc;
+  const int Ks = m->Ks;
+  if ((rc = launch_posenc_static(stream, cond, scales, w.token_sample, feat, m->F, astatic, TP, Ks))) return rc;
+  if (m->Din > 0) {
+    // latent point features (embedding.py:163-166: concatenated between the coordinate and the scale embeddings): step-invariant, so
+    // they are Din more columns of the hoisted K = Ks GEMM; columns 128 + Din .. Ks - 1 are zero padding up to the k-tile
+    if (Ks > 128 + m->Din &&
+        hipMemset2DAsync(astatic + 128 + m->Din, (size_t)Ks * 4, 0, (size_t)(Ks - 128 - m->Din) * 4, (size_t)TP, stream) != hipSuccess) {
+      rap_set_last_hip_error((int)hipGetLastError());
+      return RAP_ERR_HIP;
+    }
+    if ((rc = launch_copy_cols(stream, latent, m->Din, 0, astatic, Ks, 128, TP, m->Din))) return rc;
+  }
   GemmParams g{};
-  g.A = astatic; g.lda = 128; g.W = m->Wstatic; g.ldw = 128; g.C = w.base; g.ldc = m->d;
-  g.M = TP; g.N = m->d; g.K = 128; g.bias = m->emb_bias; g.anchor = anchor; g.anchor_emb = m->anchor_emb;
+  g.A = astatic; g.lda = Ks; g.W = m->Wstatic; g.ldw = Ks; g.C = w.base; g.ldc = m->d;
+  g.M = TP; g.N = m->d; g.K = Ks; g.bias = m->emb_bias; g.anchor = anchor; g.anchor_emb = m->anchor_emb;
   return launch_gemm_f32(stream, EPI_BIAS_ANCHOR, g);
 }
 
@@ -851,8 +873,15 @@ extern "C" int rap_dit_forward(const rap_model* m, const float* x_t, const float
                                const float* feat, const float* scales, const uint8_t* anchor, const int32_t* cu_batch,
                                const int32_t* cu_part, int32_t B, int32_t VP, int64_t TP, float* v_out, float* feats_out,
                                void* ws, size_t ws_bytes, void* stream_) {
+  return rap_dit_forward_latent(m, x_t, timesteps, cond, feat, nullptr, scales, anchor, cu_batch, cu_part, B, VP, TP, v_out, feats_out, ws, ws_bytes, stream_);
+}
+extern "C" int rap_dit_forward_latent(const rap_model* m, const float* x_t, const float* timesteps, const float* cond,
+                                      const float* feat, const float* latent, const float* scales, const uint8_t* anchor, const int32_t* cu_batch,
+                                      const int32_t* cu_part, int32_t B, int32_t VP, int64_t TP, float* v_out, float* feats_out,
+                                      void* ws, size_t ws_bytes, void* stream_) {
   if (!m || !x_t || !timesteps || !cond || !scales || !anchor || !cu_batch || !cu_part || !v_out) return RAP_ERR_INVALID;
   if (m->F > 0 && !feat) return RAP_ERR_INVALID;
+  if ((m->Din > 0) != (latent != nullptr)) return RAP_ERR_INVALID;      // a model built with in_dim > 0 needs its latent features, one without takes none
   if (B <= 0 || VP < 0 || TP < 0 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
   if (TP == 0) return RAP_OK;
   if (!ws) return RAP_ERR_WORKSPACE;
@@ -864,7 +893,7 @@ extern "C" int rap_dit_forward(const rap_model* m, const float* x_t, const float
   w.cu_part_live = w.cu_part_s;             // prepare_static sanitises the caller's part table into it
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
-  if ((rc = prepare_static(m, w, stream, cond, feat, scales, anchor, cu_batch, cu_part, B, VP, (int)TP))) return rc;
+  if ((rc = prepare_static(m, w, stream, cond, feat, scales, anchor, cu_batch, cu_part, B, VP, (int)TP, latent))) return rc;
   if ((rc = launch_adaln_table(stream, timesteps, B, 2 * m->L, m->d, m->adaW1, m->adab1, m->adaW2, m->adab2, m->adaW3,
                                m->adab3, w.ada_scratch, w.mod)))
     return rc;
@@ -951,9 +980,18 @@ extern "C" int rap_sample(const rap_model* m, const float* cond, const float* fe
                           int32_t B, int32_t P, int64_t TP, int32_t num_steps, int32_t rigidity_forcing, float* traj_x0,
                           float* traj_xt, float* R_out, float* t_out, float* feats_out, void* ws, size_t ws_bytes,
                           void* stream_) {
+  return rap_sample_latent(m, cond, feat, nullptr, scales, anchor, points_per_part, cu_batch, x_1, B, P, TP, num_steps, rigidity_forcing, traj_x0,
+                           traj_xt, R_out, t_out, feats_out, ws, ws_bytes, stream_);
+}
+extern "C" int rap_sample_latent(const rap_model* m, const float* cond, const float* feat, const float* latent, const float* scales,
+                                 const uint8_t* anchor, const int64_t* points_per_part, const int32_t* cu_batch, const float* x_1,
+                                 int32_t B, int32_t P, int64_t TP, int32_t num_steps, int32_t rigidity_forcing, float* traj_x0,
+                                 float* traj_xt, float* R_out, float* t_out, float* feats_out, void* ws, size_t ws_bytes,
+                                 void* stream_) {
   if (!m || !cond || !scales || !anchor || !points_per_part || !cu_batch || !x_1 || !traj_x0 || !traj_xt || !R_out || !t_out)
     return RAP_ERR_INVALID;
   if (m->F > 0 && !feat) return RAP_ERR_INVALID;
+  if ((m->Din > 0) != (latent != nullptr)) return RAP_ERR_INVALID;
   if (B <= 0 || P <= 0 || TP <= 0 || num_steps <= 0 || TP > 0x7fffffffLL / 8 || (int64_t)B * P > 65535) return RAP_ERR_INVALID;
   const int np = B * P;
   if (!ws) return RAP_ERR_WORKSPACE;
@@ -965,7 +1003,7 @@ extern "C" int rap_sample(const rap_model* m, const float* cond, const float* fe
   const long n3 = (long)TP * 3;
   int rc;
   if ((rc = launch_part_offsets(stream, points_per_part, np, w.part_offsets, (long)TP))) return rc;
-  if ((rc = prepare_static(m, w, stream, cond, feat, scales, anchor, cu_batch, w.part_offsets, B, np, T))) return rc;
+  if ((rc = prepare_static(m, w, stream, cond, feat, scales, anchor, cu_batch, w.part_offsets, B, np, T, latent))) return rc;
   // t is uniform over the batch inside the sampler (modeling.py:674), so the adaLN table is computed once for
   // ALL flow steps (row s = step s) instead of per sample per step.
   const double dt = 1.0 / (double)num_steps;
@@ -1253,6 +1291,18 @@ extern "C" int rap_relative_transforms(const float* R_pred, const float* t_pred,
 // ---------------------------------------------------------------------------------------------
 // cross-part overlap ratio
 // ---------------------------------------------------------------------------------------------
+// compute_transform_errors without ICP (reference eval/metrics.py:165-303): see transforms.hip
+extern "C" int rap_transform_errors(const float* R_gt, const float* t_gt, const float* R_pred, const float* t_pred,
+                                    const int64_t* points_per_part, const uint8_t* anchor_part, const int64_t* matched_part_ids,
+                                    const float* scale, int32_t B, int32_t P, float* rot_err_per_part, float* trans_err_per_part,
+                                    float* rot_err_mean, float* trans_err_mean, void* stream) {
+  if (!R_gt || !t_gt || !R_pred || !t_pred || !points_per_part || !anchor_part || !rot_err_per_part || !trans_err_per_part ||
+      !rot_err_mean || !trans_err_mean || B <= 0 || P <= 0)
+    return RAP_ERR_INVALID;
+  return launch_transform_errors((hipStream_t)stream, R_gt, t_gt, R_pred, t_pred, points_per_part, anchor_part, matched_part_ids, scale,
+                                 B, P, rot_err_per_part, trans_err_per_part, rot_err_mean, trans_err_mean);
+}
+
 struct OvWs { int32_t* off; int32_t* pid; float* min_dist; void* items; size_t total; };
 static OvWs carve_ov(int64_t TP, int B, int P, char* basep) {
   OvWs w; size_t off = 0;

@@ -46,12 +46,12 @@ int launch_posenc_x(hipStream_t stream, const float* x, float* ax, int TP) {
 //   [84,84+F) local features      rest     zero padding            (F <= 44, multiple of 4)
 __global__ __launch_bounds__(256) void posenc_static_kernel(const float* __restrict__ cond, const float* __restrict__ scales,
                                                             const int32_t* __restrict__ token_sample,
-                                                            const float* __restrict__ feat, int F, float* __restrict__ as, int TP) {
+                                                            const float* __restrict__ feat, int F, float* __restrict__ as, int TP, int ld) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const long tok = gid >> 5;
   const int j = (int)(gid & 31);
   if (tok >= TP) return;
-  float* o = as + tok * 128;
+  float* o = as + tok * ld;                  // ld = 128, or 128 + the latent-feature columns a model with in_dim > 0 appends
   if (j < 10) {
     const float* xp = cond + tok * 3;
     const float f = (float)(1 << j);
@@ -85,12 +85,12 @@ __global__ __launch_bounds__(256) void posenc_static_kernel(const float* __restr
 }
 
 int launch_posenc_static(hipStream_t stream, const float* cond, const float* scales, const int32_t* token_sample,
-                         const float* feat, int feat_dim, float* astatic, int TP) {
+                         const float* feat, int feat_dim, float* astatic, int TP, int ld) {
   if (TP <= 0) return RAP_OK;
-  if (feat_dim % 4 != 0 || feat_dim > 40 || feat_dim < 0) return RAP_ERR_INVALID;
+  if (feat_dim % 4 != 0 || feat_dim > 40 || feat_dim < 0 || ld < 128 || ld % 4 != 0) return RAP_ERR_INVALID;
   const long nthreads = (long)TP * 32;
   hipLaunchKernelGGL(posenc_static_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, cond, scales,
-                     token_sample, feat, feat_dim, astatic, TP);
+                     token_sample, feat, feat_dim, astatic, TP, ld);
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }

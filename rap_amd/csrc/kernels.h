@@ -76,7 +76,7 @@ int launch_qknorm(hipStream_t stream, float* qkv_headmajor, int TP, int heads, c
 // K1 feature builders (posenc): ax (TP,64) from x_t; astatic (TP,128) from cond / scale / features.
 int launch_posenc_x(hipStream_t stream, const float* x, float* ax, int TP);
 int launch_posenc_static(hipStream_t stream, const float* cond, const float* scales, const int32_t* token_sample,
-                         const float* feat, int feat_dim, float* astatic, int TP);
+                         const float* feat, int feat_dim, float* astatic, int TP, int ld = 128);
 // K3: adaLN modulation table.  t (rows,), out (rows, n_ln, 2d).  scratch: rows*n_ln*(256/n_ln + 2d) floats.
 int launch_adaln_table(hipStream_t stream, const float* t, int rows, int n_ln, int d, const float* W1,
                        const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
@@ -209,6 +209,11 @@ int launch_select_generation(hipStream_t stream, const float* rmse, int G, int B
 int launch_relative_transforms(hipStream_t stream, const float* R_pred, const float* t_pred, const float* R_gt, const float* t_gt,
                                const float* scales, const int64_t* ppp, int B, int P, const float* R_glob, const float* t_glob,
                                float* out);
+
+// per-part rotation / translation errors relative to the anchor part (transforms.hip; reference eval/metrics.py:165-303, no-ICP branch)
+int launch_transform_errors(hipStream_t stream, const float* R_gt, const float* t_gt, const float* R_pred, const float* t_pred,
+                            const int64_t* ppp, const uint8_t* anchor, const int64_t* matched, const float* scale, int B, int P,
+                            float* rot_pp, float* trans_pp, float* rot_mean, float* trans_mean);
 
 // cross-part overlap ratio (overlap.hip; reference eval/metrics.py:625-691)
 size_t overlap_max_items(long TP, int B);

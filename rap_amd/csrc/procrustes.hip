@@ -8,10 +8,10 @@
 //   t = mu_t - mu_s R^T ;  apply as  x R^T + t                                              (:36, :114)
 //
 // Three kernels, no host involvement:
-//  1. procrustes_moments: grid (16 chunks, parts); every block reduces 15 raw moments of its chunk
-//     (sum s, sum t, sum s t^T) in fp64 with wavefront shuffles and writes one partial record --
+//  1. procrustes_moments: grid (<= 16 chunks, parts), ~2048 points per chunk block (8 per thread); every block reduces 15 raw moments
+//     of its chunk (sum s, sum t, sum s t^T) in fp64 with ONE reduce-scatter butterfly per wave and writes one partial record --
 //     24 B read per point, deterministic (no atomics).
-//  2. procrustes_solve: one lane per part sums the 16 partials in fixed order, forms the centred H
+//  2. procrustes_solve: one lane per part sums the part's partials in fixed order, forms the centred H
 //     in fp64, runs a one-sided Jacobi SVD of the 3x3 and writes R (row-major) and t in fp32.
 //     Empty parts produce all-zero R, t (the reference leaves zero rows, procrustes.py:71-76).
 //  3. rigid_apply: out = src R^T + t, optionally blended x_t = out*w0 + x_1*w1 (sampler.py:60) and
@@ -19,16 +19,67 @@
 #include "kernels.h"
 #include "kabsch.h"
 
+// chunks a part of n points is split over: ~2048 points (8 per thread) per block, at most RAP_PROC_CHUNKS.  Round 6: the grid used to
+// run all 16 chunk blocks for every part -- 1 point per thread at configs[1] (4096-point parts), i.e. 1024 blocks whose time was the 15
+// fp64 wave reductions, not the 24 B per point they read (r05: 11.1 us for 6.3 MB).  Blocks beyond a part's chunk count leave at once.
+__device__ __forceinline__ int proc_chunks_of(int n) {
+  const int c = (n + 2047) / 2048;
+  return c < 1 ? 1 : c > RAP_PROC_CHUNKS ? RAP_PROC_CHUNKS : c;
+}
+
+// Sum of 16 per-lane doubles over the 64 lanes of a wave by a reduce-scatter butterfly: at distance 32 / 16 / 8 / 4 a lane hands the
+// half of its values it does not keep to its partner (8 + 4 + 2 + 1 exchanges), the last value is summed over distances 2 and 1 --
+// 17 fp64 exchanges instead of the 15 x 6 = 90 of one plain butterfly per moment.  On return lane L with L % 4 == 0 holds the total of
+// value index k = bit5(L) * 8 + bit4(L) * 4 + bit3(L) * 2 + bit2(L).  Fixed association: deterministic.
+__device__ __forceinline__ double wave_sum16_scatter(double (&v)[16], int lane) {
+  double w8[8], w4[4], w2[2];
+  {
+    const bool hi = (lane & 32) != 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double keep = hi ? v[8 + j] : v[j], give = hi ? v[j] : v[8 + j];
+      w8[j] = keep + __shfl_xor(give, 32, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 16) != 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double keep = hi ? w8[4 + j] : w8[j], give = hi ? w8[j] : w8[4 + j];
+      w4[j] = keep + __shfl_xor(give, 16, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 8) != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const double keep = hi ? w4[2 + j] : w4[j], give = hi ? w4[j] : w4[2 + j];
+      w2[j] = keep + __shfl_xor(give, 8, 64);
+    }
+  }
+  double r;
+  {
+    const bool hi = (lane & 4) != 0;
+    const double keep = hi ? w2[1] : w2[0], give = hi ? w2[0] : w2[1];
+    r = keep + __shfl_xor(give, 4, 64);
+  }
+  r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 1, 64);
+  return r;
+}
+
 __global__ __launch_bounds__(256) void procrustes_moments_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
                                                                  const int32_t* __restrict__ off, double* __restrict__ partials) {
   __shared__ double red[4][16];
   const int part = blockIdx.y, chunk = blockIdx.x;
   const int a = off[part], n = off[part + 1] - a;
-  const long lo = a + (long)n * chunk / RAP_PROC_CHUNKS;
-  const long hi = a + (long)n * (chunk + 1) / RAP_PROC_CHUNKS;
-  double m[15];
+  const int nc = proc_chunks_of(n);
+  if (chunk >= nc) return;
+  const long lo = a + (long)n * chunk / nc;
+  const long hi = a + (long)n * (chunk + 1) / nc;
+  double m[16];
 #pragma unroll
-  for (int k = 0; k < 15; ++k) m[k] = 0.0;
+  for (int k = 0; k < 16; ++k) m[k] = 0.0;
   for (long i = lo + threadIdx.x; i < hi; i += 256) {
     const double s0 = src[i * 3 + 0], s1 = src[i * 3 + 1], s2 = src[i * 3 + 2];
     const double t0 = tgt[i * 3 + 0], t1 = tgt[i * 3 + 1], t2 = tgt[i * 3 + 2];
@@ -39,11 +90,8 @@ __global__ __launch_bounds__(256) void procrustes_moments_kernel(const float* __
     m[12] += s2 * t0; m[13] += s2 * t1; m[14] += s2 * t2;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 15; ++k) {
-    const double v = wave_sum_d(m[k]);
-    if (lane == 0) red[wave][k] = v;
-  }
+  const double tot = wave_sum16_scatter(m, lane);
+  if ((lane & 3) == 0) red[wave][(((lane >> 5) & 1) << 3) | (((lane >> 4) & 1) << 2) | (((lane >> 3) & 1) << 1) | ((lane >> 2) & 1)] = tot;
   __syncthreads();
   if (threadIdx.x < 15) {
     const int k = threadIdx.x;
@@ -67,7 +115,8 @@ __global__ __launch_bounds__(64) void procrustes_solve_kernel(const double* __re
   double m[15];
 #pragma unroll
   for (int k = 0; k < 15; ++k) m[k] = 0.0;
-  for (int c = 0; c < RAP_PROC_CHUNKS; ++c) {
+  const int nc = proc_chunks_of(n);
+  for (int c = 0; c < nc; ++c) {
     const double* pr = partials + ((size_t)part * RAP_PROC_CHUNKS + c) * 16;
 #pragma unroll
     for (int k = 0; k < 15; ++k) m[k] += pr[k];

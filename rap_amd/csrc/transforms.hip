@@ -91,3 +91,103 @@ int launch_relative_transforms(hipStream_t stream, const float* R_pred, const fl
   RAP_LAUNCH_CHECK();
   return RAP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// compute_transform_errors, no-ICP branch (round 6; reference eval/metrics.py:165-303, the RRE / RTE BASELINE.json's "SE(3) err" is defined
+// by; the ICP branch is "for the interchangable case, which does not apply for point cloud registration tasks", metrics.py:264).
+// Per sample: the (first) anchor part's ground-truth and predicted poses are inverted, every non-anchor, non-empty part's poses are taken
+// relative to them, delta_R = R_gt_rel^T R_pred_rel, delta_t = (t_pred_rel - t_gt_rel) scale;
+//   RE = deg(acos(clamp((tr delta_R - 1) / 2, -1, 1))),  TE = |delta_t|;  means over the valid parts (0 / 0 = NaN as in the reference).
+// One block per sample, one lane per part; fp32 products in the reference's association (3 x 3 matmuls as fma chains over k), the
+// per-sample sums in part order by one lane (deterministic).  matched (B,P) int64 or null re-orders the PREDICTED poses (:223-227).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void te_mat3_mul(const float* A, const float* B, float* C) {       // C = A B, row-major
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) C[r * 3 + c] = fmaf(A[r * 3 + 2], B[6 + c], fmaf(A[r * 3 + 1], B[3 + c], A[r * 3] * B[c]));
+}
+__device__ __forceinline__ void te_mat3_vec(const float* A, const float* v, float* o) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) o[r] = fmaf(A[r * 3 + 2], v[2], fmaf(A[r * 3 + 1], v[1], A[r * 3] * v[0]));
+}
+__device__ __forceinline__ void te_transpose(const float* A, float* T) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) T[r * 3 + c] = A[c * 3 + r];
+}
+
+__global__ __launch_bounds__(64) void transform_errors_kernel(const float* __restrict__ R_gt, const float* __restrict__ t_gt,
+                                                              const float* __restrict__ R_pred, const float* __restrict__ t_pred,
+                                                              const int64_t* __restrict__ ppp, const uint8_t* __restrict__ anchor,
+                                                              const int64_t* __restrict__ matched, const float* __restrict__ scale, int P,
+                                                              float* __restrict__ rot_pp, float* __restrict__ trans_pp,
+                                                              float* __restrict__ rot_mean, float* __restrict__ trans_mean) {
+  const int b = blockIdx.x;
+  const size_t row = (size_t)b * P;
+  auto pred_index = [&](int p) -> size_t {
+    long q = matched ? (long)matched[row + p] : (long)p;
+    q = q < 0 ? 0 : q >= P ? P - 1 : q;              // an out-of-range match cannot index outside the sample's rows
+    return row + (size_t)q;
+  };
+  // the first anchor part (metrics.py:239-242), found by every lane the same way
+  int a = -1;
+  for (int p = 0; p < P; ++p)
+    if (anchor[row + p]) { a = p; break; }
+  float Rag_inv[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, tag_inv[3] = {0.f, 0.f, 0.f};
+  float Rap_inv[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, tap_inv[3] = {0.f, 0.f, 0.f};
+  if (a >= 0) {
+    float tmp[3];
+    te_transpose(R_gt + (row + a) * 9, Rag_inv);
+    te_mat3_vec(Rag_inv, t_gt + (row + a) * 3, tmp);
+    tag_inv[0] = -tmp[0]; tag_inv[1] = -tmp[1]; tag_inv[2] = -tmp[2];          // (-R^T) @ t evaluates the product of the negated matrix: same magnitude
+    const size_t ia = pred_index(a);
+    te_transpose(R_pred + ia * 9, Rap_inv);
+    te_mat3_vec(Rap_inv, t_pred + ia * 3, tmp);
+    tap_inv[0] = -tmp[0]; tap_inv[1] = -tmp[1]; tap_inv[2] = -tmp[2];
+  }
+  const float s = scale ? scale[b] : 1.0f;
+  for (int p = threadIdx.x; p < P; p += 64) {
+    float re = 0.f, te = 0.f;
+    if (ppp[row + p] != 0 && !anchor[row + p]) {
+      const size_t ip = pred_index(p);
+      float Rg_rel[9], Rp_rel[9], tg_rel[3], tp_rel[3], RgT[9], dR[9];
+      te_mat3_mul(Rag_inv, R_gt + (row + p) * 9, Rg_rel);
+      te_mat3_vec(Rag_inv, t_gt + (row + p) * 3, tg_rel);
+      te_mat3_mul(Rap_inv, R_pred + ip * 9, Rp_rel);
+      te_mat3_vec(Rap_inv, t_pred + ip * 3, tp_rel);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { tg_rel[k] += tag_inv[k]; tp_rel[k] += tap_inv[k]; }
+      te_transpose(Rg_rel, RgT);
+      te_mat3_mul(RgT, Rp_rel, dR);
+      const float tr = (dR[0] + dR[4]) + dR[8];
+      float c = 0.5f * (tr - 1.0f);
+      c = c < -1.0f ? -1.0f : c > 1.0f ? 1.0f : c;
+      re = acosf(c) * 57.29577951308232f;
+      const float d0 = (tp_rel[0] - tg_rel[0]) * s, d1 = (tp_rel[1] - tg_rel[1]) * s, d2 = (tp_rel[2] - tg_rel[2]) * s;
+      te = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    }
+    rot_pp[row + p] = re; trans_pp[row + p] = te;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sr = 0.f, st = 0.f; int n = 0;
+    for (int p = 0; p < P; ++p) {
+      sr += rot_pp[row + p]; st += trans_pp[row + p];
+      n += (ppp[row + p] != 0 && !anchor[row + p]) ? 1 : 0;
+    }
+    rot_mean[b] = sr / (float)n;             // 0 / 0 = NaN for a sample without a movable part, as the reference's division
+    trans_mean[b] = st / (float)n;
+  }
+}
+
+int launch_transform_errors(hipStream_t stream, const float* R_gt, const float* t_gt, const float* R_pred, const float* t_pred,
+                            const int64_t* ppp, const uint8_t* anchor, const int64_t* matched, const float* scale, int B, int P,
+                            float* rot_pp, float* trans_pp, float* rot_mean, float* trans_mean) {
+  if (B <= 0 || P <= 0) return RAP_OK;
+  hipLaunchKernelGGL(transform_errors_kernel, dim3(B), dim3(64), 0, stream, R_gt, t_gt, R_pred, t_pred, ppp, anchor, matched, scale, P,
+                     rot_pp, trans_pp, rot_mean, trans_mean);
+  RAP_LAUNCH_CHECK();
+  return RAP_OK;
+}

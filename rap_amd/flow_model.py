@@ -61,8 +61,11 @@ class PointCloudDiT:
                  final_mlp_act=None, max_points_per_part: int = 500, max_points_per_batch: int = 40000,
                  scale_emb_on: bool = True, local_feat_concat_on: bool = True, local_feat_dim: int = 0,
                  compute_dtype: str | None = "float32", residual_dtype: str | None = None):
-        if in_dim != 0:
-            raise NotImplementedError("in_dim != 0 (PTv3 encoder latent) is off in every shipped config (rap_12.yaml:17)")
+        # in_dim > 0 (round 6; embedding.py:107-118,163-166; modeling.py:788 builds in_dim = 64): `latent_features` (TP, in_dim) are
+        # concatenated into the embedding input between the coordinate and the scale embeddings.  Off in every shipped config
+        # (encoder_on: false) but part of the cited files: the native model takes them as in_dim more columns of the hoisted embedding GEMM.
+        if in_dim < 0 or in_dim % 4 != 0 or in_dim > 512:
+            raise NotImplementedError("in_dim must be a multiple of 4 in [0, 512]")
         if out_dim != 3:
             raise NotImplementedError("out_dim must be 3")
         if dropout_rate != 0.0 or softcap != 0.0:
@@ -102,7 +105,7 @@ class PointCloudDiT:
         if residual_dtype not in ("auto", "float32", "float16"):
             raise ValueError(f"Unsupported residual_dtype: {residual_dtype}")
         self.residual_dtype = residual_dtype
-        self.cfg = dict(embed_dim=embed_dim, num_layers=num_layers, num_heads=num_heads, local_feat_dim=local_feat_dim,
+        self.cfg = dict(embed_dim=embed_dim, num_layers=num_layers, num_heads=num_heads, local_feat_dim=local_feat_dim, in_dim=in_dim,
                         qk_norm=self.qk_norm, scale_emb_on=self.scale_emb_on, local_feat_concat_on=self.local_feat_concat_on)
         self._spec = weight_spec(self.cfg)              # the reference's state_dict for THIS configuration (names, shapes, order)
         # the native model always has the full layout: [cond 63 | x_t 63 | scale 21 | feat F'] embedding input and both qk-norm gains;
@@ -115,7 +118,7 @@ class PointCloudDiT:
         self._device: torch.device | None = None
         self._desc = _lib.ModelDesc(embed_dim, num_layers, num_heads, self._native_feat)
         lib = _lib.load()
-        n = lib.rap_weight_count(ctypes.byref(self._desc))
+        n = lib.rap_weight_count_latent(ctypes.byref(self._desc), int(in_dim))
         if n < 0:
             raise NotImplementedError(f"unsupported PointCloudDiT configuration {self.cfg}")
         self._n_floats = int(n)
@@ -189,8 +192,8 @@ class PointCloudDiT:
             blob = torch.cat([t.reshape(-1) for t in self._native_tensors()]).to(device=device, dtype=torch.float32)
             assert blob.numel() == self._n_floats
             handle = ctypes.c_void_p(0)
-            rc = lib.rap_model_create(ctypes.byref(self._desc), _lib.ptr(blob), blob.numel(),
-                                      _lib.current_stream(device), ctypes.byref(handle))
+            rc = lib.rap_model_create_latent(ctypes.byref(self._desc), int(self.in_dim), _lib.ptr(blob), blob.numel(),
+                                             _lib.current_stream(device), ctypes.byref(handle))
             _lib.check(rc, "rap_model_create")
             if not self.qk_norm:
                 _lib.check(lib.rap_model_set_qk_norm(handle, 0), "rap_model_set_qk_norm")
@@ -203,13 +206,16 @@ class PointCloudDiT:
         native model skips the norm then; the values are never read)."""
         d, H = self.embed_dim, self.num_heads
         for n, shape in weight_spec(self._native_cfg):
-            if n in self._sd and tuple(self._sd[n].shape) == tuple(shape):
+            if n in self._sd and tuple(self._sd[n].shape) == tuple(shape) and not (self.in_dim and n == "encoding_manager.emb_proj.weight"):
                 yield self._sd[n]
             elif n == "encoding_manager.emb_proj.weight":
                 w = self._sd[n]
-                full = torch.zeros(shape, dtype=torch.float32)
+                F = self._native_feat
+                full = torch.zeros((shape[0], 147 + F + self.in_dim), dtype=torch.float32)      # native order: cond | x_t | scale | feat | latent
                 full[:, :126] = w[:, :126]                                   # cond PE | x_t PE
                 c = 126
+                if self.in_dim:                                              # the reference concatenates the latent features HERE (embedding.py:163-166)
+                    full[:, 147 + F:] = w[:, c:c + self.in_dim]; c += self.in_dim
                 if self.scale_emb_on:
                     full[:, 126:147] = w[:, c:c + 21]; c += 21
                 if self.local_feat_concat_on:
@@ -246,8 +252,8 @@ class PointCloudDiT:
     def forward(self, x, timesteps, cond_coord, local_features, latent_features, scales, anchor_indices,
                 cu_seqlens_batch, cu_seqlens_part, return_transformer_features: bool = False):
         """(TP,3) velocity, or {'velocity','transformer_features'}  (point_cloud_dit.py:141-191)."""
-        if latent_features is not None:
-            raise NotImplementedError("latent_features must be None (in_dim == 0)")
+        if (latent_features is None) != (self.in_dim == 0):
+            raise ValueError("latent_features must be None (in_dim == 0)" if self.in_dim == 0 else f"latent_features (TP, {self.in_dim}) required")
         _require_cuda(x, "x")
         device = x.device
         self._activate(device)
@@ -258,6 +264,9 @@ class PointCloudDiT:
         x = _f32c(x); cond = _f32c(cond_coord.reshape(TP, 3))
         # local_feat_concat_on=False: the reference ignores the features (embedding.py:175); the native model was built without them
         feats = _f32c(local_features.reshape(TP, -1)) if (self.local_feat_concat_on and local_features is not None) else None
+        latent = None if latent_features is None else _f32c(latent_features.to(device).reshape(TP, -1))
+        if latent is not None and latent.shape[1] != self.in_dim:
+            raise ValueError(f"latent_features must be (TP, {self.in_dim})")
         ts = _f32c(timesteps.to(device)); sc = _f32c(scales.to(device))
         anchor = anchor_indices.to(device=device, dtype=torch.uint8).contiguous()
         cu_b = cu_seqlens_batch.to(device=device, dtype=torch.int32).contiguous()
@@ -269,9 +278,9 @@ class PointCloudDiT:
         nbytes = lib.rap_workspace_bytes(self._handle, TP, B, VP, B)
         ws = workspace(device, nbytes)
         with torch.cuda.device(device):
-            rc = lib.rap_dit_forward(self._handle, _lib.ptr(x), _lib.ptr(ts), _lib.ptr(cond), _lib.ptr(feats), _lib.ptr(sc),
-                                     _lib.ptr(anchor), _lib.ptr(cu_b), _lib.ptr(cu_p), B, VP, TP, _lib.ptr(v),
-                                     _lib.ptr(feat_out), _lib.ptr(ws), ws.numel(), _lib.current_stream(device))
+            rc = lib.rap_dit_forward_latent(self._handle, _lib.ptr(x), _lib.ptr(ts), _lib.ptr(cond), _lib.ptr(feats), _lib.ptr(latent), _lib.ptr(sc),
+                                            _lib.ptr(anchor), _lib.ptr(cu_b), _lib.ptr(cu_p), B, VP, TP, _lib.ptr(v),
+                                            _lib.ptr(feat_out), _lib.ptr(ws), ws.numel(), _lib.current_stream(device))
         _lib.check(rc, "rap_dit_forward")
         if return_transformer_features:
             return {"velocity": v, "transformer_features": feat_out}

@@ -66,3 +66,35 @@ def compute_correspondence_rmse(source_gt, target_gt, source_pred, target_pred, 
     if n == 0:
         return torch.tensor(float("inf"), device=device), 0, 0.0          # :453-454
     return out[0], n, n / Ns
+
+
+def compute_transform_errors(pointclouds, pointclouds_gt, rotations_gt, translations_gt, rotations_pred, translations_pred, points_per_part,
+                             anchor_part, matched_part_ids=None, scale=None, cu_seqlens_batch=None, use_icp: bool = False,
+                             return_per_part: bool = False):
+    """Reference signature (eval/metrics.py:165-303) -> (rot_errors_mean (B,) in degrees, trans_errors_mean (B,)); the RRE / RTE of the
+    registration task.  ``use_icp=False`` only: the ICP refinement is pytorch3d's and, in the reference's own words, "for the interchangable
+    case, which does not apply for point cloud registration tasks" (:264).  ``pointclouds`` / ``pointclouds_gt`` / ``cu_seqlens_batch`` are
+    accepted for signature parity -- the no-ICP branch reads only the poses.  One kernel, no host synchronisation (the reference loops
+    B x P with a ``.nonzero()`` per sample).  ``return_per_part`` (an extension) also returns the (B,P) per-part errors."""
+    if use_icp:
+        raise NotImplementedError("use_icp=True (pytorch3d iterative_closest_point) is not part of the registration path (metrics.py:264)")
+    _require_cuda(rotations_pred, "rotations_pred")
+    device = rotations_pred.device
+    B, P = points_per_part.shape
+    Rg, tg = _f32c(rotations_gt.to(device).reshape(B, P, 3, 3)), _f32c(translations_gt.to(device).reshape(B, P, 3))
+    Rp, tp = _f32c(rotations_pred.reshape(B, P, 3, 3)), _f32c(translations_pred.to(device).reshape(B, P, 3))
+    ppp = points_per_part.to(device=device, dtype=torch.int64).contiguous()
+    anc = anchor_part.to(device=device, dtype=torch.uint8).contiguous()
+    mid = None if matched_part_ids is None else matched_part_ids.to(device=device, dtype=torch.int64).contiguous()
+    sc = None if scale is None else _f32c(scale.to(device).reshape(B))
+    rot_pp = torch.empty((B, P), dtype=torch.float32, device=device); trans_pp = torch.empty_like(rot_pp)
+    rot_m = torch.empty((B,), dtype=torch.float32, device=device); trans_m = torch.empty_like(rot_m)
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        rc = lib.rap_transform_errors(_lib.ptr(Rg), _lib.ptr(tg), _lib.ptr(Rp), _lib.ptr(tp), _lib.ptr(ppp), _lib.ptr(anc), _lib.ptr(mid),
+                                      _lib.ptr(sc), B, P, _lib.ptr(rot_pp), _lib.ptr(trans_pp), _lib.ptr(rot_m), _lib.ptr(trans_m),
+                                      _lib.current_stream(device))
+    _lib.check(rc, "rap_transform_errors")
+    if return_per_part:
+        return rot_m, trans_m, rot_pp, trans_pp
+    return rot_m, trans_m

@@ -54,7 +54,10 @@ class RectifiedPointFlow:
         if flow_model is None:
             raise ValueError("flow_model is required")            # modeling.py:80-81
         if encoder_on:
-            raise NotImplementedError("encoder_on=True (PTv3 latent) is disabled in every shipped config")
+            # the PTv3 feature extractor itself is outside SURVEY.md section 8; a flow model built with in_dim > 0 takes the latent
+            # features it would produce through sample_rectified_flow(data_dict, latent_features, ...) exactly as the reference passes them
+            raise NotImplementedError("encoder_on=True: run the PTv3 encoder yourself and pass its output as latent_features "
+                                      "(flow_model in_dim > 0)")
         if inference_sampler != "euler":
             raise ValueError(f"Unknown sampler: {inference_sampler}. Available: ['euler']")   # sampler.py:168-169
         self.flow_model = flow_model
@@ -149,11 +152,13 @@ class RectifiedPointFlow:
     # modeling.py:203-231 without the boolean-mask compaction (which syncs): empty parts stay in the table as
     # zero-length segments, which every kernel treats as a no-op and which yields the same zero R,t rows.
     @staticmethod
-    def _prepare_data(data_dict: dict):
+    def _prepare_data(data_dict: dict, latent_features: torch.Tensor | None = None):
         cond = data_dict["pointclouds"]
         _require_cuda(cond, 'data_dict["pointclouds"]')
         device = cond.device
         return dict(
+            # latent point features (TP, in_dim) of a flow model built with in_dim > 0 (modeling.py:636, embedding.py:163-166), else None
+            latent=None if latent_features is None else _f32c(latent_features.to(device).reshape(cond.shape[0], -1)),
             cond=_f32c(cond), feats=_f32c(data_dict["features"].to(device)), scales=_f32c(data_dict["scales"].to(device)),
             anchor=data_dict["anchor_indices"].to(device=device, dtype=torch.uint8).contiguous(),
             ppp=data_dict["points_per_part"].to(device=device, dtype=torch.int64).contiguous(),
@@ -167,14 +172,17 @@ class RectifiedPointFlow:
 
     @torch.inference_mode()
     def sample_and_register(self, data_dict: dict, x_1: torch.Tensor | None = None,
-                            return_transformer_features: bool = False) -> dict:
+                            return_transformer_features: bool = False, latent_features: torch.Tensor | None = None) -> dict:
         """One generation: {'end_point_trajectory','trajectory' (S,TP,3), 'R' (B,P,3,3), 't' (B,P,3)[, features]}.
 
         With ``num_streams`` > 1 the batch is cut at sample boundaries into that many shards of about equal token count, which run
         concurrently on the current stream and on auxiliary streams (forked from / joined back into the current stream with
         events: the call stays stream-ordered for the caller).  The cut needs the token offsets of the samples on the HOST: free
         when ``cu_seqlens`` is a CPU tensor (as the reference's collate delivers it), one (B+1)-int read otherwise."""
-        d = self._prepare_data(data_dict)
+        d = self._prepare_data(data_dict, latent_features)
+        in_dim = int(getattr(self.flow_model, "in_dim", 0))
+        if (d["latent"] is None) != (in_dim == 0) or (d["latent"] is not None and d["latent"].shape[1] != in_dim):
+            raise ValueError(f"latent_features must be (TP, {in_dim}) for this flow model" if in_dim else "latent_features must be None (in_dim == 0)")
         B = d["ppp"].shape[0]
         n = min(self._resolved_streams(), B)
         d["flag"] = self._validate(d)             # once for the whole batch, before any shard is forked (ADVICE r03)
@@ -202,7 +210,7 @@ class RectifiedPointFlow:
             b0, b1 = cuts[k], cuts[k + 1]
             t0, t1 = cu_host[b0], cu_host[b1]
             shard = dict(cond=cond[t0:t1], feats=d["feats"][t0:t1], scales=d["scales"][b0:b1], anchor=d["anchor"][t0:t1],
-                         ppp=d["ppp"][b0:b1], cu_batch=None, flag=d["flag"])
+                         ppp=d["ppp"][b0:b1], cu_batch=None, flag=d["flag"], latent=None if d["latent"] is None else d["latent"][t0:t1])
             if k == 0 or sequential:
                 shard["cu_batch"] = d["cu_batch"][: b1 + 1] if k == 0 else (d["cu_batch"][b0: b1 + 1] - int(t0)).contiguous()
                 parts[k] = self._sample_shard(shard, x_1[t0:t1], return_transformer_features)
@@ -215,7 +223,8 @@ class RectifiedPointFlow:
             with torch.cuda.stream(st):
                 shard["cu_batch"] = (d["cu_batch"][b0: b1 + 1] - int(t0)).contiguous()
                 parts[k] = self._sample_shard(shard, x_1[t0:t1], return_transformer_features)
-            for v in (cond, d["feats"], d["scales"], d["anchor"], d["ppp"], d["cu_batch"], x_1) + ((d["flag"],) if d["flag"] is not None else ()):
+            for v in (cond, d["feats"], d["scales"], d["anchor"], d["ppp"], d["cu_batch"], x_1) + ((d["flag"],) if d["flag"] is not None else ()) + (
+                    (d["latent"],) if d["latent"] is not None else ()):
                 v.record_stream(st)                                  # caching-allocator safety: these are read on `st`
         if not sequential:
             for k in range(1, nsh):
@@ -306,6 +315,7 @@ class RectifiedPointFlow:
         if entry is None:
             static = {k: d[k].clone() for k in ("cond", "feats", "scales", "anchor", "ppp", "cu_batch")}
             static["flag"] = None
+            static["latent"] = None if d.get("latent") is None else d["latent"].clone()
             sx = x_1.clone()
             self._sample_shard(static, sx, return_transformer_features)      # eager warm-up: weight copies, attributes, allocator
             torch.cuda.current_stream(device).synchronize()
@@ -321,6 +331,8 @@ class RectifiedPointFlow:
         graph, static, sx, out = entry
         for k in ("cond", "feats", "scales", "anchor", "ppp", "cu_batch"):
             static[k].copy_(d[k])
+        if static["latent"] is not None:
+            static["latent"].copy_(d["latent"])
         sx.copy_(x_1)
         graph.replay()
         res = {k: v.clone() for k, v in out.items()}
@@ -354,10 +366,10 @@ class RectifiedPointFlow:
         stream = _lib.current_stream(device)
         with torch.cuda.device(device):
             feats = d["feats"] if getattr(model, "_native_feat", 1) else None      # local_feat_concat_on=False: the features are not an input
-            rc = lib.rap_sample(model._handle, _lib.ptr(cond), _lib.ptr(feats), _lib.ptr(d["scales"]), _lib.ptr(d["anchor"]),
-                                _lib.ptr(d["ppp"]), _lib.ptr(d["cu_batch"]), _lib.ptr(x_1), B, P, TP, S,
-                                1 if self.rigidity_forcing else 0, _lib.ptr(traj_x0), _lib.ptr(traj_xt), _lib.ptr(R),
-                                _lib.ptr(t), _lib.ptr(feats_out), _lib.ptr(ws), ws.numel(), stream)
+            rc = lib.rap_sample_latent(model._handle, _lib.ptr(cond), _lib.ptr(feats), _lib.ptr(d.get("latent")), _lib.ptr(d["scales"]),
+                                       _lib.ptr(d["anchor"]), _lib.ptr(d["ppp"]), _lib.ptr(d["cu_batch"]), _lib.ptr(x_1), B, P, TP, S,
+                                       1 if self.rigidity_forcing else 0, _lib.ptr(traj_x0), _lib.ptr(traj_xt), _lib.ptr(R),
+                                       _lib.ptr(t), _lib.ptr(feats_out), _lib.ptr(ws), ws.numel(), stream)
             _lib.check(rc, "rap_sample")
             flag = d.get("flag")
             if flag is not None:
@@ -378,9 +390,7 @@ class RectifiedPointFlow:
         The per-part poses of the final end point -- what ``test_step`` computes next with
         ``fit_transformations(cond, trajs[-1], ...)`` (modeling.py:389-391) -- come out of the same call and are
         kept in ``self.last_poses`` as ``(R (B,P,3,3), t (B,P,3))``."""
-        if latent_features is not None:
-            raise NotImplementedError("latent_features must be None (encoder_on=False)")
-        out = self.sample_and_register(data_dict, x_1, return_transformer_features)
+        out = self.sample_and_register(data_dict, x_1, return_transformer_features, latent_features=latent_features)
         self.last_poses = (out["R"], out["t"])
         result = {"end_point_trajectory": out["end_point_trajectory"], "trajectory": out["trajectory"]}
         if return_transformer_features:
@@ -392,7 +402,7 @@ class RectifiedPointFlow:
 
     @torch.inference_mode()
     def sample_generations(self, data_dict: dict, x_1_list=None, use_average_rigidity_rmse: bool = True,
-                           batch_generations: bool | None = None) -> dict:
+                           batch_generations: bool | None = None, latent_features: torch.Tensor | None = None) -> dict:
         """``n_generations`` samples per object + the reference's rigidity-based selection (test_step, modeling.py:397-592):
         per generation the trajectory, final cloud and poses; per object the generation whose rigidity RMSE is smallest --
         averaged over all end-point trajectory steps (``use_average_rigidity_rmse``, modeling.py:466-500) or taken at the
@@ -406,7 +416,7 @@ class RectifiedPointFlow:
         generations come out of one trajectory pass over the stacked batch."""
         from .selection import (average_trajectory_rigidity_rmse, compute_rigidity_rmse, select_generations_by_rigidity)
         G = int(self.n_generations)
-        d = self._prepare_data(data_dict)
+        d = self._prepare_data(data_dict, latent_features)
         cond, ppp, cu, scales = d["cond"], d["ppp"], d["cu_batch"], d["scales"]
         B, P = ppp.shape
         TP = cond.shape[0]
@@ -431,7 +441,7 @@ class RectifiedPointFlow:
                              for g in range(G)])
             offs = (torch.arange(G, device=device, dtype=torch.int32) * TP)[:, None]
             big = dict(cond=cond.repeat(G, 1), feats=d["feats"].repeat(G, 1), scales=scales.repeat(G), anchor=d["anchor"].repeat(G),
-                       ppp=ppp.repeat(G, 1),
+                       ppp=ppp.repeat(G, 1), latent=None if d["latent"] is None else d["latent"].repeat(G, 1),
                        cu_batch=torch.cat([(cu[:-1][None, :] + offs).reshape(-1), cu.new_full((1,), G * TP)]).contiguous(),
                        flag=self._validate(d))                       # the G copies are consistent iff the batch is
             o = self._sample_shard(big, x_1, False)   # one stream: the stacked call fills the chip; shards would only cut it up again
@@ -448,7 +458,7 @@ class RectifiedPointFlow:
             gens = []
             for g in range(G):
                 x_1 = None if x_1_list is None else x_1_list[g]
-                gens.append(self.sample_and_register(data_dict, x_1=x_1))
+                gens.append(self.sample_and_register(data_dict, x_1=x_1, latent_features=latent_features))
             if avg:
                 rig = [average_trajectory_rigidity_rmse(cond, o["end_point_trajectory"], ppp, cu, scales) for o in gens]
             else:

@@ -26,8 +26,10 @@ RAP_16 = dict(embed_dim=512, num_layers=16, num_heads=8, local_feat_dim=32)
 
 
 def embed_in_dim(cfg) -> int:
-    """63 (cond PE) + 63 (x_t PE) + 21 (scale PE, if scale_emb_on) + local_feat_dim (if local_feat_concat_on)  (embedding.py:107-118)."""
-    return 63 + 63 + (21 if cfg.get("scale_emb_on", True) else 0) + (cfg["local_feat_dim"] if cfg.get("local_feat_concat_on", True) else 0)
+    """63 (cond PE) + 63 (x_t PE) + in_dim (latent point features, 0 in every shipped config) + 21 (scale PE, if scale_emb_on)
+    + local_feat_dim (if local_feat_concat_on)  (embedding.py:107-118)."""
+    return (63 + 63 + int(cfg.get("in_dim", 0)) + (21 if cfg.get("scale_emb_on", True) else 0)
+            + (cfg["local_feat_dim"] if cfg.get("local_feat_concat_on", True) else 0))
 
 
 def weight_spec(cfg) -> list[tuple[str, tuple[int, ...]]]:
@@ -88,6 +90,37 @@ def make_weights(cfg, seed: int = 0) -> dict[str, torch.Tensor]:
             bound = 1.0 / math.sqrt(fan_in)
             w = (torch.rand(shape, generator=g) * 2 - 1) * bound
         sd[name] = w.to(torch.float32).contiguous()
+    return sd
+
+
+ENVELOPE_KINDS = ("big_geglu", "tiny_geglu", "mixed_gains")
+
+
+def envelope_weights(cfg, seed: int, kind: str) -> dict[str, torch.Tensor]:
+    """Seeded weights pushed to the edges of the split-precision / bounded-softmax envelope -- the SAME function of
+    its inputs up to rounding in the first two cases, so the reference's fp32 result stays O(1) while an intermediate leaves fp16's comfort zone:
+      big_geglu    ff.net.0.proj (weight, bias) x 48 and ff.net.2.weight / 48^2: the GEGLU output h * gelu(g) grows ~2 300 x (10^3 ... 10^4,
+                   toward fp16's 65 504) and the down-projection takes it back;
+      tiny_geglu   ff.net.0.proj / 64 and ff.net.2.weight x 64^2: GEGLU outputs of 10^-5 ... 10^-3, whose fp16 TAILS (x 2^-11) are subnormal or
+                   zero -- the values themselves straddle fp16's smallest normal number 6.1e-5;
+      mixed_gains  the q / k gains of layer 0's per-part attention and layer 1's per-sample attention x 2.5 (logit bound 8 max|gq| max|gk| up
+                   to ~110 > 40: online softmax), the other two launches untouched (bound <= 18: bounded softmax) -- kernel choice per launch."""
+    sd = make_weights(cfg, seed)
+    L = cfg["num_layers"]
+    if kind == "big_geglu" or kind == "tiny_geglu":
+        a = 48.0 if kind == "big_geglu" else 1.0 / 64.0
+        for i in range(L):
+            p = f"transformer_layers.{i}."
+            sd[p + "ff.net.0.proj.weight"] = sd[p + "ff.net.0.proj.weight"] * a
+            sd[p + "ff.net.0.proj.bias"] = sd[p + "ff.net.0.proj.bias"] * a
+            sd[p + "ff.net.2.weight"] = sd[p + "ff.net.2.weight"] / (a * a)
+    elif kind == "mixed_gains":
+        for i, which in ((0, "self"), (1 % L, "global")):
+            p = f"transformer_layers.{i}.{which}_"
+            sd[p + "q_norm.gamma"] = sd[p + "q_norm.gamma"] * 2.5
+            sd[p + "k_norm.gamma"] = sd[p + "k_norm.gamma"] * 2.5
+    else:
+        raise ValueError(f"unknown envelope kind {kind!r} (one of {ENVELOPE_KINDS})")
     return sd
 
 

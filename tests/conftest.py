@@ -35,3 +35,6 @@ MODEL_SIZE_CASES = ["l16_small_rigid", "l10_small_free"]
 # unmodified reference (round 5; oracle/make_golden.py CASE_SWITCHES): name -> keyword overrides
 SWITCH_CASES = {"l2_noqknorm_rigid": {"qk_norm": False}, "l2_noscale_free": {"scale_emb_on": False},
                 "l2_nofeat_rigid": {"local_feat_concat_on": False}}
+# round 6: a model with in_dim = 64 (latent point features concatenated into the embedding, embedding.py:163-166); the fixture carries
+# `in_latent_features` (TP, 64) next to the usual inputs
+LATENT_CASES = {"l2_latent64_rigid": {"in_dim": 64}}

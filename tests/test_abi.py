@@ -51,7 +51,7 @@ def test_header_is_plain_c_and_a_c_program_links_against_the_library(lib_path, t
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", src])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "0 failure(s), ABI version 5" in r.stdout
+    assert "0 failure(s), ABI version 6" in r.stdout
 
 
 def test_weight_count_matches_reference_parameter_count(lib_path):
@@ -191,5 +191,5 @@ def test_splitk_rule_of_the_16bit_residual_gemm_is_host_arithmetic():
     # epilogue 6 (two different meanings in rounds 2 and 3) is retired with ABI version 4: refused, never reinterpreted
     assert lib.rap_gemm_h16_splitk(1, 6, one, 2048, one, 2048, one, 512, 2048, 512, 2048, N, one, 512, one, 1 << 30, N) == -1
     assert lib.rap_gemm_h16(1, 6, one, 512, one, 512, one, 512, 256, 512, 512, N, one, 512, 0, N, 0, N) == -1
-    assert lib.rap_version() == _lib.ABI_VERSION == 5
+    assert lib.rap_version() == _lib.ABI_VERSION == 6
     assert lib.rap_poison_on_flag(N, one, 4, N) == -1 and lib.rap_poison_on_flag(one, N, 4, N) == -1

@@ -1,0 +1,61 @@
+"""GPU: the ENVELOPE of the split-precision mode ("float32x2") and of the per-launch softmax selection against the unmodified reference
+ -- not at kernel level (tests/test_x2_gpu.py does that) but through the whole velocity network and the sampling call.
+
+Fixtures: tests/golden/envelope_{big_geglu,tiny_geglu,mixed_gains}.npz, produced by oracle/make_golden.py --envelope-only from the reference's
+own modules (fp32, CPU) on rap_amd.synthetic.envelope_weights:
+  big_geglu    GEGLU outputs up to 8.6e3 (fp16 saturates at 65 504; head / tail planes are clipped there),
+  tiny_geglu   GEGLU outputs of median 1.6e-5, maximum 4.9e-4 -- around and below fp16's smallest normal number 6.1e-5: the fp16 TAIL of such a
+               value is a subnormal or zero, so an un-scaled head + tail pair carries 11-14 bits, not 22,
+  mixed_gains  two of the four attention launches with logit bounds > 40 (online softmax), two with bounds <= 18 (bounded softmax).
+The exact-fp32 mode is held to the usual fp32 asserts on all three; the split-precision mode is held to the SAME asserts (since round 6 the
+GEGLU epilogue stores its planes times a power of two chosen per launch from the weights' scale -- see gemm_x2_epilogue)."""
+import pytest
+import torch
+
+import rap_amd
+from conftest import load_golden
+from oracle import rap_oracle as O
+from rap_amd import _lib, synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("mode", ["float32", "float32x2"])
+@pytest.mark.parametrize("kind", list(S.ENVELOPE_KINDS))
+def test_envelope_fixture_of_the_reference(kind, mode, dev):
+    lib = _lib.load()
+    g, inp = load_golden(f"envelope_{kind}")
+    cfg = dict(S.RAP_12); cfg["num_layers"] = int(g["num_layers"])
+    sd = S.envelope_weights(cfg, int(g["weight_seed"]), kind)
+    assert abs(sum(v.double().sum().item() for v in sd.values()) - float(g["weights_checksum"])) < 1e-3
+    try:
+        assert lib.rap_set_tuning(17, 0) == 0                  # the split kernels whatever the call size
+        model = rap_amd.PointCloudDiT(in_dim=0, out_dim=3, embed_dim=512, num_layers=cfg["num_layers"], num_heads=8, local_feat_dim=32,
+                                      attn_dtype="float32", compute_dtype=mode)
+        model.load_state_dict(sd); model.to(dev)
+        if kind == "mixed_gains":      # per-launch selection: exactly the two untouched launches are bounded
+            assert lib.rap_model_bounded_attention_launches(model._handle) == 2
+        cu_b, cu_p = O.prepare_cu_seqlens(inp)
+        d = {k: v.to(dev) for k, v in inp.items()}
+        v = model(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"], local_features=d["features"],
+                  latent_features=None, scales=d["scales"], anchor_indices=d["anchor_indices"], cu_seqlens_batch=cu_b.to(dev),
+                  cu_seqlens_part=cu_p.to(dev)).cpu()
+        flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=int(g["num_steps"]), rigidity_forcing=True)
+        res = flow.sample_rectified_flow(d, None, x_1=d["x_1"])
+        R, t = flow.last_poses
+    finally:
+        assert lib.rap_set_tuning(17, 1024) == 0
+    v_ref = torch.from_numpy(g["fwd_velocity"])
+    ev = float((v - v_ref).abs().max()) / float(v_ref.abs().max())
+    e0 = float((res["end_point_trajectory"].cpu() - torch.from_numpy(g["end_point_trajectory"])).abs().max())
+    eR = float(torch.linalg.matrix_norm(R.cpu() - torch.from_numpy(g["R"])).max())
+    print(f"envelope {kind} [{mode}]: |GEGLU| max {float(g['geglu_abs_max']):.3g} median {float(g['geglu_abs_median']):.3g};  "
+          f"velocity {ev:.2e} of max|v|, clouds {e0:.2e}, |dR|_F {eR:.2e}")
+    assert torch.isfinite(v).all() and torch.isfinite(res["end_point_trajectory"]).all()
+    assert ev < 1e-4 and e0 < 5e-5 and eR < 1e-4, (kind, mode, ev, e0, eR)

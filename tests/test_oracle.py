@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_CASES, MODEL_SIZE_CASES, SWITCH_CASES, load_golden
+from conftest import GOLDEN_CASES, LATENT_CASES, MODEL_SIZE_CASES, SWITCH_CASES, load_golden
 from oracle import rap_oracle as O
 from oracle import ref_loader
 from rap_amd import synthetic as S
@@ -17,10 +17,11 @@ def _cfg(g, name=None):
     cfg = dict(S.RAP_12)
     cfg["num_layers"] = int(g["num_layers"])
     cfg.update(SWITCH_CASES.get(name, {}))
+    cfg.update(LATENT_CASES.get(name, {}))
     return cfg
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES + MODEL_SIZE_CASES + list(SWITCH_CASES))
+@pytest.mark.parametrize("name", GOLDEN_CASES + MODEL_SIZE_CASES + list(SWITCH_CASES) + list(LATENT_CASES))
 def test_oracle_matches_reference_golden(name):
     g, inp = load_golden(name)
     cfg = _cfg(g, name)
@@ -39,18 +40,21 @@ def test_oracle_matches_reference_golden(name):
         assert float((out["transformer_features"] - f_ref).abs().max()) < 2e-5 * max(1.0, float(f_ref.abs().max()))
     cu_b, cu_p = O.prepare_cu_seqlens(inp)
     fw = O.dit_forward(sd, cfg, inp["x_1"], torch.from_numpy(g["fwd_timesteps"]), inp["pointclouds"], inp["features"],
-                       inp["scales"], inp["anchor_indices"], cu_b, cu_p, return_transformer_features=True)
+                       inp["scales"], inp["anchor_indices"], cu_b, cu_p, return_transformer_features=True, latent=inp.get("latent_features"))
     assert float((fw["velocity"] - torch.from_numpy(g["fwd_velocity"])).abs().max()) < 2e-6
     assert float((fw["transformer_features"] - torch.from_numpy(g["fwd_features"])).abs().max()) < 2e-5
 
 
 @pytest.mark.skipif(not ref_loader.reference_available(), reason="/root/reference is only mounted in the build container")
-@pytest.mark.parametrize("switch", [{}] + list(SWITCH_CASES.values()), ids=["shipped-config"] + list(SWITCH_CASES))
+@pytest.mark.parametrize("switch", [{}] + list(SWITCH_CASES.values()) + list(LATENT_CASES.values()),
+                         ids=["shipped-config"] + list(SWITCH_CASES) + list(LATENT_CASES))
 def test_oracle_matches_live_reference_modules(switch):
     cfg = dict(S.RAP_12); cfg["num_layers"] = 2
     cfg.update(switch)
     sd = S.make_weights(cfg, 3)
     inp = S.make_inputs([[40, 77], [130, 20, 65]], seed=99)
+    if cfg.get("in_dim", 0):
+        inp["latent_features"] = torch.randn(inp["x_1"].shape[0], cfg["in_dim"], generator=torch.Generator().manual_seed(5))
     for rigid in ((False, True) if not switch else (True,)):
         ref = ref_loader.reference_sample(cfg, sd, inp, 3, rigid)
         mine = O.sample(sd, cfg, inp, 3, rigid)
@@ -206,6 +210,24 @@ def test_oracle_relative_transforms_match_reference_written_files():
 def _overlap_golden():
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "overlap_ratio.npz"))
     return {k: z[k] for k in z.files}
+
+
+def test_oracle_transform_errors_match_reference_golden():
+    """compute_transform_errors, no-ICP branch (eval/metrics.py:165-303): the restatement vs the reference's own function (fixture from
+    oracle/make_golden.py --transform-errors-only): plain, scaled, and with matched_part_ids; NaN where a sample has no movable part."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transform_errors.npz"))
+    T = lambda k: torch.from_numpy(z[k])
+    for tag, mid, sc in (("plain", None, None), ("scaled", None, T("scale")), ("matched", T("matched_part_ids"), T("scale"))):
+        re, te, _, _ = O.compute_transform_errors(T("R_gt"), T("t_gt"), T("R_pred"), T("t_pred"), T("points_per_part"), T("anchor_part"), mid, sc)
+        ref_r, ref_t = T(f"{tag}_rot"), T(f"{tag}_trans")
+        assert torch.equal(torch.isnan(re), torch.isnan(ref_r)) and bool(torch.isnan(ref_r).any())
+        ok = ~torch.isnan(ref_r)
+        assert float((re[ok] - ref_r[ok]).abs().max()) < 2e-3 and float((te[ok] - ref_t[ok]).abs().max()) < 1e-5, tag
+    # fp64 evaluation of the same formula: what the fp32 values are a rounding of (acos near 1 is ill-conditioned: 0.3 degrees in the fixture)
+    re64, te64, _, _ = O.compute_transform_errors(T("R_gt").double(), T("t_gt").double(), T("R_pred").double(), T("t_pred").double(),
+                                                  T("points_per_part"), T("anchor_part"))
+    ok = ~torch.isnan(re64)
+    assert float((re64[ok].float() - T("plain_rot")[ok]).abs().max()) < 2e-2
 
 
 def test_oracle_overlap_ratio_matches_reference_golden():

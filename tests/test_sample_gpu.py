@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import rap_amd
-from conftest import GOLDEN_CASES, MODEL_SIZE_CASES, SWITCH_CASES, load_golden
+from conftest import GOLDEN_CASES, LATENT_CASES, MODEL_SIZE_CASES, SWITCH_CASES, load_golden
 from oracle import rap_oracle as O
 from rap_amd import synthetic as S
 
@@ -177,6 +177,52 @@ def test_constructor_switches_match_reference_golden(name, mode, dev):
     if name == "l2_noqknorm_rigid":
         from rap_amd import _lib
         assert _lib.load().rap_model_bounded_attention_launches(model._handle) == 0      # no norm, no logit bound: online softmax everywhere
+
+
+@pytest.mark.parametrize("mode", FP32_MODES + ["bfloat16"])
+@pytest.mark.parametrize("name", list(LATENT_CASES))
+def test_latent_features_match_reference_golden(name, mode, dev):
+    """in_dim = 64 (round 6; embedding.py:107-118,163-166, point_cloud_dit.py:56,86, modeling.py:636): `latent_features` (TP, 64) concatenated
+    into the embedding input -- natively 64 more columns of the hoisted, step-invariant embedding GEMM.  One forward and the whole sampling
+    call through sample_rectified_flow(data_dict, latent_features, ...) against the fixture of the unmodified reference built with in_dim = 64."""
+    g, inp = load_golden(name)
+    kw = LATENT_CASES[name]
+    cfg = dict(S.RAP_12); cfg["num_layers"] = int(g["num_layers"]); cfg.update(kw)
+    sd = S.make_weights(cfg, int(g["weight_seed"]))
+    assert abs(sum(v.double().sum().item() for v in sd.values()) - float(g["weights_checksum"])) < 1e-6
+    assert sd["encoding_manager.emb_proj.weight"].shape == (512, 147 + 32 + kw["in_dim"])
+    model = rap_amd.PointCloudDiT(in_dim=kw["in_dim"], out_dim=3, embed_dim=512, num_layers=cfg["num_layers"], num_heads=8, local_feat_dim=32,
+                                  attn_dtype="float32", compute_dtype=mode)
+    model.load_state_dict(sd); model.to(dev)
+    cu_b, cu_p = O.prepare_cu_seqlens(inp)
+    d = to_dev(inp, dev)
+    lat = d["latent_features"]
+    args = dict(x=d["x_1"], timesteps=torch.from_numpy(g["fwd_timesteps"]).to(dev), cond_coord=d["pointclouds"], local_features=d["features"],
+                scales=d["scales"], anchor_indices=d["anchor_indices"], cu_seqlens_batch=cu_b.to(dev), cu_seqlens_part=cu_p.to(dev))
+    out = model(latent_features=lat, return_transformer_features=True, **args)
+    v_ref = torch.from_numpy(g["fwd_velocity"])
+    ev = (out["velocity"].cpu() - v_ref).abs().max().item()
+    flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=int(g["num_steps"]), rigidity_forcing=bool(g["rigidity"]))
+    res = flow.sample_rectified_flow(d, lat, x_1=d["x_1"])
+    e0 = (res["end_point_trajectory"].cpu() - torch.from_numpy(g["end_point_trajectory"])).abs().max().item()
+    e1 = (res["trajectory"].cpu() - torch.from_numpy(g["trajectory"])).abs().max().item()
+    print(f"{name} [{mode}]: velocity {ev:.2e}  x0 {e0:.2e}  xt {e1:.2e}")
+    # the latent input is not optional for this model, and not accepted by one without it
+    with pytest.raises(ValueError):
+        model(latent_features=None, **args)
+    with pytest.raises(ValueError):
+        flow.sample_rectified_flow(d, None, x_1=d["x_1"])
+    if mode == "bfloat16":
+        assert ev <= 3e-2 * max(1.0, v_ref.abs().max().item()) and e0 <= 5e-2 and e1 <= 5e-2, (ev, e0, e1)
+        return
+    assert ev <= 1e-4 * v_ref.abs().max().item() and ev < 2e-5, ev
+    assert e0 < 5e-5 and e1 < 5e-5, (e0, e1)
+    R, t = flow.last_poses
+    assert torch.linalg.matrix_norm(R.cpu() - torch.from_numpy(g["R"])).max().item() < 1e-4
+    assert (t.cpu() - torch.from_numpy(g["t"])).abs().max().item() < 1e-4
+    # the latent columns matter: other features, another velocity field
+    out2 = model(latent_features=torch.zeros_like(lat), **args)
+    assert (out2.cpu() - v_ref).abs().max().item() > 1e-3
 
 
 def test_sample_matches_oracle_on_fresh_ragged_batch(dev):
@@ -409,6 +455,34 @@ def test_transform_files_match_reference_written_files(dev, tmp_path):
 # ---------------------------------------------------------------------------------------------
 # cross-part overlap ratio
 # ---------------------------------------------------------------------------------------------
+def test_transform_errors_match_reference_golden(dev):
+    """rap_transform_errors (round 6; compute_transform_errors without ICP, eval/metrics.py:165-303 -- the RRE / RTE of the registration
+    task) through rap_amd.metrics against the fixture of the reference's OWN function: plain, with scale, with matched_part_ids; a sample
+    whose anchor is not part 0, one with two anchors, one without any, one with only the anchor (NaN as the reference's 0 / 0)."""
+    import os
+    import numpy as np
+    from rap_amd.metrics import compute_transform_errors
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transform_errors.npz"))
+    T = lambda k: torch.from_numpy(z[k]).to(dev)
+    pts = torch.zeros(int(z["cu_seqlens"][-1]), 3, device=dev)
+    for tag, mid, sc in (("plain", None, None), ("scaled", None, T("scale")), ("matched", T("matched_part_ids"), T("scale"))):
+        re, te, re_pp, te_pp = compute_transform_errors(pts, pts, T("R_gt"), T("t_gt"), T("R_pred"), T("t_pred"), T("points_per_part"), T("anchor_part"),
+                                                        matched_part_ids=mid, scale=sc, cu_seqlens_batch=T("cu_seqlens"), return_per_part=True)
+        ref_r, ref_t = torch.from_numpy(z[f"{tag}_rot"]), torch.from_numpy(z[f"{tag}_trans"])
+        re, te = re.cpu(), te.cpu()
+        assert torch.equal(torch.isnan(re), torch.isnan(ref_r)) and torch.equal(torch.isnan(te), torch.isnan(ref_t))
+        ok = ~torch.isnan(ref_r)
+        er, et = float((re[ok] - ref_r[ok]).abs().max()), float((te[ok] - ref_t[ok]).abs().max())
+        print(f"transform errors [{tag}]: rot {er:.2e} deg, trans {et:.2e}")
+        # fp32 acos: d(theta) = d(cos) / sin(theta); the smallest error in the fixture is 0.3 degrees -> 2e-7 / 5e-3 rad = 2e-3 degrees per part
+        assert er < 5e-3 and et < 1e-5, (tag, er, et)
+        # anchor and empty parts carry 0 in the per-part tables, exactly as the reference's zero-initialised (B,P) tensors
+        skip = (T("points_per_part") == 0) | T("anchor_part")
+        assert float(re_pp[skip].abs().max()) == 0.0 and float(te_pp[skip].abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        compute_transform_errors(pts, pts, T("R_gt"), T("t_gt"), T("R_pred"), T("t_pred"), T("points_per_part"), T("anchor_part"), use_icp=True)
+
+
 def test_overlap_ratio_matches_reference_golden_and_oracle(dev):
     import numpy as np
     import os
