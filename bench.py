@@ -79,7 +79,7 @@ SHIPPED_ATTENTION_SYMBOL = {
     ("bfloat16", False): "attention_h16_kernel<1, 3, true>",
     ("float16", True): "attention_h16_kernel<2, 3, true>",
     ("float16", False): "attention_h16_kernel<2, 3, true>",
-    ("float32x2", True): "attention_x2_kernel<2>", ("float32x2", False): "attention_x2_kernel<2>",
+    ("float32x2", True): "attention_x2_kernel<2, false>", ("float32x2", False): "attention_x2_kernel<2, false>",
 }
 
 
@@ -761,7 +761,8 @@ def main():
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": source,
             # rocprofv3 --pmc cannot run inside this process: the figure is a committed constant of the builder's separate PMC passes
-            # for exactly this kernel symbol at the uniform configs[1] shape (profiles/pmc_traffic.json), not a measurement of this run
+            # (scripts/evidence.sh, refreshed on the round-6 tree) for exactly this kernel symbol at the uniform configs[1] shape
+            # (profiles/pmc_traffic.json), not a measurement of this run
             "traffic_measured_in_this_run": False,
             "algorithmic_bytes_per_launch": 4 * elem * tokens * 512,
             "launches": n_launch, "avg_launch_ms": 1e3 * secs / n_launch, "flops_per_launch_avg": flops / n_launch,

@@ -478,7 +478,17 @@ int rap_profile_collect_ex(float* h_ms_out, int64_t* h_count_out, int32_t n_clas
  *   key 15 attention work lists of rap_sample / forward    {1 (default): longest segment first, 0: segment order}   both precisions
  *   key 16 split-precision attention: blocks per CU          {2 (default): one 8-wave block, 4: two}                 compute dtype 3
  *   key 17 split precision from this many token rows per call {1024 (default); 0 = always}: SMALLER calls of a model in compute dtype 3
- *          run the exact-fp32 kernels (both are fp32-accurate; below a few thousand tokens the fp32 path's few-token forms are faster)
+ *          run the exact-fp32 kernels (both are fp32-accurate; below a few thousand tokens the fp32 path's few-token forms are faster).
+ *          rap_workspace_bytes of such a model covers both layouts, so the key may change between the size query and the call
+ *   key 18 four-stage LDS-DMA ring of the 128 x 128 16-bit / split-precision GEMM (few-token calls) for launches of at most this many
+ *          blocks {256 (default); 0 = never: two stages, two blocks per CU}.  Bit-identical results.
+ *   key 19 few-token 16-bit / split-precision calls: the combine pass of every residual GEMM folded into the LayerNorm that follows it
+ *          {1 (default), 0 = the round-5 launch sequence}.  Bit-identical in the 16-bit modes; in split precision the fused sequence
+ *          also splits K of the out-projection (fp32-class agreement)
+ * Operand range of compute dtype 3 (and of the fp16 residual stream): every paired activation -- LayerNorm output, q / k (also without
+ * qk-norm), v, attention output, GEGLU output -- is clipped to +-65 504 before it is split into head and tail (NaN stays NaN), and
+ * rap_model_set_compute_dtype(3) refuses weights that are not finite.  scripts/check_checkpoint.py compares the mode with exact fp32 on
+ * the weights it is given and exits non-zero on a miss.
  * Any other key returns RAP_ERR_INVALID.  (Keys 0-4 selected among the kernel variants of the round-1/2 experiments; those variants
  * are no longer in the tree, and what is left of the switch exists only in a library built with -DRAP_ABLATION_BUILD.) */
 int rap_set_tuning(int32_t key, int32_t value);

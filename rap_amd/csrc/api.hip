@@ -97,6 +97,10 @@ struct LayerWH {
   const u16* Wff2;
   // split precision (RAP_DT_F32X2): the planes hold w * 2^e per tensor; s_* = 2^-e, the factor the epilogue applies to the accumulators
   float s_qkv[2] = {1.f, 1.f}, s_out[2] = {1.f, 1.f}, s_ff1 = 1.f, s_ff2 = 1.f;
+  // ... and the powers of two the ACTIVATIONS those weights produce are stored with (round 6, GemmParamsH::out_scale): g_v for the V^T image
+  // (2^(e_qkv - 16): 1 for a tensor whose largest weight lies in (2^-5, 2^-4], the nn.Linear default range at d = 512), g_ff1 for the GEGLU
+  // output (value x gate: 2^(2 (e_ff1 - 16))).  The consuming GEMM (out-projection, ff2) divides its accumulator scale by it (exact).
+  float g_v[2] = {1.f, 1.f}, g_ff1 = 1.f;
 };
 struct HalfWeights {
   u16* blob = nullptr;
@@ -372,6 +376,7 @@ static int build_x2_weights(rap_model* m, hipStream_t stream) {
   u16* q = hw.blob;
   std::vector<const u16*> planes(nt);
   std::vector<float> inv(nt);
+  std::vector<int> expo(nt);
   for (int k = 0; k < nt && rc == RAP_OK; ++k) {
     // largest magnitude * 2^e in (2^11, 2^12]; an all-zero tensor keeps e = 0
     // a NaN / Inf weight would silently become +-65 504 in the planes (saturating split): refuse the model instead
@@ -379,6 +384,7 @@ static int build_x2_weights(rap_model* m, hipStream_t stream) {
     int e = 0;
     if (hmax[k] > 0.f) { int ex; (void)frexpf(hmax[k], &ex); e = 12 - ex; }
     e = e > 60 ? 60 : e < -60 ? -60 : e;
+    expo[k] = hmax[k] > 0.f ? e : 16;
     inv[k] = ldexpf(1.0f, -e);
     planes[k] = q;
     rc = launch_x2_pack(stream, items[k].src, (long)items[k].cols, (long)items[k].rows, (int)items[k].cols, ldexpf(1.0f, e), q);
@@ -391,9 +397,11 @@ static int build_x2_weights(rap_model* m, hipStream_t stream) {
     const int k0 = (int)(6 * i);
     for (int a = 0; a < 2; ++a) {
       lh.Wqkv[a] = planes[k0 + 2 * a]; lh.s_qkv[a] = inv[k0 + 2 * a];
+      { int g = expo[k0 + 2 * a] - 16; g = g > 12 ? 12 : g < -12 ? -12 : g; lh.g_v[a] = ldexpf(1.0f, g); }
       lh.Wout[a] = planes[k0 + 2 * a + 1]; lh.s_out[a] = inv[k0 + 2 * a + 1];
     }
     lh.Wff1p = planes[k0 + 4]; lh.s_ff1 = inv[k0 + 4];
+    { int g = 2 * (expo[k0 + 4] - 16); g = g > 24 ? 24 : g < -24 ? -24 : g; lh.g_ff1 = ldexpf(1.0f, g); }
     lh.Wff2 = planes[k0 + 5]; lh.s_ff2 = inv[k0 + 5];
   }
   (void)hipFree(d_max);
@@ -474,6 +482,7 @@ struct Workspace {
   float *hid1, *hid2, *astatic;        // head hidden layers (T,d), (T,d/2) and the static feature matrix (T,128): aliases
   u16 *xnh, *qkh, *vth, *atth, *ffmidh; // reduced-precision mode: 16-bit activations (xn/qkv/att/ffmid are then unused)
   float* splitk_h;                      // reduced-precision mode, few-token calls only: fp32 partial planes of the split-K ff2 GEMM (else null)
+  int splitk_planes;                    // ... and how many (T, d) planes were reserved there (2 or 4; 0 without the buffer)
   int vt_nblk;
   int rows;                             // TQ = align_up(TP, 256): rows of every token-row buffer
   int dtype;                            // the arithmetic this call runs in (eff_dtype: the model's, or fp32 for a small split-precision call)
@@ -509,6 +518,7 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   w.xn = w.qkv = w.att = w.ffmid = nullptr;
   w.xnh = w.qkh = w.vth = w.atth = w.ffmidh = nullptr;
   w.splitk_h = nullptr;
+  w.splitk_planes = 0;
   w.vt_nblk = 0;
   if (dtype == RAP_DT_F32) {
     w.xn = (float*)take(T * d * 4);            // also head hidden 1 (TP,d)
@@ -530,7 +540,7 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
     // ff2: the one layer GEMM with K >= 1024.  Reserved by SHAPE alone (tuning key 6 only gates the launch), so that the size
     // rap_workspace_bytes reports cannot change between the query and the call
     const int splits = gemm_h16_splits_by_shape((int)T, (int)d, (int)((x2 ? 8 : 4) * d));   // (split precision: the physical K of ff2 is 8 d)
-    if (splits > 1) w.splitk_h = (float*)take((size_t)splits * T * d * 4);
+    if (splits > 1) { w.splitk_h = (float*)take((size_t)splits * T * d * 4); w.splitk_planes = splits; }
   }
   w.ax = (float*)take(T * 64 * 4);
   w.v = (float*)take(T * 3 * 4);
@@ -674,7 +684,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         if (rc) return rc;
         GemmParamsH g{};
         g.A = w.xnh; g.lda = 2 * d; g.W = lh.Wqkv[a]; g.ldw = 2 * d; g.C = w.qkh; g.M = TP; g.N = 3 * d; g.K = 2 * d; g.heads = H;
-        g.vt = w.vth; g.vt_nblk = w.vt_nblk; g.q_mul = 8.0f; g.acc_scale = lh.s_qkv[a];
+        g.vt = w.vth; g.vt_nblk = w.vt_nblk; g.q_mul = 8.0f; g.acc_scale = lh.s_qkv[a]; g.out_scale = lh.g_v[a];
         if (w.qk_norm) { g.gamma_q = lw.gq[a]; g.gamma_k = lw.gk[a]; }      // null gains: the epilogue splits q / k as projected
         { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_QKV_NORM, g); }
         if (rc) return rc;
@@ -691,7 +701,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         if (rc) return rc;
         GemmParamsH o{};
         o.A = w.atth; o.lda = 2 * d; o.W = lh.Wout[a]; o.ldw = 2 * d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = 2 * d;
-        o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d; o.acc_scale = lh.s_out[a];
+        o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d; o.acc_scale = lh.s_out[a] / lh.g_v[a];      // (the attention output carries V's activation scale)
         if (fused) { o.splitk_ws = w.splitk_h; o.defer_combine = 1; }
         { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, o); }
         if (rc) return rc;
@@ -707,12 +717,12 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       if (rc) return rc;
       GemmParamsH f1{};
       f1.A = w.xnh; f1.lda = 2 * d; f1.W = lh.Wff1p; f1.ldw = 2 * d; f1.C = w.ffmidh; f1.ldc = 8 * d; f1.M = TP; f1.N = 8 * d; f1.K = 2 * d;
-      f1.bias = lw.bff1p; f1.acc_scale = lh.s_ff1;
+      f1.bias = lw.bff1p; f1.acc_scale = lh.s_ff1; f1.out_scale = lh.g_ff1;
       { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_GEGLU, f1); }
       if (rc) return rc;
       GemmParamsH f2{};
       f2.A = w.ffmidh; f2.lda = 8 * d; f2.W = lh.Wff2; f2.ldw = 8 * d; f2.C = w.h; f2.ldc = d; f2.M = TP; f2.N = d; f2.K = 8 * d;
-      f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d; f2.acc_scale = lh.s_ff2;
+      f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d; f2.acc_scale = lh.s_ff2 / lh.g_ff1;
       f2.splitk_ws = w.splitk_h;               // few-token calls: the physical K = 8d split over 2 / 4 blocks per tile (null otherwise)
       const bool f2_fused = fused && i + 1 < m->L;      // ... and its combine pass is the first LayerNorm of the next layer
       if (f2_fused) f2.defer_combine = 1;
@@ -861,10 +871,15 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
   // final_mlp (point_cloud_dit.py:111-117): Lin+SiLU, Lin+SiLU, Lin(no bias)
   GemmParams h0{};
   h0.A = h_final; h0.lda = d; h0.W = m->hW0; h0.ldw = d; h0.C = w.hid1; h0.ldc = d; h0.M = head_rows; h0.N = d; h0.K = d; h0.bias = m->hb0;
+  // few-token calls: K of the two hidden layers over 2 / 4 blocks per tile (launch_gemm_f32 decides by the tile count); the partial planes
+  // live in the FFN buffer of the fp32 layout (4 T d floats, idle here) resp. the split-K planes of the 16-bit layouts
+  float* const head_ws = w.dtype == RAP_DT_F32 ? w.ffmid : w.splitk_h;
+  const int head_planes = w.dtype == RAP_DT_F32 ? 4 : w.splitk_planes;
+  h0.splitk_ws = head_ws; h0.splitk_planes = head_planes;
   if ((rc = launch_gemm_f32(stream, EPI_BIAS_SILU, h0))) return rc;
   GemmParams h2{};
   h2.A = w.hid1; h2.lda = d; h2.W = m->hW2; h2.ldw = d; h2.C = w.hid2; h2.ldc = d / 2; h2.M = head_rows; h2.N = d / 2; h2.K = d;
-  h2.bias = m->hb2;
+  h2.bias = m->hb2; h2.splitk_ws = head_ws; h2.splitk_planes = head_planes;
   if ((rc = launch_gemm_f32(stream, EPI_BIAS_SILU, h2))) return rc;
   return launch_head_out3(stream, w.hid2, d / 2, m->hW4, v_out, TP_valid, d / 2);
 }

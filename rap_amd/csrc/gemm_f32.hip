@@ -726,13 +726,15 @@ __global__ __launch_bounds__(512) void gemm_f32_dma256p_kernel(GemmParams p) {
 }
 
 // C[m][n] = resid[m][n] + bias[n] + sum_s part[s][m][n]   (the split-K path of EPI_BIAS_RESID; one thread per 4 columns)
+// SILU (round 6, the two hidden layers of final_mlp in few-token calls): no residual, C = silu(bias + sum of the partials)
+template <bool SILU>
 __global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(GemmParams p, int splits) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int n4 = p.N / 4;
   if (i >= (long)p.M * n4) return;
   const long m = i / n4;
   const int n = (int)(i % n4) * 4;
-  float4 acc = *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
+  float4 acc = SILU ? float4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n);
   if (p.bias) {
     const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
     acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
@@ -740,6 +742,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(GemmParams p, 
   for (int s = 0; s < splits; ++s) {
     const float4 v = *reinterpret_cast<const float4*>(p.splitk_ws + ((size_t)s * p.M + m) * p.N + n);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  if (SILU) {
+    acc.x = acc.x / (1.0f + expf(-acc.x)); acc.y = acc.y / (1.0f + expf(-acc.y));
+    acc.z = acc.z / (1.0f + expf(-acc.z)); acc.w = acc.w / (1.0f + expf(-acc.w));
   }
   *reinterpret_cast<float4*>(p.C + m * p.ldc + n) = acc;
 }
@@ -818,7 +824,17 @@ int launch_gemm_f32(hipStream_t stream, int epilogue, const GemmParams& p_in) {
     const int splits = 4;
     hipLaunchKernelGGL(gemm_f32_dma_kernel<EPI_SPLITK_PART>, dim3(((p.M + GBM - 1) / GBM) * (p.N / GBN), splits), dim3(256), 0, stream, p);
     RAP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_splitk_combine_kernel, dim3((unsigned)(((long)p.M * (p.N / 4) + 255) / 256)), dim3(256), 0, stream, p, splits);
+    hipLaunchKernelGGL(gemm_splitk_combine_kernel<false>, dim3((unsigned)(((long)p.M * (p.N / 4) + 255) / 256)), dim3(256), 0, stream, p, splits);
+    RAP_LAUNCH_CHECK();
+    return RAP_OK;
+  }
+  // the hidden layers of final_mlp (Linear + SiLU, fp32 in every mode) of a few-token call: 64 / 32 tiles of a 16-k-tile chain on 256 CUs
+  // (r06 call 2: 39 us per launch, a fifth of a demo-size pair's per-step overhead) -- K over `splitk_planes` (2 or 4) blocks per tile
+  if (epilogue == EPI_BIAS_SILU && p.splitk_ws && (p.splitk_planes == 2 || p.splitk_planes == 4) && g_rap_gemm_splitk && (p.ldc & 3) == 0 &&
+      p.K >= 512 && (p.K / GBK) % p.splitk_planes == 0 && tiles128 <= 64) {
+    hipLaunchKernelGGL(gemm_f32_dma_kernel<EPI_SPLITK_PART>, dim3(((p.M + GBM - 1) / GBM) * (p.N / GBN), p.splitk_planes), dim3(256), 0, stream, p);
+    RAP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_splitk_combine_kernel<true>, dim3((unsigned)(((long)p.M * (p.N / 4) + 255) / 256)), dim3(256), 0, stream, p, p.splitk_planes);
     RAP_LAUNCH_CHECK();
     return RAP_OK;
   }

@@ -321,9 +321,10 @@ __device__ __forceinline__ void gemm_x2_epilogue(const GemmParamsH& p, f32x16 (&
         g2[j] = __builtin_elementwise_fma(f32x2{acc[i][1][2 * j], acc[i][1][2 * j + 1]}, f32x2{sc, sc}, f32x2{bg, bg});
       }
       geglu_pairs<8>(h2, g2, o2);
+      const float osc = p.out_scale;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const f32x2 s2 = {f16_sat(o2[j].x), f16_sat(o2[j].y)};
+        const f32x2 s2 = {f16_sat(o2[j].x * osc), f16_sat(o2[j].y * osc)};
         const typename H16<RAP_DT_F16>::T2 h16 = __builtin_convertvector(s2, typename H16<RAP_DT_F16>::T2);
         const typename H16<RAP_DT_F16>::T2 l16 = __builtin_convertvector(s2 - __builtin_convertvector(h16, f32x2), typename H16<RAP_DT_F16>::T2);
         const unsigned ph = __builtin_bit_cast(unsigned, h16), pl = __builtin_bit_cast(unsigned, l16);
@@ -379,6 +380,7 @@ __device__ __forceinline__ void gemm_x2_epilogue(const GemmParamsH& p, f32x16 (&
     u16* sh = reinterpret_cast<u16*>(stg);       // [64 d][72]: one chunk (32 tokens) of one 64-token block: 32 heads | 32 tails
     const int dmodel = p.heads * 64;
     const int h = (nw - 2 * dmodel) >> 6;
+    const float sc = p.acc_scale * p.out_scale;  // (shadows the function-level scale: the V planes carry out_scale, see GemmParamsH)
 #pragma unroll
     for (int ip = 0; ip < TM / 2; ++ip) {
 #pragma unroll

@@ -31,6 +31,7 @@ struct GemmParams {
   // splitk_ws (>= 4 * M * N floats) is given and the tile grid covers at most half (K >= 1024) / a quarter (K >= 512) of the CUs, K is split over 4
   // blocks per tile writing partial tiles to splitk_ws, and a combine pass adds residual + bias + partials (deterministic order)
   float* splitk_ws;
+  int splitk_planes;   // EPI_BIAS_SILU (round 6, the head of few-token calls): fp32 planes of M x N floats available in splitk_ws (2 or 4; 0 = no split)
   // EPI_QKV_HEADMAJOR with gamma_q / gamma_k set: MultiHeadRMSNorm (norm.py:28-33) fused -- q and k leave the GEMM normalised
   // (x / max(|x|, 1e-12) * gamma * 8 per head row), v unchanged; NULL = plain projection
   const float* gamma_q; const float* gamma_k;
@@ -145,6 +146,10 @@ struct GemmParamsH {
   // RAP_DT_F32X2 (split precision): the weight planes are stored multiplied by a power of two (their tails stay normal fp16 numbers);
   // every epilogue multiplies the accumulators by acc_scale = its inverse (exact) first
   float acc_scale = 1.0f;
+  // RAP_DT_F32X2, round 6: the 16-bit OUTPUT planes of this GEMM (V^T image of EPI_H_QKV[_NORM], GEGLU output) are stored times this
+  // power of two -- chosen per tensor from the producing weights' own scale, so that a model whose weights are uniformly small (large)
+  // does not push the activation's fp16 tails into the subnormals (its heads past 65 504); the consumer GEMM's acc_scale carries the inverse
+  float out_scale = 1.0f;
 };
 // 1 = no split; 2 or 4 for GEMMs with K >= 1024 whose 128 x 128 tile grid covers at most a quarter / half of the CUs (tuning key 6)
 int gemm_h16_splits(int M, int N, int K);

@@ -80,14 +80,29 @@ __global__ __launch_bounds__(256) void procrustes_moments_kernel(const float* __
   double m[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) m[k] = 0.0;
-  for (long i = lo + threadIdx.x; i < hi; i += 256) {
-    const double s0 = src[i * 3 + 0], s1 = src[i * 3 + 1], s2 = src[i * 3 + 2];
-    const double t0 = tgt[i * 3 + 0], t1 = tgt[i * 3 + 1], t2 = tgt[i * 3 + 2];
-    m[0] += s0; m[1] += s1; m[2] += s2;
-    m[3] += t0; m[4] += t1; m[5] += t2;
-    m[6] += s0 * t0; m[7] += s0 * t1; m[8] += s0 * t2;
-    m[9] += s1 * t0; m[10] += s1 * t1; m[11] += s1 * t2;
-    m[12] += s2 * t0; m[13] += s2 * t1; m[14] += s2 * t2;
+  // up to 8 points per thread in flight at once (all 48 loads of a 2048-point batch are requested before the first is used: a loop of
+  // one point per iteration pays one memory round trip per point); points beyond the chunk are clamped to its last point and weighted 0
+  for (long base = lo; base < hi; base += 2048) {
+    float sv[8][3], tv[8][3];
+    double wgt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      long i = base + threadIdx.x + u * 256;
+      wgt[u] = i < hi ? 1.0 : 0.0;
+      i = i < hi ? i : hi - 1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { sv[u][c] = src[i * 3 + c]; tv[u][c] = tgt[i * 3 + c]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double s0 = sv[u][0] * wgt[u], s1 = sv[u][1] * wgt[u], s2 = sv[u][2] * wgt[u];
+      const double t0 = tv[u][0] * wgt[u], t1 = tv[u][1] * wgt[u], t2 = tv[u][2] * wgt[u];
+      m[0] += s0; m[1] += s1; m[2] += s2;
+      m[3] += t0; m[4] += t1; m[5] += t2;
+      m[6] += s0 * t0; m[7] += s0 * t1; m[8] += s0 * t2;
+      m[9] += s1 * t0; m[10] += s1 * t1; m[11] += s1 * t2;
+      m[12] += s2 * t0; m[13] += s2 * t1; m[14] += s2 * t2;
+    }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double tot = wave_sum16_scatter(m, lane);

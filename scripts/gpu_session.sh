@@ -21,8 +21,8 @@ for STAGE in "$@"; do
   case "$KIND" in
     tests)
       if [ -n "$REST" ]; then
-        timeout 1500 python -m pytest tests -m gpu -q -k "$REST" > "$OUT/pytest_${REST//[^a-zA-Z0-9_]/_}.log" 2>&1; echo "pytest -k '$REST' exit $?"
-        grep -E "^(FAILED|ERROR)|passed|failed" "$OUT/pytest_${REST//[^a-zA-Z0-9_]/_}.log" | tail -15
+        timeout 1500 python -m pytest tests -m gpu -q -rP -k "$REST" > "$OUT/pytest_${REST//[^a-zA-Z0-9_]/_}.log" 2>&1; echo "pytest -k '$REST' exit $?"
+        grep -E "^(FAILED|ERROR)|passed|failed|^envelope |^transform errors|\[float32x2\]|\[bfloat16\]: vel" "$OUT/pytest_${REST//[^a-zA-Z0-9_]/_}.log" | tail -40
       else
         timeout 1700 python -m pytest tests -m gpu -q --durations=15 > "$OUT/pytest_gpu.log" 2>&1; echo "pytest exit $?"
         grep -E "^(FAILED|ERROR)|passed|failed|s call" "$OUT/pytest_gpu.log" | tail -30

@@ -41,9 +41,16 @@ def _sample(dev, cdt, rdt, parts, layers=2, steps=3, seed=11):
 MODES = [("bfloat16", "float32"), ("bfloat16", "float16"), ("float16", "float32"), ("float16", "float16"), ("float32x2", "float32")]
 
 
-@pytest.mark.parametrize("cdt,rdt", MODES, ids=[f"{c}-{r}-stream" for c, r in MODES])
-@pytest.mark.parametrize("parts", [[[1024, 1024]], [[300, 211], [64, 500, 33]], [[2000, 1500, 500]]], ids=["c0-geometry", "ragged-2-samples", "4000-tokens"])
-def test_ring_and_fused_combine_layernorm_are_bit_identical_to_the_round5_launch_sequence(dev, cdt, rdt, parts):
+GEOMS = {"c0-geometry": [[1024, 1024]], "ragged-2-samples": [[300, 211], [64, 500, 33]], "4000-tokens": [[2000, 1500, 500]]}
+# every mode at the demo-pair size; the ragged and the 4 000-token geometries (other tile counts, split-K factors 4 / 2) in one 16-bit stream
+# variant each and in split precision -- the GPU suite has a time budget
+CASES = [(c, r, "c0-geometry") for c, r in MODES] + [("bfloat16", "float16", "ragged-2-samples"), ("float32x2", "float32", "ragged-2-samples"),
+                                                      ("float16", "float32", "4000-tokens"), ("float32x2", "float32", "4000-tokens")]
+
+
+@pytest.mark.parametrize("cdt,rdt,geom", CASES, ids=[f"{g}-{c}-{r}-stream" for c, r, g in CASES])
+def test_ring_and_fused_combine_layernorm_are_bit_identical_to_the_round5_launch_sequence(dev, cdt, rdt, geom):
+    parts = GEOMS[geom]
     lib = _lib.load()
     outs = {}
     try:
