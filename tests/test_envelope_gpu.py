@@ -7,8 +7,11 @@ own modules (fp32, CPU) on rap_amd.synthetic.envelope_weights:
   tiny_geglu   GEGLU outputs of median 1.6e-5, maximum 4.9e-4 -- around and below fp16's smallest normal number 6.1e-5: the fp16 TAIL of such a
                value is a subnormal or zero, so an un-scaled head + tail pair carries 11-14 bits, not 22,
   mixed_gains  two of the four attention launches with logit bounds > 40 (online softmax), two with bounds <= 18 (bounded softmax).
-The exact-fp32 mode is held to the usual fp32 asserts on all three; the split-precision mode is held to the SAME asserts (since round 6 the
-GEGLU epilogue stores its planes times a power of two chosen per launch from the weights' scale -- see gemm_x2_epilogue)."""
+The exact-fp32 mode is held to the usual fp32 asserts on all three; the split-precision mode is held to the SAME asserts.  Measured on the
+first round-6 tree (profiles/r06_c4_envelope_latent_transform_errors.txt), tiny_geglu put split precision at 6.6e-5 of max|v| against 1.4e-6
+for exact fp32 (clouds 1.5e-5 vs 4.8e-7): outside the fp32 class.  Since then the V^T image and the GEGLU output carry a power-of-two
+ACTIVATION scale derived from the producing weight tensor's own scale (GemmParamsH::out_scale; the consumer GEMM's accumulator scale
+carries the inverse, exact): 1.2e-6 / 4.5e-7 on the same fixture (profiles/r06_c5_envelope.txt).  The bound below is 10 x the fp32 floor."""
 import pytest
 import torch
 
@@ -58,4 +61,4 @@ def test_envelope_fixture_of_the_reference(kind, mode, dev):
     print(f"envelope {kind} [{mode}]: |GEGLU| max {float(g['geglu_abs_max']):.3g} median {float(g['geglu_abs_median']):.3g};  "
           f"velocity {ev:.2e} of max|v|, clouds {e0:.2e}, |dR|_F {eR:.2e}")
     assert torch.isfinite(v).all() and torch.isfinite(res["end_point_trajectory"]).all()
-    assert ev < 1e-4 and e0 < 5e-5 and eR < 1e-4, (kind, mode, ev, e0, eR)
+    assert ev < 1.5e-5 and e0 < 5e-6 and eR < 1e-5, (kind, mode, ev, e0, eR)
