@@ -492,7 +492,6 @@ struct Workspace {
   int32_t *cu_batch_s, *cu_part_s;      // sanitised copies of the caller's segment tables (clamped to [0, TP], non-decreasing)
   const int32_t* cu_part_live;          // the part table the attention work lists were built from (part_offsets in rap_sample, cu_part_s in rap_dit_forward)
   int nseg_part, nseg_batch;            // segments in the two tables
-  int32_t* attn_cnt;                    // arrival counters of the in-kernel split-KV merge (16-bit attention, few-token calls): zeroed once per call
   AttnWorkItem *items_batch, *items_part;
   int max_items_batch, max_items_part;
   size_t total;
@@ -558,7 +557,6 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   w.max_items_part = (int)(TP / RAP_ATTN_BQ) + nseg_part + 1;
   w.items_batch = (AttnWorkItem*)take((size_t)w.max_items_batch * sizeof(AttnWorkItem));
   w.items_part = (AttnWorkItem*)take((size_t)w.max_items_part * sizeof(AttnWorkItem));
-  w.attn_cnt = (int32_t*)take((size_t)(w.max_items_part > w.max_items_batch ? w.max_items_part : w.max_items_batch) * m->H * 4);
   w.attn_sort = (int32_t*)take(((size_t)(nseg_part > B ? nseg_part : B) + 1) * 4);   // scratch of the longest-first work-list order
   w.proc_partials = (double*)take((size_t)nseg_part * RAP_PROC_CHUNKS * 16 * 8);
   w.Rc = (float*)take((size_t)nseg_part * 9 * 4);
@@ -616,7 +614,6 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
   // part, PE(x_t), the attention output, the sample index of a token -- once per call; everything else in rows TP .. TQ-1 is then
   // computed from those by row-independent kernels (LayerNorm, GEMMs) and stays finite.
   const int TQ = w.rows, d = m->d;
-  if ((rc = zero_rows(stream, w.attn_cnt, 4, 0, (w.max_items_part > w.max_items_batch ? w.max_items_part : w.max_items_batch) * m->H))) return rc;
   if ((rc = zero_rows(stream, w.base, (size_t)d * 4, TP, TQ))) return rc;
   if ((rc = zero_rows(stream, w.ax, 64 * 4, TP, TQ))) return rc;
   if ((rc = zero_rows(stream, w.token_sample, 4, TP, TQ))) return rc;
@@ -768,12 +765,8 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         {
           ProfScope ps(stream, a);
           const float* bound = bnd ? m->logit_bound + (size_t)j * H : nullptr;
-          // few-token calls: the keys of every work item over 2 / 4 blocks, merged by the last block to arrive (no combine launch); partial
-          // O planes in the split-K buffer (idle between the residual GEMMs' combine passes), (m, l) pairs in the idle FFN buffer
-          const int max_items = a == 0 ? w.max_items_part : w.max_items_batch;
-          const int splits = attention_h16_splits(max_items, H, w.splitk_planes);      // (tuning key 5; 1 when the call has no split-K planes)
           rc = launch_attention_h16(stream, dt, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch,
-                                    max_items, bound, prescale ? 1 : 0, w.splitk_h, reinterpret_cast<float*>(w.ffmidh), w.attn_cnt, splits);
+                                    a == 0 ? w.max_items_part : w.max_items_batch, bound, prescale ? 1 : 0);
         }
         if (rc) return rc;
         GemmParamsH o{};

@@ -56,17 +56,10 @@ __device__ __forceinline__ float hmax3(float a, float b, float c) {
 // bank conflicts are removed as in the GEMMs: 16-byte slot' = slot ^ ((row >> 1) & 7), applied to the per-lane global source
 // address and to the ds_read_b128 address.  DMA = false keeps the register-staged stream with 144-byte padded rows (rap_set_tuning(13, 0)).
 // The output tile leaves through the wave's own 4.6 KB slab of the (by then idle) K / V^T buffers and is stored as whole 128-byte rows.
-// SPLIT (round 6, few-token calls: one pair of 2 x 1024 points is 64 blocks of 16-32 key tiles for 256 CUs): gridDim.y blocks share the key
-// tiles of a work item.  Every block writes its un-normalised O (fp32) and its (m, l) to the call's scratch, releases them (agent scope) and
-// bumps the item's counter; the block that finds the counter at gridDim.y - 1 -- whichever it is -- re-reads ALL partials in split order
-// (deterministic), merges them (weights exp2((m_y - m) c); all 1 for the bounded kernels), normalises and stores.  No combine launch: round 3
-// measured the split with a separate pass and dropped it (kernel 23.8 -> 19.2 us, pass + 5.3 us).  The counter is left at 0 for the next launch.
-struct AttnSplit { float* part_o; float* part_ml; int* counters; };
-template <int DT, int OPT, bool DMA, bool SPLIT = false>
+template <int DT, int OPT, bool DMA>
 __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt, int vt_nblk,
                                                                u16* __restrict__ out, int TP, int heads,
-                                                               const AttnWorkItem* __restrict__ items, const float* __restrict__ bound,
-                                                               AttnSplit sp) {
+                                                               const AttnWorkItem* __restrict__ items, const float* __restrict__ bound) {
   typedef typename H16<DT>::T8 T8;
   constexpr int LDR = DMA ? 64 : HLD;   // LDS row stride in 16-bit elements: 128 B swizzled (DMA) or 144 B padded
   // (a ring of THREE stages with tiles requested two ahead and a counted vmcnt(2) was measured too, r03 call 21: 1 132 vs 1 141 TF in the
@@ -114,13 +107,8 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   float mrun = (OPT & 16) ? 0.f : (OPT & 8) ? bound[head] * 8.0f : -1e30f, lsum = 0.f;
   const float c = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e)
 
-  const int b_first0 = seg0 >> 6;
-  const int ntile0 = ((seg1 - 1) >> 6) - b_first0 + 1;
-  // SPLIT: this block's share of the key tiles (an empty share leaves O = 0, l = 0: nothing to add in the merge)
-  const int per = SPLIT ? (ntile0 + (int)gridDim.y - 1) / (int)gridDim.y : ntile0;
-  const int t_begin = SPLIT ? (int)blockIdx.y * per : 0;
-  const int b_first = b_first0 + t_begin;
-  const int ntile = SPLIT ? (ntile0 - t_begin < per ? ntile0 - t_begin : per) : ntile0;      // may be <= 0
+  const int b_first = seg0 >> 6;
+  const int ntile = ((seg1 - 1) >> 6) - b_first + 1;
   // ---- register staging (DMA = false): 512 threads, one 16-byte chunk of K and one of V^T per thread per tile
   const int srow = tid >> 3, sch = (tid & 7) * 8;
   const int soff = srow * HLD + sch;
@@ -157,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   }
 
   if (DMA) {
-    if (!SPLIT || ntile > 0) { HATT_DMA(0, 0) }
+    HATT_DMA(0, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the Q fragments have landed too -- tell the compiler (a use of every fragment), or it waits for them with vmcnt(3..0) inside
     // the key loop, where those waits would drain the DMA pieces of the NEXT tile it does not know about
@@ -269,88 +257,6 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
     __syncthreads();
   }
 
-  if constexpr (SPLIT) {
-    const int q = qw0 + l31;
-    const bool mine = wave_active && q < len;
-    const size_t dmodel = (size_t)heads * 64;
-    if (mine) {
-      const size_t tok = (size_t)blockIdx.y * TP + (size_t)(seg0 + q);
-      float* po = sp.part_o + tok * dmodel + head * 64 + 4 * hi;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<float4*>(po + 8 * g) = float4{o0[4 * g + 0], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]};
-        *reinterpret_cast<float4*>(po + 32 + 8 * g) = float4{o1[4 * g + 0], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
-      }
-    }
-    const float lall = h_xhalf_sum(lsum);
-    if (mine && hi == 0) *reinterpret_cast<float2*>(sp.part_ml + (((size_t)blockIdx.y * TP + (size_t)(seg0 + q)) * heads + head) * 2) = float2{mrun, lall};
-    // Hand-off to whichever block merges (cdna_hip_programming.md section 6, guideline 16: nothing is assumed about placement -- the merging
-    // block may sit on another XCD, whose L2 is not coherent with this one): every wave's stores retired -> block barrier -> ONE lane:
-    // agent-scope release, drain, count; the last arrival acquires at agent scope (invalidates this CU's L1 for the plain loads below).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    __shared__ int s_last;
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int old = __hip_atomic_fetch_add(sp.counters + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == (int)gridDim.y - 1;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(sp.counters + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch finds 0 (and the call zeroes the table once)
-      }
-      s_last = last;
-    }
-    __syncthreads();
-    if (!s_last || !wave_active) return;
-    // ---- merge in split order: deterministic whichever block arrives last
-    float mall = -3e38f;
-    if (mine) {
-      for (int y = 0; y < (int)gridDim.y; ++y)
-        mall = fmaxf(mall, sp.part_ml[(((size_t)y * TP + (size_t)(seg0 + q)) * heads + head) * 2]);
-    }
-    const float cm = (OPT & 16) ? 1.0f : c;
-    lsum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    if (mine) {
-      for (int y = 0; y < (int)gridDim.y; ++y) {
-        const size_t tok = (size_t)y * TP + (size_t)(seg0 + q);
-        const float2 ml = *reinterpret_cast<const float2*>(sp.part_ml + (tok * heads + head) * 2);
-        const float wy = __builtin_amdgcn_exp2f((ml.x - mall) * cm);
-        lsum += ml.y * wy;
-        const float* po = sp.part_o + tok * dmodel + head * 64 + 4 * hi;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 a = *reinterpret_cast<const float4*>(po + 8 * g);
-          const float4 b = *reinterpret_cast<const float4*>(po + 32 + 8 * g);
-          o0[4 * g + 0] += a.x * wy; o0[4 * g + 1] += a.y * wy; o0[4 * g + 2] += a.z * wy; o0[4 * g + 3] += a.w * wy;
-          o1[4 * g + 0] += b.x * wy; o1[4 * g + 1] += b.y * wy; o1[4 * g + 2] += b.z * wy; o1[4 * g + 3] += b.w * wy;
-        }
-      }
-    } else {
-      lsum = 1.f;
-    }
-    // (lsum is already the row's full sum here, identical in both half-waves: no cross-half add below)
-    const float inv = 1.0f / lsum;
-    u16* slab = smem + wave * (32 * HLD);
-    u16* wp = slab + l31 * HLD + 4 * hi;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      *reinterpret_cast<uint2*>(wp + 8 * g) = h16_pack4<DT>(o0[4 * g + 0] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-      *reinterpret_cast<uint2*>(wp + 32 + 8 * g) = h16_pack4<DT>(o1[4 * g + 0] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (lane >> 3) + 8 * i, piece = lane & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(slab + row * HLD + piece * 8);
-      if (qw0 + row < len)
-        *reinterpret_cast<uint4*>(out + (size_t)(seg0 + qw0 + row) * (heads * 64) + head * 64 + piece * 8) = v;
-    }
-    return;
-  }
   if (!wave_active) return;
   // ---- normalise and store: lane owns query l31; register r of tile e is d = 32e + crow(r, hi): groups of 4 contiguous d.
   // every wave of the block is past the last tile's barrier: the K / V^T buffers are free.  Slab of this wave: [32 queries][72]
@@ -386,6 +292,13 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
 // 2 x 2048 (call 34) -- a wave then issues 4 / 2 times the LDS-DMA pieces per tile, and their issue cost is the wave's chain; (b) the fp32
 // kernel's split over key ranges with fp32 partial planes and a combine pass: 17.5 vs 17.7 ms and 54.6 vs 51.4 (call 35) -- the kernel
 // drops from 23.8 to 19.2 us per launch, the combine pass adds 5.3.  At that size every kernel of the layer sits at the 5-13 us launch floor.
+// Round 6 (GPU call 6, source at commit "16-bit attention: split-KV for few-token calls with the merge inside the kernel",
+// profiles/r06_c6_h16_split_kv_in_kernel_merge_*): (c) the same split with the merge INSIDE the kernel -- every block releases its fp32
+// partial (agent scope), the last arrival per work item re-reads all of them in split order and stores the result, no combine launch: correct
+// and bit-stable (134 tests), but 43.4 us per launch against 24.1 (21.0 vs 16.5 ms per bf16 call).  Two reasons, both in the CDNA4 guide:
+// a 4-way split leaves 4 x 64 KB of fp32 partials per work item for ONE block to read back serially (~1 us per 16 KB), and the arrival
+// flag as a second __shared__ object makes hipcc drain the LDS-DMA stream (vmcnt(0)) in front of every fragment read of the key loop.
+// The partials of a split cost 8 x the bytes of the 16-bit output they replace: at this size the attention launch stays unsplit.
 rap_tuning_t g_rap_attn_h16_variant = 0;
 rap_tuning_t g_rap_attn_h16_dma = 1;      // tuning key 13: K / V^T tiles by LDS-DMA (1, default) or staged through registers (0)
 
@@ -399,47 +312,20 @@ bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {
   return dtype == RAP_DT_BF16 && bounded;
 }
 
-// key ranges per work item of a few-token launch (1 = no split): work lists that leave most of the chip idle
-extern rap_tuning_t g_rap_attn_split;    // attn_f32.hip, tuning key 5
-int attention_h16_splits(int max_items, int heads, int planes) {
-  if (g_rap_attn_split == 0 || planes < 2) return 1;
-  const long blocks = (long)max_items * heads;
-  const int want = blocks <= 96 ? 4 : blocks <= 192 ? 2 : 1;
-  return want > planes ? (planes >= 2 ? 2 : 1) : want;
-}
-
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
-                         int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled, float* part_o,
-                         float* part_ml, int* counters, int splits) {
+                         int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0 || vt_nblk * 64 < TP) return RAP_ERR_INVALID;
   if (q_prescaled && !(bound && attention_h16_wants_prescaled_q(dtype, true))) return RAP_ERR_INVALID;
-  if (splits > 1) {
-    if (!part_o || !part_ml || !counters || !g_rap_attn_h16_dma) return RAP_ERR_INVALID;
-    const AttnSplit sp{part_o, part_ml, counters};
-    const dim3 grid(max_items * heads, splits);
-#define HATT_LAUNCH_SPLIT(DTV, OPTV) hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, true, true>), grid, dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, sp);
-    if (dtype == RAP_DT_BF16) {
-      if (bound && q_prescaled) HATT_LAUNCH_SPLIT(RAP_DT_BF16, 24)
-      else if (bound) HATT_LAUNCH_SPLIT(RAP_DT_BF16, 8)
-      else HATT_LAUNCH_SPLIT(RAP_DT_BF16, 3)
-    } else if (dtype == RAP_DT_F16) {
-      HATT_LAUNCH_SPLIT(RAP_DT_F16, 3)
-    } else {
-      return RAP_ERR_INVALID;
-    }
-    RAP_LAUNCH_CHECK();
-    return RAP_OK;
-  }
 #ifdef RAP_ABLATION_BUILD
   if (g_rap_attn_h16_variant == 5) bound = nullptr;
 #endif
 #define HATT_LAUNCH(DTV, OPTV)                                                                                                            \
   {                                                                                                                                       \
     if (g_rap_attn_h16_dma)                                                                                                               \
-      hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, AttnSplit{}); \
+      hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound); \
     else                                                                                                                                  \
-      hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, false>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, AttnSplit{}); \
+      hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, false>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound); \
   }
   if (dtype == RAP_DT_BF16) {
     if (bound && q_prescaled) HATT_LAUNCH(RAP_DT_BF16, 24)

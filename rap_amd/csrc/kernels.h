@@ -160,13 +160,8 @@ int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t
 // attention on q,k half [2][H][TP][64] + transposed-blocked v (vt); out half (TP, H*64)
 // bound: optional per-head upper bounds (device, H floats) on the logits q.k/8 -- enables the bounded-softmax kernel (bf16)
 // q_prescaled: q was written by launch_qknorm_h16(..., RAP_QMUL_PRESCALED) -- scores arrive in log2 units (needs bound, bf16)
-// splits > 1 (round 6, few-token calls): key ranges per work item; partial O in part_o [splits][TP][heads*64] fp32, (m, l) in part_ml
-// [splits][TP][heads][2], arrival counters[max_items * heads] (zero before the first launch; every launch leaves them zero): the LAST block of
-// a work item to arrive merges the partials inside the kernel -- no combine launch.  attention_h16_splits() picks the count (<= planes).
 int launch_attention_h16(hipStream_t stream, int dtype, const uint16_t* qk, const uint16_t* vt, int vt_nblk, uint16_t* out,
-                         int TP, int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled,
-                         float* part_o = nullptr, float* part_ml = nullptr, int* counters = nullptr, int splits = 1);
-int attention_h16_splits(int max_items, int heads, int planes);
+                         int TP, int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled);
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded);
 int attention_h16_block_queries(int dtype);      // work-list granularity of the selected 16-bit attention schedule (256; 512 for variant 24)
 // per-head logit bounds of one attention branch after qk-norm: out[h] = 8 * max_j|gamma_q[h][j]| * max_j|gamma_k[h][j]|
