@@ -28,7 +28,7 @@ extern "C" {
  * value must not use the library (round 4, version 4: rap_spinnet_describe gained `flags` and three entry points were removed in
  * round 3 without a bump; the fp16-residual epilogue of rap_gemm_h16 moved from 6 to 7 and 6 is refused; rap_poison_on_flag is new;
  * round 5, version 5: compute dtype 3 (split precision) and the rap_x2_* entry points are new, nothing was removed or re-numbered;
- * round 6, version 6: additive -- the *_latent entry points (in_dim > 0), rap_transform_errors, tuning keys 18 / 19; the scratch of the
+ * round 6, version 6: additive -- the *_latent entry points (in_dim > 0), rap_transform_errors, tuning keys 18 / 19 / 20; the scratch of the
  * kernel-level attention entry points grew by a sanitised copy of cu_seqlens (rap_attention_workspace_bytes reports it)). */
 #define RAPFLOW_ABI_VERSION 6
 
@@ -485,6 +485,8 @@ int rap_profile_collect_ex(float* h_ms_out, int64_t* h_count_out, int32_t n_clas
  *   key 19 few-token 16-bit / split-precision calls: the combine pass of every residual GEMM folded into the LayerNorm that follows it
  *          {1 (default), 0 = the round-5 launch sequence}.  Bit-identical in the 16-bit modes; in split precision the fused sequence
  *          also splits K of the out-projection (fp32-class agreement)
+ *   key 20 16-bit attention of few-token calls (<= 4 096 token rows): work items of 64 / 128 query rows and a four-stage K / V^T ring
+ *          {1 (default), 0 = 256-row items, two stages}.  Bit-identical results.  (rap_workspace_bytes does not depend on it.)
  * Operand range of compute dtype 3 (and of the fp16 residual stream): every paired activation -- LayerNorm output, q / k (also without
  * qk-norm), v, attention output, GEGLU output -- is clipped to +-65 504 before it is split into head and tail (NaN stays NaN), and
  * rap_model_set_compute_dtype(3) refuses weights that are not finite.  scripts/check_checkpoint.py compares the mode with exact fp32 on

@@ -158,6 +158,7 @@ extern rap_tuning_t g_rap_gemm_h16_persistent;   // gemm_h16.hip
 extern rap_tuning_t g_rap_attn_h16_dma;          // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_f32_persistent;   // gemm_f32.hip
 extern rap_tuning_t g_rap_attn_x2_wpe;           // attn_x2.hip
+extern rap_tuning_t g_rap_attn_h16_small;        // attn_h16.hip, tuning key 20
 rap_tuning_t g_rap_attn_lpt = 1;               // tuning key 15: attention work lists longest-segment-first (1, default) or in segment order (0)
 // tuning key 17: split precision takes over from this many token rows (align_up(TP, 256)) per call; SMALLER calls of a model in compute
 // dtype 3 run the exact-fp32 kernels -- both are fp32-accurate, and below a few thousand tokens every kernel of a layer sits at the launch
@@ -195,6 +196,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 17 && value >= 0) { g_rap_x2_min_rows = value; return RAP_OK; }   // split precision from this many token rows per call (smaller calls: exact fp32)
   if (key == 18 && value >= 0) { g_rap_ring_blocks = value; return RAP_OK; }      // four-stage ring of the 128 x 128 16-bit GEMM up to this many blocks per launch (0 = never)
   if (key == 19 && (value == 0 || value == 1)) { g_rap_small_fused = value; return RAP_OK; }      // combine + LayerNorm fusion of few-token calls
+  if (key == 20 && (value == 0 || value == 1)) { g_rap_attn_h16_small = value; return RAP_OK; }   // 16-bit attention of few-token calls: 64 / 128-row work items + four-stage ring
   if (key == 16 && (value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: 1 / 2 blocks per CU
   return RAP_ERR_INVALID;
 }
@@ -494,6 +496,7 @@ struct Workspace {
   int nseg_part, nseg_batch;            // segments in the two tables
   AttnWorkItem *items_batch, *items_part;
   int max_items_batch, max_items_part;
+  int attn_bq;                          // query rows per work item of this call's attention lists
   size_t total;
 };
 
@@ -553,10 +556,13 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   w.cu_batch_s = (int32_t*)take(((size_t)B + 1) * 4);
   w.cu_part_s = (int32_t*)take(((size_t)nseg_part + 1) * 4);
   w.cu_part_live = w.part_offsets; w.nseg_part = nseg_part; w.nseg_batch = B;
-  w.max_items_batch = (int)(TP / RAP_ATTN_BQ) + B + 1;
-  w.max_items_part = (int)(TP / RAP_ATTN_BQ) + nseg_part + 1;
-  w.items_batch = (AttnWorkItem*)take((size_t)w.max_items_batch * sizeof(AttnWorkItem));
-  w.items_part = (AttnWorkItem*)take((size_t)w.max_items_part * sizeof(AttnWorkItem));
+  // query rows per attention work item: 256, or 64 / 128 for few-token calls of the 16-bit modes (attention_h16_block_queries)
+  w.attn_bq = (dtype == RAP_DT_BF16 || dtype == RAP_DT_F16) ? attention_h16_block_queries(dtype, (long)T) : RAP_ATTN_BQ;
+  w.max_items_batch = (int)(TP / w.attn_bq) + B + 1;
+  w.max_items_part = (int)(TP / w.attn_bq) + nseg_part + 1;
+  // (reserved for the smallest work items whatever tuning key 20 says: the size rap_workspace_bytes reports does not depend on the key)
+  w.items_batch = (AttnWorkItem*)take(((size_t)(TP / 64) + B + 1) * sizeof(AttnWorkItem));
+  w.items_part = (AttnWorkItem*)take(((size_t)(TP / 64) + nseg_part + 1) * sizeof(AttnWorkItem));
   w.attn_sort = (int32_t*)take(((size_t)(nseg_part > B ? nseg_part : B) + 1) * 4);   // scratch of the longest-first work-list order
   w.proc_partials = (double*)take((size_t)nseg_part * RAP_PROC_CHUNKS * 16 * 8);
   w.Rc = (float*)take((size_t)nseg_part * 9 * 4);
@@ -604,7 +610,7 @@ static int prepare_static(const rap_model* m, const Workspace& w, hipStream_t st
     cu_part = w.cu_part_s;
   }
   if ((rc = launch_token_sample(stream, cu_batch, B, w.token_sample))) return rc;
-  const int bq = w.dtype == RAP_DT_F32 ? 0 : w.dtype == RAP_DT_F32X2 ? 256 : attention_h16_block_queries(w.dtype);
+  const int bq = w.dtype == RAP_DT_F32 ? 0 : w.dtype == RAP_DT_F32X2 ? 256 : w.attn_bq;
   int32_t* sort_ws = g_rap_attn_lpt ? w.attn_sort : nullptr;
   if ((rc = launch_build_attn_worklist(stream, cu_batch, B, w.items_batch, w.max_items_batch, bq, sort_ws))) return rc;
   if ((rc = launch_build_attn_worklist(stream, cu_part, nseg_part, w.items_part, w.max_items_part, bq, sort_ws))) return rc;
@@ -766,7 +772,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
           ProfScope ps(stream, a);
           const float* bound = bnd ? m->logit_bound + (size_t)j * H : nullptr;
           rc = launch_attention_h16(stream, dt, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch,
-                                    a == 0 ? w.max_items_part : w.max_items_batch, bound, prescale ? 1 : 0);
+                                    a == 0 ? w.max_items_part : w.max_items_batch, bound, prescale ? 1 : 0, w.attn_bq);
         }
         if (rc) return rc;
         GemmParamsH o{};

@@ -56,17 +56,25 @@ __device__ __forceinline__ float hmax3(float a, float b, float c) {
 // bank conflicts are removed as in the GEMMs: 16-byte slot' = slot ^ ((row >> 1) & 7), applied to the per-lane global source
 // address and to the ds_read_b128 address.  DMA = false keeps the register-staged stream with 144-byte padded rows (rap_set_tuning(13, 0)).
 // The output tile leaves through the wave's own 4.6 KB slab of the (by then idle) K / V^T buffers and is stored as whole 128-byte rows.
-template <int DT, int OPT, bool DMA>
+// NS / bq (round 6, few-token calls): a demo pair is 64 work items x heads of 16-32 key tiles on 256 CUs -- one block per CU, nothing to hide
+// the L2 round trip of the next tile behind (r06: ~1 us per tile whatever the block computes; the r03 sub-block experiment ran into the same
+// wall).  NS = 4: a ring of four K / V^T stages, tiles requested three ahead, counted vmcnt.  bq = query rows per work item (64 / 128
+// instead of 256: the waves whose rows lie beyond bq only stage -- every wave still issues two pieces per tile): 4 / 2 times the blocks,
+// each with a quarter / half of the MFMA work per tile.  Same per-query arithmetic in the same order: bit-identical results.
+template <int DT, int OPT, bool DMA, int NS = 2>
 __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __restrict__ qk, const u16* __restrict__ vt, int vt_nblk,
                                                                u16* __restrict__ out, int TP, int heads,
-                                                               const AttnWorkItem* __restrict__ items, const float* __restrict__ bound) {
+                                                               const AttnWorkItem* __restrict__ items, const float* __restrict__ bound, int bq) {
   typedef typename H16<DT>::T8 T8;
   constexpr int LDR = DMA ? 64 : HLD;   // LDS row stride in 16-bit elements: 128 B swizzled (DMA) or 144 B padded
-  // (a ring of THREE stages with tiles requested two ahead and a counted vmcnt(2) was measured too, r03 call 21: 1 132 vs 1 141 TF in the
-  // bench -- the DMA latency is not exposed with two.)
-  __shared__ __attribute__((aligned(16))) u16 smem[4 * HKV * HLD];   // 36 KB: two stages of K and V^T (32 KB with DMA) / the 8 output slabs
-  u16* Ks = smem;                    // [2][64 keys][LDR]
-  u16* Vs = smem + 2 * HKV * LDR;    // [2][64 d][LDR]   (columns = vt_pos of the key)
+  static_assert(NS == 2 || (DMA && NS == 4), "two stages, or the four-stage LDS-DMA ring");
+  // (at the full configuration -- two blocks per CU cover each other -- a ring of THREE stages was measured in r03 call 21: 1 132 vs
+  // 1 141 TF in the bench; there the DMA latency is not exposed with two.)
+  constexpr int SMEM_ELEMS = NS == 2 ? 4 * HKV * HLD : NS * 2 * HKV * 64;      // 36 KB (two stages / the 8 output slabs) or 64 KB (ring)
+  static_assert(8 * 32 * HLD <= SMEM_ELEMS, "output slabs must fit");
+  __shared__ __attribute__((aligned(16))) u16 smem[SMEM_ELEMS];
+  u16* Ks = smem;                    // [NS][64 keys][LDR]
+  u16* Vs = smem + NS * HKV * LDR;   // [NS][64 d][LDR]   (columns = vt_pos of the key)
 
   const int tid = threadIdx.x;
   const int head = blockIdx.x % heads;
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   const u16* Vg = vt + (size_t)head * vt_nblk * (64 * 64);
 
   const int qw0 = it.q0 + wave * 32;
-  const bool wave_active = qw0 < len;   // waves beyond the segment still help stage K/V
+  const bool wave_active = wave * 32 < bq && qw0 < len;   // waves beyond the work item's rows / the segment still help stage K/V
 
   // ---- Q fragments (B operand of S^T): qf[s] = Q[q][16s + 8hi .. +7]
   T8 qf[4];
@@ -145,7 +153,9 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   }
 
   if (DMA) {
-    HATT_DMA(0, 0)
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+      if (s_ < ntile) { HATT_DMA(s_, s_) }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the Q fragments have landed too -- tell the compiler (a use of every fragment), or it waits for them with vmcnt(3..0) inside
     // the key loop, where those waits would drain the DMA pieces of the NEXT tile it does not know about
@@ -158,9 +168,10 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
   __syncthreads();
 
   for (int t = 0; t < ntile; ++t) {
-    const int cur = t & 1;
+    const int cur = t & (NS - 1);
     const bool more = (t + 1) < ntile;
-    if (more) { if (DMA) { HATT_DMA(t + 1, cur ^ 1) } else { HATT_LOAD(t + 1) } }   // DMA: every wave left buffer cur^1 at the last barrier
+    const bool ahead = (t + NS - 1) < ntile;      // the tile this iteration requests: NS - 1 ahead, into the stage tile t - 1 left at the last barrier
+    if (DMA) { if (ahead) { HATT_DMA(t + NS - 1, (t + NS - 1) & (NS - 1)) } } else if (more) { HATT_LOAD(t + 1) }
 
     if (wave_active) {
       // ---- S^T = K Q^T : two 32-key sub-tiles x 32 queries
@@ -253,7 +264,10 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
     }
 
     if (more && !DMA) { HATT_STORE(cur ^ 1) }
-    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's two pieces of tile t + 1 have landed
+    if (DMA) {      // this wave's two pieces of tile t + 1 have landed: loads retire in order, the NS - 2 younger tiles may stay in flight
+      if (NS > 2 && ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
   }
 
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
 // 2 x 2048 (call 34) -- a wave then issues 4 / 2 times the LDS-DMA pieces per tile, and their issue cost is the wave's chain; (b) the fp32
 // kernel's split over key ranges with fp32 partial planes and a combine pass: 17.5 vs 17.7 ms and 54.6 vs 51.4 (call 35) -- the kernel
 // drops from 23.8 to 19.2 us per launch, the combine pass adds 5.3.  At that size every kernel of the layer sits at the 5-13 us launch floor.
-// Round 6 (GPU call 6, source at commit "16-bit attention: split-KV for few-token calls with the merge inside the kernel",
+// Round 6 (GPU call 6, source at commit da4c269,
 // profiles/r06_c6_h16_split_kv_in_kernel_merge_*): (c) the same split with the merge INSIDE the kernel -- every block releases its fp32
 // partial (agent scope), the last arrival per work item re-reads all of them in split order and stores the result, no combine launch: correct
 // and bit-stable (134 tests), but 43.4 us per launch against 24.1 (21.0 vs 16.5 ms per bf16 call).  Two reasons, both in the CDNA4 guide:
@@ -302,7 +316,13 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
 rap_tuning_t g_rap_attn_h16_variant = 0;
 rap_tuning_t g_rap_attn_h16_dma = 1;      // tuning key 13: K / V^T tiles by LDS-DMA (1, default) or staged through registers (0)
 
-int attention_h16_block_queries(int) { return 256; }
+// Query rows per work item: 256, or -- few-token calls (tuning key 20) -- 64 / 128 for calls of at most 2 048 / 4 096 token rows, where 256-row
+// items leave three quarters / half of the CUs without a block.  rows = align_up(TP, 256) of the call (0: the kernel-level entry points).
+rap_tuning_t g_rap_attn_h16_small = 1;    // tuning key 20: 1 (default) = small work items + four-stage ring for few-token calls, 0 = 256 rows, two stages
+int attention_h16_block_queries(int, long rows) {
+  if (!g_rap_attn_h16_small || !g_rap_attn_h16_dma || rows <= 0) return 256;
+  return rows <= 2048 ? 64 : rows <= 4096 ? 128 : 256;
+}
 
 // the model path asks before it runs qk-norm: pre-scaled q only feeds the bounded bf16 kernel
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {
@@ -313,19 +333,22 @@ bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {
 }
 
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
-                         int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled) {
+                         int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled, int bq) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
-  if (heads <= 0 || vt_nblk * 64 < TP) return RAP_ERR_INVALID;
+  if (heads <= 0 || vt_nblk * 64 < TP || (bq != 64 && bq != 128 && bq != 256)) return RAP_ERR_INVALID;
+  const bool ring = bq < 256 && g_rap_attn_h16_dma;      // few-token work lists: the four-stage ring
   if (q_prescaled && !(bound && attention_h16_wants_prescaled_q(dtype, true))) return RAP_ERR_INVALID;
 #ifdef RAP_ABLATION_BUILD
   if (g_rap_attn_h16_variant == 5) bound = nullptr;
 #endif
 #define HATT_LAUNCH(DTV, OPTV)                                                                                                            \
   {                                                                                                                                       \
-    if (g_rap_attn_h16_dma)                                                                                                               \
-      hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound); \
+    if (ring)                                                                                                                             \
+      hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, true, 4>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, bq); \
+    else if (g_rap_attn_h16_dma)                                                                                                          \
+      hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, true>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, bq); \
     else                                                                                                                                  \
-      hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, false>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound); \
+      hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, false>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, bq); \
   }
   if (dtype == RAP_DT_BF16) {
     if (bound && q_prescaled) HATT_LAUNCH(RAP_DT_BF16, 24)

@@ -160,10 +160,12 @@ int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t
 // attention on q,k half [2][H][TP][64] + transposed-blocked v (vt); out half (TP, H*64)
 // bound: optional per-head upper bounds (device, H floats) on the logits q.k/8 -- enables the bounded-softmax kernel (bf16)
 // q_prescaled: q was written by launch_qknorm_h16(..., RAP_QMUL_PRESCALED) -- scores arrive in log2 units (needs bound, bf16)
+// bq: the query rows per work item the list was built with (attention_h16_block_queries: 256; 64 / 128 for few-token calls, which also take
+// the four-stage K / V^T ring)
 int launch_attention_h16(hipStream_t stream, int dtype, const uint16_t* qk, const uint16_t* vt, int vt_nblk, uint16_t* out,
-                         int TP, int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled);
+                         int TP, int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled, int bq = 256);
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded);
-int attention_h16_block_queries(int dtype);      // work-list granularity of the selected 16-bit attention schedule (256; 512 for variant 24)
+int attention_h16_block_queries(int dtype, long rows = 0);      // work-list granularity of the 16-bit attention for a call of `rows` token rows
 // per-head logit bounds of one attention branch after qk-norm: out[h] = 8 * max_j|gamma_q[h][j]| * max_j|gamma_k[h][j]|
 int launch_qk_logit_bound(hipStream_t stream, const float* gamma_q, const float* gamma_k, int heads, float* out);
 // LayerNorm with 16-bit output (fp32 statistics), same modulation forms as launch_layernorm_*

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Few-token latency A/B (round 6): one sampling call at a time, un-instrumented, for the call sizes the reference's users live at
 (config/RAP_inference.yaml:30-36: batch_size 1).  Geometries: configs[0] (1 pair x 2 x 1024, 10 steps) and one sample of 8 views x N points,
-20 steps.  Variants = tuning keys 18 (four-stage GEMM ring up to this many blocks), 19 (combine + LayerNorm fusion), 7 (fused qk-norm).
+20 steps.  Variants = tuning keys 18 (four-stage GEMM ring up to this many blocks), 19 (combine + LayerNorm fusion), 7 (fused qk-norm), 20 (16-bit
+attention: small work items + four-stage ring).
 JSON lines on stdout.  usage: small_call_latency.py [--modes=bfloat16,float32x2,float32] [--variants=r6,r5,...] [--sizes=1000,2000]"""
 import json
 import os
@@ -23,9 +24,9 @@ def arg(name, default):
     return default
 
 
-VARIANTS = {"r6": {18: 256, 19: 1, 7: 1}, "r5": {18: 0, 19: 0, 7: 0}, "ring-only": {18: 256, 19: 0, 7: 1}, "fused-only": {18: 0, 19: 1, 7: 1},
-            "ring512": {18: 512, 19: 1, 7: 1}, "ring1024": {18: 1024, 19: 1, 7: 1}, "ring4096": {18: 4096, 19: 1, 7: 1},
-            "unfused-qknorm": {18: 256, 19: 1, 7: 0}}
+VARIANTS = {"r6": {18: 256, 19: 1, 7: 1, 20: 1}, "r5": {18: 0, 19: 0, 7: 0, 20: 0}, "ring-only": {18: 256, 19: 0, 7: 1, 20: 0}, "fused-only": {18: 0, 19: 1, 7: 1, 20: 0},
+            "no-attn-small": {18: 256, 19: 1, 7: 1, 20: 0}, "ring512": {18: 512, 19: 1, 7: 1, 20: 1}, "ring1024": {18: 1024, 19: 1, 7: 1, 20: 1}, "ring4096": {18: 4096, 19: 1, 7: 1, 20: 1},
+            "unfused-qknorm": {18: 256, 19: 1, 7: 0, 20: 1}}
 dev = torch.device("cuda:0")
 lib = _lib.load()
 cfg = dict(S.RAP_12)

@@ -5,6 +5,8 @@ C ABI and the model path:
     BIT-identical to the two-stage kernel;
   * the combine pass of every residual GEMM folded into the following LayerNorm (tuning key 19) forms the residual-stream value in the
     order of the stand-alone combine pass and normalises the STORED value: BIT-identical to the unfused launch sequence;
+  * the 16-bit attention of few-token calls on 64 / 128-row work items with a four-stage K / V^T ring (tuning key 20): the same per-query
+    arithmetic in the same order, BIT-identical to 256-row items on two stages;
   * qk-norm inside the QKV epilogue on 128 x 128 tiles (the 16-bit modes; split precision had it) against the fp32 golden vectors of the
     reference, and kernel-level against fp64 on the rounded operands.
 """
@@ -55,15 +57,16 @@ def test_ring_and_fused_combine_layernorm_are_bit_identical_to_the_round5_launch
     outs = {}
     try:
         assert lib.rap_set_tuning(17, 0) == 0                      # split precision at every size (small calls default to exact fp32)
-        for tag, ring, fused in (("r6", 256, 1), ("ring-only", 256, 0), ("fused-only", 0, 1), ("r5", 0, 0)):
-            assert lib.rap_set_tuning(18, ring) == 0 and lib.rap_set_tuning(19, fused) == 0
+        # tuning keys 18 (GEMM ring), 19 (combine + LayerNorm), 20 (16-bit attention: 64 / 128-row work items + four-stage K / V^T ring)
+        for tag, ring, fused, attn in (("r6", 256, 1, 1), ("ring-only", 256, 0, 0), ("fused-only", 0, 1, 0), ("attn-only", 0, 0, 1), ("r5", 0, 0, 0)):
+            assert lib.rap_set_tuning(18, ring) == 0 and lib.rap_set_tuning(19, fused) == 0 and lib.rap_set_tuning(20, attn) == 0
             outs[tag], ctx = _sample(dev, cdt, rdt, parts)
     finally:
-        assert lib.rap_set_tuning(18, 256) == 0 and lib.rap_set_tuning(19, 1) == 0 and lib.rap_set_tuning(17, 1024) == 0
-    for tag in ("r6", "ring-only", "fused-only"):
+        assert lib.rap_set_tuning(18, 256) == 0 and lib.rap_set_tuning(19, 1) == 0 and lib.rap_set_tuning(20, 1) == 0 and lib.rap_set_tuning(17, 1024) == 0
+    for tag in ("r6", "ring-only", "fused-only", "attn-only"):
         for k, v in outs["r5"].items():
             assert not torch.isnan(v).any()
-            if cdt == "float32x2" and tag != "ring-only":
+            if cdt == "float32x2" and tag not in ("ring-only", "attn-only"):
                 # split precision: the fused sequence ALSO splits K of the out-projection (physical K = 1024; round 5 split ff2 only), so the
                 # k-sum is re-associated there: fp32-class agreement instead of bit identity
                 assert float((outs[tag][k] - v).abs().max()) < 5e-6, (tag, k)
