@@ -141,14 +141,14 @@ def parse_args():
                     help="where the FULL record goes (default gpurun_out/bench_detail.json; it is also printed to stderr); stdout carries "
                          "only the compact line")
     ap.add_argument("--light", action="store_true",
-                    help="headline only: --no-secondary --no-ragged --gamma-scale 0 (profiler-driven and per-config runs)")
+                    help="headline only: --no-secondary --no-ragged --gamma-scale 0 --no-cpu-baseline (profiler-driven and per-config runs)")
     args = ap.parse_args()
     p = PRESETS[1 if args.config is None else args.config]
     for k in ("batch", "views", "points", "flow_steps", "dtype", "rigidity"):
         if getattr(args, k) is None:
             setattr(args, k, p[k])
-    if args.light:
-        args.no_secondary, args.no_ragged, args.gamma_scale = True, True, 0.0
+    if args.light:      # (the CPU leg and the device checker of a 2 x 32 768-point pair take tens of minutes: they belong to the default run only)
+        args.no_secondary, args.no_ragged, args.gamma_scale, args.no_cpu_baseline = True, True, 0.0, True
     return args
 
 

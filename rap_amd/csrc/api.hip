@@ -196,7 +196,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 17 && value >= 0) { g_rap_x2_min_rows = value; return RAP_OK; }   // split precision from this many token rows per call (smaller calls: exact fp32)
   if (key == 18 && value >= 0) { g_rap_ring_blocks = value; return RAP_OK; }      // four-stage ring of the 128 x 128 16-bit GEMM up to this many blocks per launch (0 = never)
   if (key == 19 && (value == 0 || value == 1)) { g_rap_small_fused = value; return RAP_OK; }      // combine + LayerNorm fusion of few-token calls
-  if (key == 20 && (value == 0 || value == 1)) { g_rap_attn_h16_small = value; return RAP_OK; }   // 16-bit attention of few-token calls: 64 / 128-row work items + four-stage ring
+  if (key == 20 && (value == 0 || value == 1 || value == 64 || value == 128)) { g_rap_attn_h16_small = value; return RAP_OK; }   // 16-bit attention of few-token calls: 64 / 128-row work items + four-stage ring
   if (key == 16 && (value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: 1 / 2 blocks per CU
   return RAP_ERR_INVALID;
 }

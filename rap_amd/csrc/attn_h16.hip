@@ -316,12 +316,14 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
 rap_tuning_t g_rap_attn_h16_variant = 0;
 rap_tuning_t g_rap_attn_h16_dma = 1;      // tuning key 13: K / V^T tiles by LDS-DMA (1, default) or staged through registers (0)
 
-// Query rows per work item: 256, or -- few-token calls (tuning key 20) -- 64 / 128 for calls of at most 2 048 / 4 096 token rows, where 256-row
-// items leave three quarters / half of the CUs without a block.  rows = align_up(TP, 256) of the call (0: the kernel-level entry points).
+// Query rows per work item: 256, or -- few-token calls (tuning key 20) -- 64 / 128 for calls of at most 2 048 / 8 192 token rows, where 256-row
+// items leave most of the CUs without a block (or with one block and nothing to overlap its barriers with).  rows = align_up(TP, 256) of the call (0: the kernel-level entry points).
 rap_tuning_t g_rap_attn_h16_small = 1;    // tuning key 20: 1 (default) = small work items + four-stage ring for few-token calls, 0 = 256 rows, two stages
 int attention_h16_block_queries(int, long rows) {
-  if (!g_rap_attn_h16_small || !g_rap_attn_h16_dma || rows <= 0) return 256;
-  return rows <= 2048 ? 64 : rows <= 4096 ? 128 : 256;
+  const int mode = g_rap_attn_h16_small;
+  if (!mode || !g_rap_attn_h16_dma || rows <= 0 || rows > 8192) return 256;
+  if (mode == 64 || mode == 128) return mode;      // A/B: force the item size for every call of at most 8 192 rows
+  return rows <= 2048 ? 64 : 128;
 }
 
 // the model path asks before it runs qk-norm: pre-scaled q only feeds the bounded bf16 kernel
@@ -336,7 +338,8 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
                          int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled, int bq) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0 || vt_nblk * 64 < TP || (bq != 64 && bq != 128 && bq != 256)) return RAP_ERR_INVALID;
-  const bool ring = bq < 256 && g_rap_attn_h16_dma;      // few-token work lists: the four-stage ring
+  // few-token work lists -- small items, or at most two blocks per CU: nothing hides the next tile's round trip -- take the four-stage ring
+  const bool ring = g_rap_attn_h16_dma && g_rap_attn_h16_small && (bq < 256 || (long)max_items * heads <= 512);
   if (q_prescaled && !(bound && attention_h16_wants_prescaled_q(dtype, true))) return RAP_ERR_INVALID;
 #ifdef RAP_ABLATION_BUILD
   if (g_rap_attn_h16_variant == 5) bound = nullptr;
