@@ -316,14 +316,16 @@ __global__ __launch_bounds__(512, 2) void attention_h16_kernel(const u16* __rest
 rap_tuning_t g_rap_attn_h16_variant = 0;
 rap_tuning_t g_rap_attn_h16_dma = 1;      // tuning key 13: K / V^T tiles by LDS-DMA (1, default) or staged through registers (0)
 
-// Query rows per work item: 256, or -- few-token calls (tuning key 20) -- 64 / 128 for calls of at most 2 048 / 8 192 token rows, where 256-row
-// items leave most of the CUs without a block (or with one block and nothing to overlap its barriers with).  rows = align_up(TP, 256) of the call (0: the kernel-level entry points).
+// Query rows per work item: 256, or -- few-token calls (tuning key 20) -- 128 for calls of at most 4 096 token rows, where 256-row items leave
+// most of the CUs without a block.  rows = align_up(TP, 256) of the call (0: the kernel-level entry points).
 rap_tuning_t g_rap_attn_h16_small = 1;    // tuning key 20: 1 (default) = small work items + four-stage ring for few-token calls, 0 = 256 rows, two stages
 int attention_h16_block_queries(int, long rows) {
   const int mode = g_rap_attn_h16_small;
   if (!mode || !g_rap_attn_h16_dma || rows <= 0 || rows > 8192) return 256;
   if (mode == 64 || mode == 128) return mode;      // A/B: force the item size for every call of at most 8 192 rows
-  return rows <= 2048 ? 64 : 128;
+  // r06 call 9 (bf16, ms per call; 64 / 128 / 256-row items): 2 048 rows 16.4 / 16.2 / 17.6, 4 096 rows 48.9 / 43.3 / 47.0, 8 000 rows
+  // 110 / 80.8 / 77.5 -- 128-row items up to 4 096 rows, 256 above
+  return rows <= 4096 ? 128 : 256;
 }
 
 // the model path asks before it runs qk-norm: pre-scaled q only feeds the bounded bf16 kernel
@@ -338,8 +340,9 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
                          int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled, int bq) {
   if (max_items <= 0 || TP <= 0) return RAP_OK;
   if (heads <= 0 || vt_nblk * 64 < TP || (bq != 64 && bq != 128 && bq != 256)) return RAP_ERR_INVALID;
-  // few-token work lists -- small items, or at most two blocks per CU: nothing hides the next tile's round trip -- take the four-stage ring
-  const bool ring = g_rap_attn_h16_dma && g_rap_attn_h16_small && (bq < 256 || (long)max_items * heads <= 512);
+  // few-token work lists (small items: one block per CU, nothing hides the next tile's round trip) take the four-stage ring.  For 256-row
+  // items with at most two blocks per CU (8 000 rows) the ring measured 77.5 vs 76.9 ms per call (r06 call 10): two stages there.
+  const bool ring = g_rap_attn_h16_dma && bq < 256;
   if (q_prescaled && !(bound && attention_h16_wants_prescaled_q(dtype, true))) return RAP_ERR_INVALID;
 #ifdef RAP_ABLATION_BUILD
   if (g_rap_attn_h16_variant == 5) bound = nullptr;
