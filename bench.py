@@ -75,10 +75,10 @@ CPU_BASELINE_THREADS = 16
 # were measured on.
 SHIPPED_ATTENTION_SYMBOL = {
     ("float32", True): "attention_f32_kernel<4, true, false>", ("float32", False): "attention_f32_kernel<4, false, false>",
-    ("bfloat16", True): "attention_h16_kernel<1, 24, true>",
-    ("bfloat16", False): "attention_h16_kernel<1, 3, true>",
-    ("float16", True): "attention_h16_kernel<2, 3, true>",
-    ("float16", False): "attention_h16_kernel<2, 3, true>",
+    ("bfloat16", True): "attention_h16_kernel<1, 24, true, 2>",
+    ("bfloat16", False): "attention_h16_kernel<1, 3, true, 2>",
+    ("float16", True): "attention_h16_kernel<2, 3, true, 2>",
+    ("float16", False): "attention_h16_kernel<2, 3, true, 2>",
     ("float32x2", True): "attention_x2_kernel<2, false>", ("float32x2", False): "attention_x2_kernel<2, false>",
 }
 

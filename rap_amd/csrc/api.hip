@@ -708,12 +708,12 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         GemmParamsH o{};
         o.A = w.atth; o.lda = 2 * d; o.W = lh.Wout[a]; o.ldw = 2 * d; o.C = w.h; o.ldc = d; o.M = TP; o.N = d; o.K = 2 * d;
         o.bias = lw.bout[a]; o.resid = w.h; o.ldr = d; o.acc_scale = lh.s_out[a] / lh.g_v[a];      // (the attention output carries V's activation scale)
-        if (fused) { o.splitk_ws = w.splitk_h; o.defer_combine = 1; }
+        if (fused) { o.splitk_ws = w.splitk_h; o.defer_combine = 1; o.force_splits = fused_splits(o); }      // (the count is fixed HERE: the GEMM and the pass that reads its planes cannot disagree)
         { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, o); }
         if (rc) return rc;
         if (fused) {      // combine pass + the NEXT LayerNorm in one kernel: adaLN of the per-sample branch after a = 0, the FFN's affine LN after a = 1
           ProfScope ps(stream, 3);
-          rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, fused_splits(o), o.bias, w.h, 0, w.xnh, TP, d,
+          rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, o.force_splits, o.bias, w.h, 0, w.xnh, TP, d,
                                            a == 0 ? mod + (size_t)(j + 1) * 2 * d : nullptr, mod_stride, token_row, lw.ffn_g, lw.ffn_b);
           if (rc) return rc;
           xn_ready = true;
@@ -731,13 +731,13 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       f2.bias = lw.bff2; f2.resid = w.h; f2.ldr = d; f2.acc_scale = lh.s_ff2 / lh.g_ff1;
       f2.splitk_ws = w.splitk_h;               // few-token calls: the physical K = 8d split over 2 / 4 blocks per tile (null otherwise)
       const bool f2_fused = fused && i + 1 < m->L;      // ... and its combine pass is the first LayerNorm of the next layer
-      if (f2_fused) f2.defer_combine = 1;
+      if (f2_fused) { f2.defer_combine = 1; f2.force_splits = fused_splits(f2); }
       { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, EPI_H_BIAS_RESID_F32, f2); }
       if (rc) return rc;
       xn_ready = false;
       if (f2_fused) {
         ProfScope ps(stream, 3);
-        rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, fused_splits(f2), f2.bias, w.h, 0, w.xnh, TP, d,
+        rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, f2.force_splits, f2.bias, w.h, 0, w.xnh, TP, d,
                                          mod + (size_t)(2 * i + 2) * 2 * d, mod_stride, token_row, nullptr, nullptr);
         if (rc) return rc;
         xn_ready = true;
@@ -779,12 +779,12 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
         o.A = w.atth; o.lda = d; o.W = lh.Wout[a]; o.ldw = d; o.ldc = d; o.M = TP; o.N = d; o.K = d;
         o.bias = lw.bout[a]; o.ldr = d;
         if (w.h16) { o.C = w.h16; o.resid_h = w.h16; } else { o.C = w.h; o.resid = w.h; }
-        if (fused) { o.splitk_ws = w.splitk_h; o.defer_combine = 1; }
+        if (fused) { o.splitk_ws = w.splitk_h; o.defer_combine = 1; o.force_splits = fused_splits(o); }
         { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, epi_resid, o); }
         if (rc) return rc;
         if (fused) {      // combine pass + the NEXT LayerNorm in one kernel (see the split-precision block)
           ProfScope ps(stream, 3);
-          rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, fused_splits(o), o.bias, w.h16 ? (void*)w.h16 : (void*)w.h, hres_f16, w.xnh, TP, d,
+          rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, o.force_splits, o.bias, w.h16 ? (void*)w.h16 : (void*)w.h, hres_f16, w.xnh, TP, d,
                                            a == 0 ? mod + (size_t)(j + 1) * 2 * d : nullptr, mod_stride, token_row, lw.ffn_g, lw.ffn_b);
           if (rc) return rc;
           xn_ready = true;
@@ -803,13 +803,13 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
       f2.splitk_ws = w.splitk_h;               // few-token calls: K = 4d split over 2 / 4 blocks per tile (null otherwise)
       if (w.h16) { f2.C = w.h16; f2.resid_h = w.h16; } else { f2.C = w.h; f2.resid = w.h; }
       const bool f2_fused = fused && i + 1 < m->L;
-      if (f2_fused) f2.defer_combine = 1;
+      if (f2_fused) { f2.defer_combine = 1; f2.force_splits = fused_splits(f2); }
       { ProfScope ps(stream, 2); rc = launch_gemm_h16(stream, dt, epi_resid, f2); }
       if (rc) return rc;
       xn_ready = false;
       if (f2_fused) {
         ProfScope ps(stream, 3);
-        rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, fused_splits(f2), f2.bias, w.h16 ? (void*)w.h16 : (void*)w.h, hres_f16, w.xnh, TP, d,
+        rc = launch_resid_combine_ln_h16(stream, dt, w.splitk_h, f2.force_splits, f2.bias, w.h16 ? (void*)w.h16 : (void*)w.h, hres_f16, w.xnh, TP, d,
                                          mod + (size_t)(2 * i + 2) * 2 * d, mod_stride, token_row, nullptr, nullptr);
         if (rc) return rc;
         xn_ready = true;
