@@ -12,6 +12,12 @@
 //   * MODE bit 4: epilogue through a per-wave LDS slab (ds_write_b64 of the lane's 4-column groups, whole 256-byte rows out);
 //   * ablation of the main loop (with MODE bits 0 and 1 set): bit 2 = no LDS-DMA after the prologue, bit 3 = no fragment reads after the
 //     first (the MFMAs run on stale registers): 3 = full loop, 7 = MFMA + reads, 11 = MFMA + DMA, 15 = MFMA + barrier only.
+//   * MODE bit 6 (round 6): the W operand does NOT go through LDS.  The weights are static, so they are packed once in
+//     MFMA-fragment order (pack_w_kernel: [32-column block][k-tile][k-step][lane][8 bf16] = one contiguous KB per fragment load) and every
+//     wave loads its own fragments global -> VGPR (global_load_dwordx4, scalar base + lane * 16) one k-tile ahead into a second register
+//     set; the LDS-DMA stream carries A only (8 pieces per k-tile instead of 16) and the four W fragment reads per k-step disappear.  The
+//     price: the two wave rows of a 256 x 256 tile multiply the same 256 weight columns, LDS served them once, registers serve each its own
+//     copy (64 KB of W per k-tile per CU from L2 instead of 32).
 // extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_err)  -> TFLOP/s (max_err vs a naive kernel on a sample of C)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,9 +45,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(VOFF), "s"(LDSB), "s"(SBASE) : "memory", "m0");
 #define W4_FENCE __builtin_amdgcn_sched_barrier(0);
 
+// one W fragment (8 bf16 per lane, 1 KB per wave) global -> VGPR: scalar base + per-lane byte offset; the caller counts it on vmcnt
+#define W4_GLD(DST, VOFF, SBASE) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(DST) : "v"(VOFF), "s"(SBASE) : "memory");
+
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const u16* __restrict__ A, int lda, const u16* __restrict__ W, int ldw,
-                                                         u16* __restrict__ C, int ldc, int M, int N, int K) {
+                                                         u16* __restrict__ C, int ldc, int M, int N, int K, const u16* __restrict__ Wp) {
+  constexpr bool BREG = (MODE & 64) != 0;
   constexpr int STAGE = 65536, WOFF = 32768;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -84,6 +94,125 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const u16* __restrict__
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[set][j]), __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
   };
 
+  if constexpr (BREG) {
+    // ---------------- W through registers (see the header): persistent walk, one output tile after the other, nk even ----------------
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 fwg[2][4][4];                           // [k-tile parity][k-step][32-column block j]
+    const unsigned vlane = (unsigned)lane * 16u;
+    const size_t jstride = (size_t)nk * 4096;      // bytes between the packed panels of consecutive 32-column blocks
+    const int stride_b = (MODE & 2) ? (int)gridDim.x : total;
+    int vb = blockIdx.x;
+    if (vb >= total) return;
+    auto bases = [&](int v, const unsigned char*& ab, const unsigned char*& wpb, int& m0_, int& n0_) {
+      const int logical = xcd_remap(v, total);
+      m0_ = (logical / nt) * 256; n0_ = (logical % nt) * 256;
+      ab = reinterpret_cast<const unsigned char*>(A) + (size_t)m0_ * lda * 2;
+      wpb = reinterpret_cast<const unsigned char*>(Wp) + (size_t)((n0_ + wc * 128) / 32) * jstride;
+    };
+    const unsigned char *ab, *wpb, *abn, *wpbn;
+    int m0b, n0b, m0bn, n0bn;
+    bases(vb, ab, wpb, m0b, n0b);
+    // prologue: A k-tile 0 -> stage 0 (8 pieces), W k-tile 0 -> register set 0 (16 loads)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W4_DMA1(voffA, ab + i * a_step, lds_wave + (unsigned)(i * 4096))
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) W4_GLD(fwg[0][ks][j], vlane, wpb + j * jstride + ks * 1024)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto read_a = [&](int set, int stage, int ks) {
+      const int co = ((2 * ks + hi) ^ sw) * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const uint4*>(a_rd + stage * STAGE + i * 4096 + co);
+    };
+    read_a(0, 0, 0);
+    int par = 0;
+    for (;;) {
+      const int vn = vb + stride_b;
+      const bool has_next = vn < total;
+      if (has_next) bases(vn, abn, wpbn, m0bn, n0bn); else { abn = ab; wpbn = wpb; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      // one k-tile with compile-time register parity P: MFMAs on fa (LDS) x fwg[P]; fillers: the 4 A fragment reads of the next k-step,
+      // the 16 W loads of the NEXT k-tile into fwg[P ^ 1] (6 + 5 + 5 in k-steps 0-2), its 8 A pieces by LDS-DMA (3 + 3 + 2)
+      auto ktile = [&](auto pc, int kt) __attribute__((always_inline)) {
+        constexpr int P = decltype(pc)::value;
+        const int cur = par;
+        const bool own = kt + 1 < nk;
+        const unsigned char* a_n = own ? ab + (size_t)(kt + 1) * 128 : abn;
+        const unsigned char* w_n = own ? wpb + (size_t)(kt + 1) * 4096 : wpbn;
+        const unsigned lds_n = lds_wave + (unsigned)((cur ^ 1) * STAGE);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int set = ks & 1, nset = set ^ 1;
+#pragma unroll
+          for (int idx = 0; idx < 16; ++idx) {
+            const int i = idx & 3, j = idx >> 2;
+            if (ks == 3 && idx == 8) {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next k-tile's A pieces AND its 16 W fragments have landed
+              __builtin_amdgcn_s_barrier();
+              W4_FENCE
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fwg[P][ks][j]), __builtin_bit_cast(bf16x8, fa[set][i]), acc[i][j], 0, 0, 0);
+            W4_FENCE
+            // ---- fillers
+            if (ks < 3 ? idx < 4 : (idx >= 8 && idx < 12)) {          // A fragments of the next k-step (of the next k-tile's k-step 0 after the barrier)
+              const int rd = ks < 3 ? idx : idx - 8;
+              const int stage_r = ks < 3 ? cur : (cur ^ 1);
+              const int ks_r = ks < 3 ? ks + 1 : 0;
+              const int co = ((2 * ks_r + hi) ^ sw) * 16;
+              fa[nset][rd] = *reinterpret_cast<const uint4*>(a_rd + stage_r * STAGE + rd * 4096 + co);
+            }
+            if (ks < 3) {
+              const int g0 = ks == 0 ? 0 : ks == 1 ? 6 : 11, ng = ks == 0 ? 6 : 5;     // W loads of this k-step: 6 + 5 + 5 = 16
+              if (idx >= 4 && idx - 4 < ng) {
+                const int g = g0 + idx - 4;                       // 0..15 -> (k-step g >> 2, column block g & 3) of the next k-tile
+                W4_GLD(fwg[P ^ 1][g >> 2][g & 3], vlane, w_n + (size_t)(g & 3) * jstride + (g >> 2) * 1024)
+              }
+              const int p0 = ks == 0 ? 0 : ks == 1 ? 3 : 6, np = ks == 2 ? 2 : 3;      // A pieces: 3 + 3 + 2 = 8
+              if (idx >= 12 && idx - 12 < np) {
+                const int pi = p0 + idx - 12;
+                W4_DMA1(voffA, a_n + pi * a_step, lds_n + (unsigned)(pi * 4096))
+              }
+            }
+            W4_FENCE
+          }
+        }
+        par ^= 1;
+      };
+      for (int kt = 0; kt < nk; kt += 2) {
+        ktile(std::integral_constant<int, 0>{}, kt);
+        ktile(std::integral_constant<int, 1>{}, kt + 1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+      W4_FENCE
+      const bool store = (MODE & 1) ? (acc[0][0][0] == 123456.789f) : true;
+      if (store) {      // direct 8-byte stores (the epilogue is not what this mode measures)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u16* crow = C + (size_t)(m0b + wr * 128 + 32 * i + l31) * ldc + n0b + wc * 128 + 4 * hi;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 v4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+              *reinterpret_cast<uint2*>(crow + 32 * j + 8 * g) = __builtin_bit_cast(uint2, __builtin_convertvector(v4, bf16x4));
+            }
+        }
+      }
+      if (!has_next) break;
+      vb = vn; ab = abn; wpb = wpbn; m0b = m0bn; n0b = n0bn;
+    }
+    return;
+  }
   // The k-tiles of consecutive output tiles form ONE stream (as in the shipped persistent kernel): the last k-tile of an output tile
   // requests the FIRST k-tile of the block's next output tile (or, for the very last one, its own first k-tile again: valid memory,
   // never read), so there is one prologue per block and one copy of the k-loop body without a branch.  The epilogue uses no LDS.
@@ -235,6 +364,21 @@ __global__ void init_kernel(u16* p, size_t n, unsigned seed, float scale) {
   }
 }
 
+// W (N,K) row-major -> fragment order: [n / 32][k / 64][k-step 0..3][lane 0..63][8]: lane (l31, hi) of k-step ks holds W[32 nb + l31][64 kt + 8 (2 ks + hi) .. +7]
+__global__ void pack_w_kernel(const u16* __restrict__ W, int ldw, int N, int K, u16* __restrict__ Wp) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte piece
+  const size_t pieces = (size_t)N * K / 8;
+  if (i >= pieces) return;
+  const int lane = (int)(i & 63);
+  const size_t f = i >> 6;                       // fragment index = (nb * nk + kt) * 4 + ks
+  const int ks = (int)(f & 3);
+  const int nk = K / 64;
+  const int kt = (int)((f >> 2) % nk);
+  const int nb = (int)((f >> 2) / nk);
+  const int n = nb * 32 + (lane & 31), k = kt * 64 + 8 * (2 * ks + (lane >> 5));
+  *reinterpret_cast<uint4*>(Wp + i * 8) = *reinterpret_cast<const uint4*>(W + (size_t)n * ldw + k);
+}
+
 // naive reference on a sample of rows
 __global__ void ref_kernel(const u16* A, int lda, const u16* W, int ldw, float* out, const int* rows, int nrows, int N, int K) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -260,6 +404,12 @@ extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_
   hipLaunchKernelGGL(init_kernel, dim3(4096), dim3(256), 0, 0, A, na, 12345u, 2.0f * zs);
   hipLaunchKernelGGL(init_kernel, dim3(4096), dim3(256), 0, 0, W, nw, 777u, 0.1f * zs);
   (void)hipMemset(C, 0, nc * 2);
+  u16* Wp = nullptr;
+  if (mode & 64) {
+    if ((K / 64) % 2) return -1.0;
+    if (hipMalloc((void**)&Wp, nw * 2) != hipSuccess) return -2.0;
+    hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((nw / 8 + 255) / 256)), dim3(256), 0, 0, W, K, N, K, Wp);
+  }
   constexpr int LDS = 2 * 65536;
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
@@ -269,11 +419,11 @@ extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_
 #define W4_CASE(MD)                                                                                                          \
   case MD:                                                                                                                   \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<MD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-    hipLaunchKernelGGL(gemm_w4_kernel<MD>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K);                        \
+    hipLaunchKernelGGL(gemm_w4_kernel<MD>, dim3(grid), dim3(256), LDS, 0, A, K, W, K, C, N, M, N, K, Wp);                    \
     break;
   auto launch = [&]() {
-    switch (mode & 31) {
-      W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(7) W4_CASE(11) W4_CASE(15) W4_CASE(16) W4_CASE(18)
+    switch (mode & (31 | 64)) {
+      W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(7) W4_CASE(11) W4_CASE(15) W4_CASE(16) W4_CASE(18) W4_CASE(66) W4_CASE(67)
       default: break;
     }
   };
@@ -314,6 +464,6 @@ extern "C" double gemm_w4(int M, int N, int K, int mode, int iters, double* max_
   (void)hipEventSynchronize(e1);
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, e0, e1);
-  (void)hipFree(A); (void)hipFree(W); (void)hipFree(C);
+  (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); if (Wp) (void)hipFree(Wp);
   return 2.0 * M * N * K * iters / (ms * 1e-3) / 1e12;
 }

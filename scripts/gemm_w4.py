@@ -21,6 +21,9 @@ for name, M, N, K in SHAPES:
     if "--ablation" in sys.argv:
         modes = ((3, "persistent, main loop only"), (7, "main loop without LDS-DMA (MFMA + fragment reads + barrier)"),
                  (11, "main loop without fragment reads (MFMA + LDS-DMA + barrier)"), (15, "MFMA + barrier only"))
+    if "--breg" in sys.argv:      # round 6: W packed in fragment order, global -> VGPR, the LDS-DMA stream carries A only
+        modes = ((2, "persistent, both operands through LDS (direct 8-byte stores)"), (66, "persistent, W through REGISTERS (packed, global -> VGPR), A through LDS"),
+                 (3, "persistent, main loop only, both operands through LDS"), (67, "persistent, main loop only, W through REGISTERS"))
     if "--zeros" in sys.argv:
         if name != "guide square":
             continue
