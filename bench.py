@@ -970,7 +970,8 @@ def main():
         total_pts = job_pts * args.steps
         value = total_pts / elapsed
         result = {
-            "metric": f"registered points/sec @{args.flow_steps} flow steps, {args.views}-view N={args.points}", "value": value, "unit": "points/s",
+            "metric": (f"registered points/sec @{args.flow_steps} flow steps, {args.views}-view N={args.points}" if args.workload == "uniform" else
+                       f"registered points/sec @{args.flow_steps} flow steps, ragged reference-regime batch"), "value": value, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": DTYPE_TAG[args.dtype], "data": "synthetic",
             "config": {"workload": ((f"RAGGED reference-regime batch ({len(parts)} samples, {pts_per_rank} points; NOT BASELINE's configuration): "
