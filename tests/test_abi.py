@@ -132,6 +132,20 @@ def test_new_entry_points_validate_arguments_without_a_gpu():
     for key in (5, 6, 7, 9, 11, 12, 13, 15):
         assert lib.rap_set_tuning(key, 2) == -1 and lib.rap_set_tuning(key, 1) == 0, key
     assert lib.rap_model_bounded_attention_launches(N) < 0
+    # round 6: the latent-feature entry points, the transform-error metric, the few-token switches
+    desc = _lib.ModelDesc(512, 12, 8, 32)
+    n0 = lib.rap_weight_count(ctypes.byref(desc))
+    assert lib.rap_weight_count_latent(ctypes.byref(desc), 0) == n0
+    assert lib.rap_weight_count_latent(ctypes.byref(desc), 64) == n0 + 512 * 64        # 64 more columns of emb_proj.weight
+    assert lib.rap_weight_count_latent(ctypes.byref(desc), 6) == -1 and lib.rap_weight_count_latent(ctypes.byref(desc), 516) == -1
+    assert lib.rap_model_create_latent(ctypes.byref(desc), 64, N, n0 + 512 * 64, N, ctypes.byref(ctypes.c_void_p(0))) == -1      # NULL weights
+    assert lib.rap_dit_forward_latent(N, N, N, N, N, N, N, N, N, N, 1, 1, 10, N, N, N, 0, N) == -1
+    assert lib.rap_sample_latent(N, N, N, N, N, N, N, N, N, 1, 1, 10, 2, 1, N, N, N, N, N, N, 0, N) == -1
+    assert lib.rap_transform_errors(N, N, N, N, N, N, N, N, 1, 1, N, N, N, N, N) == -1
+    assert lib.rap_attention_workspace_bytes(262144, 64) >= (262144 // 256 + 65) * 16 + 65 * 4      # work items + the sanitised cu_seqlens copy
+    assert lib.rap_set_tuning(18, -1) == -1 and lib.rap_set_tuning(18, 256) == 0
+    assert lib.rap_set_tuning(19, 2) == -1 and lib.rap_set_tuning(19, 1) == 0
+    assert lib.rap_set_tuning(20, 32) == -1 and lib.rap_set_tuning(20, 1) == 0
 
 
 def test_split_precision_entry_points_refuse_bad_shapes_without_a_gpu():
