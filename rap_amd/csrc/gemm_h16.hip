@@ -1309,7 +1309,7 @@ static int launch_cfg(hipStream_t stream, const GemmParamsH& p, int splits = 1) 
 // The 128 x 128 kernel for few-token calls (round 6): a launch with at most g_rap_ring_blocks blocks (tuning key 18; 0 = never) takes the
 // four-stage ring, one block per CU; larger launches keep two stages and two blocks per CU, whose second block is what hides the latency.
 // (FIVE stages -- all 160 KB, three tiles in flight beside the fragment prefetch -- were measured for split precision in r06 call 14 and are
-// not kept: residual GEMMs 14.5 vs 13.9 us, QKV 21.0 vs 20.4, 24.9 vs 24.8 ms per demo-pair call; profiles/r06_c14_x2_ring_five_stages_*.
+// not kept: residual GEMMs 14.5 vs 13.9 us, QKV 21.0 vs 20.4, 25.2 vs 24.9 ms per demo-pair call; profiles/r06_c14_x2_ring_five_stages_*.
 // The ~1 us per split-precision k-tile that remains is not the L2 round trip.)
 rap_tuning_t g_rap_ring_blocks = 256;
 template <int EPI, int DT, bool X2 = false>
