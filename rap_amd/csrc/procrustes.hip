@@ -68,6 +68,8 @@ __device__ __forceinline__ double wave_sum16_scatter(double (&v)[16], int lane) 
   return r;
 }
 
+struct __attribute__((packed, aligned(4))) P3 { float x, y, z; };
+
 __global__ __launch_bounds__(256) void procrustes_moments_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
                                                                  const int32_t* __restrict__ off, double* __restrict__ partials) {
   __shared__ double red[4][16];
@@ -90,8 +92,9 @@ __global__ __launch_bounds__(256) void procrustes_moments_kernel(const float* __
       long i = base + threadIdx.x + u * 256;
       wgt[u] = i < hi ? 1.0 : 0.0;
       i = i < hi ? i : hi - 1;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { sv[u][c] = src[i * 3 + c]; tv[u][c] = tgt[i * 3 + c]; }
+      // one 12-byte load per point (global_load_dwordx3 needs 4-byte alignment only) instead of three strided dword loads
+      const P3 ps = reinterpret_cast<const P3*>(src)[i], pt = reinterpret_cast<const P3*>(tgt)[i];
+      sv[u][0] = ps.x; sv[u][1] = ps.y; sv[u][2] = ps.z; tv[u][0] = pt.x; tv[u][1] = pt.y; tv[u][2] = pt.z;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
