@@ -85,7 +85,7 @@ SHIPPED_ATTENTION_SYMBOL = {
 
 def pmc_traffic(dtype, symbol, section="kernels"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside this
-    process; the passes are separate runs, scripts/pmc_passes.sh, summarised in profiles/pmc_traffic.json per kernel SYMBOL).
+    process; the passes are separate runs, scripts/evidence.sh stages pmc / ragged, summarised in profiles/pmc_traffic.json per kernel SYMBOL).
     Returned only when the passes measured the instantiation this run timed; otherwise (None, reason)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:

@@ -10,7 +10,7 @@
 # Copy the files to profiles/r<NN>_final_* and profiles/pmc_traffic.json afterwards (bench.py reads the latter for roofline.traffic).
 set -u
 OUT=${1:?outdir}; shift || true
-STAGES=${*:-"trace pmc mfma c0"}
+STAGES=${*:-"trace pmc mfma c0"}      # + "ragged": the same two PMC passes on the ragged reference-regime batch (fp32, split precision, bf16)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 has() { [[ " $STAGES " == *" $1 "* ]]; }
@@ -19,6 +19,18 @@ ONE_STEP="--steps 1 --warmup 0 --flow-steps 1 --no-cpu-baseline --light --no-pro
 
 if has trace; then
   for m in $MODES; do HEAD=14 timeout 600 bash scripts/prof_bench.sh "$OUT/trace_$m" --dtype $m; done
+fi
+if has ragged; then
+  for m in float32 float32x2 bfloat16; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      D=$(mktemp -d /tmp/pmc.XXXXXX)
+      ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d "$D" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --workload ragged --dtype $m $ONE_STEP > "$GRAFT_REPO_ROOT/$OUT/pmc_ragged_${m}_$c.log" 2>&1 )
+      DB=$(find "$D" -name '*.db' | head -1)
+      if [ -n "$DB" ]; then python scripts/rocpd_summary.py "$DB" --pmc | grep -E "^PMC.*attention" > "$OUT/pmc_ragged_${m}_$c.txt"; else echo "no db" > "$OUT/pmc_ragged_${m}_$c.txt"; fi
+      rm -rf "$D"
+    done
+  done
+  cat "$OUT"/pmc_ragged_*_FETCH_SIZE.txt "$OUT"/pmc_ragged_*_WRITE_SIZE.txt
 fi
 if has pmc; then
   for m in $MODES; do

@@ -7,8 +7,7 @@
 #   latency[:args]   scripts/small_call_latency.py (comma-free args after ':' are passed through, '+' separates them)
 #   bench[:args]     bench.py with the given args ('+'-separated) -> bench_<n>.json (stdout line), bench_<n>_detail.json
 #   trace:<name>:<bench args>   rocprofv3 --kernel-trace of ONE call (scripts/prof_bench.sh) -> <name>.txt
-#   pmc              scripts/pmc_passes.sh (FETCH_SIZE / WRITE_SIZE passes for the dominant kernels)
-#   mfma             scripts/mfma_util.sh (SQ busy / MFMA counters on the model path)
+#   evidence[:stages] scripts/evidence.sh into gpurun_out/<tag>/evidence ('+'-separated stages: trace pmc ragged mfma c0; default all but ragged)
 set -u
 TAG=${1:?tag}; shift
 OUT=gpurun_out/$TAG
@@ -38,8 +37,7 @@ for STAGE in "$@"; do
     trace)
       NAME=${REST%%:*}; ARGS=""; [[ "$REST" == *:* ]] && ARGS=${REST#*:}
       HEAD=${HEAD:-24} timeout 900 bash scripts/prof_bench.sh "$OUT/$NAME" ${ARGS//+/ } ;;
-    pmc) bash scripts/pmc_passes.sh "$OUT/pmc" ;;
-    mfma) bash scripts/mfma_util.sh "$OUT/mfma" ;;
+    evidence) bash scripts/evidence.sh "$OUT/evidence" ${REST//+/ } ;;
     *) echo "unknown stage $STAGE" ;;
   esac
   n=$((n + 1))
