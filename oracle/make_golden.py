@@ -385,6 +385,9 @@ def make_headline_goldens(which=("c1_rigid", "c1_free", "c3", "c4")):
     sd = S.make_weights(cfg, 0)
     jobs = {"c1_rigid": ("headline_c1_rigid", 2, 4096, 20, True, 32), "c1_free": ("headline_c1_free", 2, 4096, 20, False, 32),
             "c3": ("headline_c3_rigid", 8, 2048, 30, True, 64),
+            # round 6: configs[0] in full -- the reference's own CPU-runnable case (demo pair: 2 views x 1024 points, rap_12, all 10
+            # steps, rigidity forcing on), input seed 2024; every 8th point of every step is kept
+            "c0": ("headline_c0_rigid", 2, 1024, 10, True, 8, 2024),
             # round 3: configs[4] geometry through ALL 12 layers and two re-noised flow steps with rigidity
             # forcing (attention at L = 65 536), and the first pair of RANK 1 of the configs[2] job (bench.py: rank r owns
             # samples [32 r, 32 r + 32), sample b is seeded 1234 + b)
@@ -458,7 +461,7 @@ def make_headline_goldens(which=("c1_rigid", "c1_free", "c3", "c4")):
 if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if a.endswith("-only")]     # e.g. --overlap-only regenerates one fixture
     if "--headline-only" in only:                               # ~1.5 h of CPU: never part of the default regeneration
-        make_headline_goldens(tuple(a[2:] for a in sys.argv[1:] if a[2:] in ("c1_rigid", "c1_free", "c3", "c4", "c4_steps", "c2_rank1", "c1_ragged", "c1_rap16")) or ("c1_rigid", "c1_free", "c3", "c4"))
+        make_headline_goldens(tuple(a[2:] for a in sys.argv[1:] if a[2:] in ("c0", "c1_rigid", "c1_free", "c3", "c4", "c4_steps", "c2_rank1", "c1_ragged", "c1_rap16")) or ("c1_rigid", "c1_free", "c3", "c4"))
         sys.exit(0)
     if any(a.startswith("--case=") for a in sys.argv[1:]):      # only the named sampler fixtures (main() filters)
         main()

@@ -45,6 +45,27 @@ def test_oracle_matches_reference_golden(name):
     assert float((fw["transformer_features"] - torch.from_numpy(g["fwd_features"])).abs().max()) < 2e-5
 
 
+def test_oracle_matches_reference_at_configs0_in_full():
+    """BASELINE configs[0] -- the reference's own CPU-runnable case -- in full: demo pair (2 views x 1024 points), rap_12, all 10 Euler
+    steps with rigidity forcing.  tests/golden/headline_c0_rigid.npz is the UNMODIFIED reference's output (make_golden.py
+    --headline-only --c0: final clouds, poses, per-step maxima and every 8th point of every step); the oracle must reproduce it."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "headline_c0_rigid.npz"))
+    g = {k: z[k] for k in z.files}
+    cfg = dict(S.RAP_12)
+    sd = S.make_weights(cfg, int(g["weight_seed"]))
+    assert abs(float(sum(v.double().sum().item() for v in sd.values())) - float(g["weights_checksum"])) < 1e-6
+    inp = S.make_uniform_inputs(1, int(g["views"]), int(g["points"]), seed=int(g["input_seed"]))
+    out = O.sample(sd, cfg, inp, int(g["num_steps"]), bool(g["rigidity"]))
+    st = int(g["stride"])
+    errs = {"final_end_point": float((out["end_point_trajectory"][-1] - torch.from_numpy(g["final_end_point"])).abs().max()),
+            "final_x_t": float((out["trajectory"][-1] - torch.from_numpy(g["final_x_t"])).abs().max()),
+            "end_point_steps": float((out["end_point_trajectory"][:, ::st] - torch.from_numpy(g["end_point_strided"])).abs().max()),
+            "x_t_steps": float((out["trajectory"][:, ::st] - torch.from_numpy(g["x_t_strided"])).abs().max()),
+            "R": float((out["R"] - torch.from_numpy(g["R"])).abs().max()), "t": float((out["t"] - torch.from_numpy(g["t"])).abs().max())}
+    print("oracle vs reference, configs[0] in full:", errs)
+    assert max(errs.values()) < 1e-5, errs
+
+
 @pytest.mark.skipif(not ref_loader.reference_available(), reason="/root/reference is only mounted in the build container")
 @pytest.mark.parametrize("switch", [{}] + list(SWITCH_CASES.values()) + list(LATENT_CASES.values()),
                          ids=["shipped-config"] + list(SWITCH_CASES) + list(LATENT_CASES))

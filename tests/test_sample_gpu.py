@@ -565,20 +565,29 @@ def test_chamfer_full_geometry_properties(dev):
     assert (compute_cd(gt, shifted, cu) - 0.25).abs().max().item() < 1e-6
 
 
-def test_config0_demo_pair_full_run_matches_oracle(dev):
+def test_config0_demo_pair_full_run_matches_the_reference(dev):
     """BASELINE configs[0] in full: one pair, 2 views x 1024 points, rap_12, all 10 Euler steps with the reference's default
-    rigidity forcing, against the CPU oracle (the reference's own CPU-runnable case; ~30 s of host time)."""
+    rigidity forcing, against the UNMODIFIED reference's own output for the same seeds (tests/golden/headline_c0_rigid.npz, made
+    by oracle/make_golden.py --headline-only --c0; the CPU suite holds the oracle to the same fixture).  Until round 6 this test
+    ran the CPU oracle on the GPU box (~60 s of host time); the fixture is the stronger checker and costs nothing."""
+    import numpy as np, os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "headline_c0_rigid.npz"))
+    g = {k: z[k] for k in z.files}
     cfg, sd, model = get_model(12, 0, dev)
-    inp = S.make_uniform_inputs(1, 2, 1024, seed=2024)
-    steps = 10
-    ref = O.sample(sd, cfg, inp, steps, True)
+    assert abs(float(sum(v.double().sum().item() for v in sd.values())) - float(g["weights_checksum"])) < 1e-6
+    steps, st = int(g["num_steps"]), int(g["stride"])
+    assert (int(g["views"]), int(g["points"]), steps, int(g["rigidity"])) == (2, 1024, 10, 1)
+    inp = S.make_uniform_inputs(1, 2, 1024, seed=int(g["input_seed"]))
     flow = rap_amd.RectifiedPointFlow(flow_model=model, inference_sampling_steps=steps, rigidity_forcing=True)
     out = flow.sample_and_register(to_dev(inp, dev), x_1=inp["x_1"].to(dev))
-    e0 = (out["end_point_trajectory"].cpu() - ref["end_point_trajectory"]).abs().max().item()
-    e1 = (out["trajectory"].cpu() - ref["trajectory"]).abs().max().item()
-    eR = torch.linalg.matrix_norm(out["R"].cpu() - ref["R"]).max().item()
-    et = (out["t"].cpu() - ref["t"]).abs().max().item()
-    print(f"configs[0] full run: x0 {e0:.2e} xt {e1:.2e} |dR|_F {eR:.2e} dt {et:.2e}")
+    ep, tr = out["end_point_trajectory"].cpu(), out["trajectory"].cpu()
+    e0 = max((ep[-1] - torch.from_numpy(g["final_end_point"])).abs().max().item(),
+             (ep[:, ::st] - torch.from_numpy(g["end_point_strided"])).abs().max().item())
+    e1 = max((tr[-1] - torch.from_numpy(g["final_x_t"])).abs().max().item(),
+             (tr[:, ::st] - torch.from_numpy(g["x_t_strided"])).abs().max().item())
+    eR = torch.linalg.matrix_norm(out["R"].cpu() - torch.from_numpy(g["R"])).max().item()
+    et = (out["t"].cpu() - torch.from_numpy(g["t"])).abs().max().item()
+    print(f"configs[0] full run vs the reference: x0 {e0:.2e} xt {e1:.2e} |dR|_F {eR:.2e} dt {et:.2e}")
     assert e0 <= 5e-4 and e1 <= 5e-4 and eR <= 1e-3 and et <= 1e-3, (e0, e1, eR, et)          # the stated tolerance
     assert e0 < 5e-5 and e1 < 5e-5 and eR < 5e-5 and et < 5e-5, (e0, e1, eR, et)              # what exact fp32 achieves
 
