@@ -485,8 +485,14 @@ int rap_profile_collect_ex(float* h_ms_out, int64_t* h_count_out, int32_t n_clas
  *   key 19 few-token 16-bit / split-precision calls: the combine pass of every residual GEMM folded into the LayerNorm that follows it
  *          {1 (default), 0 = the round-5 launch sequence}.  Bit-identical in the 16-bit modes; in split precision the fused sequence
  *          also splits K of the out-projection (fp32-class agreement)
- *   key 20 16-bit attention of few-token calls (<= 4 096 token rows): work items of 128 query rows and a four-stage K / V^T ring
- *          {1 (default), 0 = 256-row items, two stages; 64 / 128 force the item size up to 8 192 rows}.  Bit-identical results.  (rap_workspace_bytes does not depend on it.)
+ *   key 20 16-bit attention of few-token calls (<= 4 096 token rows)
+ *          {1 (default): the eight waves of a block are query waves x KEY GROUPS -- work items of 64 rows x 4 key groups up to 2 048 token
+ *             rows, 128 rows x 2 key groups up to 4 096; the groups' partial (O, l, m) meet in LDS, nothing extra leaves the CU.  The keys of a
+ *             row are summed in another order than by the unsplit kernel: deterministic, same error bound, not bit-identical to it;
+ *           2: work items of 128 rows and a four-stage K / V^T ring, no key groups -- bit-identical to 0;
+ *           0: 256-row items, two stages (round 5);
+ *           64 / 128: that item size + ring, 66 / 130: 64 rows x 4 / 128 rows x 2 key groups -- forced for every call of at most 8 192 token
+ *             rows AND for rap_attention_h16 (the A/B values)}.  (rap_workspace_bytes does not depend on it.)
  * Operand range of compute dtype 3 (and of the fp16 residual stream): every paired activation -- LayerNorm output, q / k (also without
  * qk-norm), v, attention output, GEGLU output -- is clipped to +-65 504 before it is split into head and tail (NaN stays NaN), and
  * rap_model_set_compute_dtype(3) refuses weights that are not finite.  scripts/check_checkpoint.py compares the mode with exact fp32 on

@@ -196,7 +196,7 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 17 && value >= 0) { g_rap_x2_min_rows = value; return RAP_OK; }   // split precision from this many token rows per call (smaller calls: exact fp32)
   if (key == 18 && value >= 0) { g_rap_ring_blocks = value; return RAP_OK; }      // four-stage ring of the 128 x 128 16-bit GEMM up to this many blocks per launch (0 = never)
   if (key == 19 && (value == 0 || value == 1)) { g_rap_small_fused = value; return RAP_OK; }      // combine + LayerNorm fusion of few-token calls
-  if (key == 20 && (value == 0 || value == 1 || value == 64 || value == 128)) { g_rap_attn_h16_small = value; return RAP_OK; }   // 16-bit attention of few-token calls: 64 / 128-row work items + four-stage ring
+  if (key == 20 && (value == 0 || value == 1 || value == 2 || value == 64 || value == 128 || value == 66 || value == 130)) { g_rap_attn_h16_small = value; return RAP_OK; }   // 16-bit attention of few-token calls: 64 / 128-row work items + four-stage ring
   if (key == 16 && (value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: 1 / 2 blocks per CU
   return RAP_ERR_INVALID;
 }
@@ -497,6 +497,7 @@ struct Workspace {
   AttnWorkItem *items_batch, *items_part;
   int max_items_batch, max_items_part;
   int attn_bq;                          // query rows per work item of this call's attention lists
+  int attn_kg;                          // key groups per block of the 16-bit attention (1, or 2 / 4 for few-token calls)
   size_t total;
 };
 
@@ -558,6 +559,7 @@ static Workspace carve_workspace(const rap_model* m, int64_t TP, int B, int nseg
   w.cu_part_live = w.part_offsets; w.nseg_part = nseg_part; w.nseg_batch = B;
   // query rows per attention work item: 256, or 64 / 128 for few-token calls of the 16-bit modes (attention_h16_block_queries)
   w.attn_bq = (dtype == RAP_DT_BF16 || dtype == RAP_DT_F16) ? attention_h16_block_queries(dtype, (long)T) : RAP_ATTN_BQ;
+  w.attn_kg = (dtype == RAP_DT_BF16 || dtype == RAP_DT_F16) ? attention_h16_key_groups(dtype, (long)T) : 1;
   w.max_items_batch = (int)(TP / w.attn_bq) + B + 1;
   w.max_items_part = (int)(TP / w.attn_bq) + nseg_part + 1;
   // (reserved for the smallest work items whatever tuning key 20 says: the size rap_workspace_bytes reports does not depend on the key)
@@ -772,7 +774,7 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
           ProfScope ps(stream, a);
           const float* bound = bnd ? m->logit_bound + (size_t)j * H : nullptr;
           rc = launch_attention_h16(stream, dt, w.qkh, w.vth, w.vt_nblk, w.atth, TP, H, a == 0 ? w.items_part : w.items_batch,
-                                    a == 0 ? w.max_items_part : w.max_items_batch, bound, prescale ? 1 : 0, w.attn_bq);
+                                    a == 0 ? w.max_items_part : w.max_items_batch, bound, prescale ? 1 : 0, w.attn_bq, w.attn_kg);
         }
         if (rc) return rc;
         GemmParamsH o{};
@@ -1079,7 +1081,8 @@ extern "C" int rap_geglu_interleave(const float* W, const float* b, float* Wp, f
 
 // [work items | sanitised copy of the caller's cu_seqlens]: the kernel-level attention entry points index with the copy only (ADVICE r05:
 // an entry above TP in the caller's table made seg_start + q run past the planes; the model path has sanitised its tables since round 5)
-static size_t attn_items_bytes(int64_t TP, int32_t nseg) { return align_up(((size_t)(TP / RAP_ATTN_BQ) + (size_t)nseg + 1) * sizeof(AttnWorkItem), 256); }
+// (work items reserved at the smallest granularity, 64 rows: tuning key 20's forced item sizes reach rap_attention_h16 too)
+static size_t attn_items_bytes(int64_t TP, int32_t nseg) { return align_up(((size_t)(TP / 64) + (size_t)nseg + 1) * sizeof(AttnWorkItem), 256); }
 extern "C" size_t rap_attention_workspace_bytes(int64_t TP, int32_t nseg) {
   return attn_items_bytes(TP, nseg) + align_up(((size_t)nseg + 1) * sizeof(int32_t), 256);
 }
@@ -1183,12 +1186,16 @@ extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16
                                  const float* logit_bound, void* ws, size_t ws_bytes, void* stream_) {
   if (!qk || !vt || !cu_seqlens || !out || nseg < 0 || TP < 0 || TP > 0x7fffffffLL / 8) return RAP_ERR_INVALID;
   if (!ws || ws_bytes < rap_attention_workspace_bytes(TP, nseg)) return RAP_ERR_WORKSPACE;
-  const int max_items = (int)(TP / RAP_ATTN_BQ) + nseg + 1;
+  // 256-row work items, two stages -- unless tuning key 20 FORCES an item size / key groups (64, 128, 66, 130: the A/B values), which
+  // then applies here as it does to a model call of the same row count (so the few-token kernels have kernel-level tests)
+  const long rows = attention_h16_forced() ? (long)align_up((size_t)TP, 256) : 0;
+  const int bq = attention_h16_block_queries(dtype, rows), kg = attention_h16_key_groups(dtype, rows);
+  const int max_items = (int)(TP / bq) + nseg + 1;
   hipStream_t stream = (hipStream_t)stream_;
   int rc;
   if ((rc = attn_ws_sanitize(stream, cu_seqlens, nseg, TP, ws, &cu_seqlens))) return rc;
-  if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, attention_h16_block_queries(dtype)))) return rc;
-  return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound, 0);
+  if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, bq))) return rc;
+  return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound, 0, bq, kg);
 }
 extern "C" int rap_layernorm_mod_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* mod,
                                      int64_t mod_stride, const int32_t* token_row, void* stream) {

@@ -285,6 +285,11 @@ __global__ __launch_bounds__(512, WPE) void attention_x2_kernel(const u16* __res
 // 8192 against 5.62 / 11.05 ms for this kernel, 43.4 k vs 45.1 k points/s for the whole call.  Two blocks per CU (WPE = 4) are no
 // faster either.  As for the bf16 kernel, every schedule lands on the same ~1.2 PFLOP/s of issued fp16 MFMA work: the
 // SQ counters (profiles/r05_c3_mfma_utilisation_x2.txt) show the clock the part sustains under this load, not the schedule, as the limit.
+// Round 6 (GPU call 19, profiles/r06_c19_x2_attention_ring_latency.jsonl): the four-stage K / V^T ring that took the 16-bit kernel's few-token
+// launches from 24.1 to 19.2 us (attn_h16.hip) was built for the SPLIT launches of this kernel too (128 KB of LDS, counted vmcnt, bit-identical)
+// and changed nothing: 25.5 vs 25.4 ms per configs[0]-geometry call, 80.8 vs 80.5 at 4 096 rows.  A tile here is 48 MFMAs, ~350 VALU
+// instructions and 32 ds_read_b128 per wave with all eight waves of the block working -- about 1 us each of matrix pipe, VALU and LDS
+// bandwidth per tile and CU, executed phase by phase by waves that one barrier per tile keeps in step -- not the round trip of the next tile.
 rap_tuning_t g_rap_attn_x2_wpe = 2;      // tuning key 16: 2 / 4 = one / two blocks per CU
 extern rap_tuning_t g_rap_attn_split;    // attn_f32.hip, tuning key 5: split few-token attention launches over key ranges (1, default) or not (0)
 

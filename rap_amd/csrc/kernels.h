@@ -163,9 +163,12 @@ int launch_convert_h16(hipStream_t stream, int dtype, const float* src, uint16_t
 // bq: the query rows per work item the list was built with (attention_h16_block_queries: 256; 64 / 128 for few-token calls, which also take
 // the four-stage K / V^T ring)
 int launch_attention_h16(hipStream_t stream, int dtype, const uint16_t* qk, const uint16_t* vt, int vt_nblk, uint16_t* out,
-                         int TP, int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled, int bq = 256);
+                         int TP, int heads, const AttnWorkItem* items, int max_items, const float* bound, int q_prescaled, int bq = 256,
+                         int kg = 1);      // kg: key groups per block (1; 4 with bq = 64, 2 with bq = 128: attention_h16_kgroup_kernel)
 bool attention_h16_wants_prescaled_q(int dtype, bool bounded);
 int attention_h16_block_queries(int dtype, long rows = 0);      // work-list granularity of the 16-bit attention for a call of `rows` token rows
+bool attention_h16_forced();                                    // tuning key 20 holds one of its A/B values (a forced item size / key groups)
+int attention_h16_key_groups(int dtype, long rows = 0);         // key groups per block for the same call (1 unless tuning key 20 says so)
 // per-head logit bounds of one attention branch after qk-norm: out[h] = 8 * max_j|gamma_q[h][j]| * max_j|gamma_k[h][j]|
 int launch_qk_logit_bound(hipStream_t stream, const float* gamma_q, const float* gamma_k, int heads, float* out);
 // LayerNorm with 16-bit output (fp32 statistics), same modulation forms as launch_layernorm_*

@@ -23,7 +23,7 @@ for STAGE in "$@"; do
         timeout 1500 python -m pytest tests -m gpu -q -rP -k "$REST" > "$OUT/pytest_${REST//[^a-zA-Z0-9_]/_}.log" 2>&1; echo "pytest -k '$REST' exit $?"
         grep -E "^(FAILED|ERROR)|passed|failed|^envelope |^transform errors|\[float32x2\]|\[bfloat16\]: vel" "$OUT/pytest_${REST//[^a-zA-Z0-9_]/_}.log" | tail -40
       else
-        timeout 1700 python -m pytest tests -m gpu -q --durations=15 > "$OUT/pytest_gpu.log" 2>&1; echo "pytest exit $?"
+        timeout 1700 python -m pytest tests -m gpu -q --durations=40 > "$OUT/pytest_gpu.log" 2>&1; echo "pytest exit $?"
         grep -E "^(FAILED|ERROR)|passed|failed|s call" "$OUT/pytest_gpu.log" | tail -30
       fi ;;
     smoke)
