@@ -580,15 +580,17 @@ bool attention_h16_wants_prescaled_q(int dtype, bool bounded) {
 
 #define HKG_LDS_BYTES (16 * HKV * 64 * 2)      // 8 K + 8 V^T tile slots
 template <int DT, int OPT, int KG>
-static void launch_kgroup(hipStream_t stream, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP, int heads, const AttnWorkItem* items,
-                          int max_items, const float* bound) {
-  static bool prepared = false;        // more than the 64 KB a kernel may use without asking
-  if (!prepared) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_h16_kgroup_kernel<DT, OPT, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, HKG_LDS_BYTES);
-    prepared = true;
+static int launch_kgroup(hipStream_t stream, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP, int heads, const AttnWorkItem* items,
+                         int max_items, const float* bound) {
+  // more than the 64 KB a kernel may use without asking; set per launch (as attn_x2.hip does): the attribute belongs to the current device
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_h16_kgroup_kernel<DT, OPT, KG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          HKG_LDS_BYTES) != hipSuccess) {
+    rap_set_last_hip_error((int)hipGetLastError());
+    return RAP_ERR_HIP;
   }
   hipLaunchKernelGGL((attention_h16_kgroup_kernel<DT, OPT, KG>), dim3(max_items * heads), dim3(512), HKG_LDS_BYTES, stream, qk, vt, vt_nblk, out, TP,
                      heads, items, bound);
+  return RAP_OK;
 }
 
 int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16* vt, int vt_nblk, u16* out, int TP,
@@ -605,10 +607,11 @@ int launch_attention_h16(hipStream_t stream, int dtype, const u16* qk, const u16
 #endif
 #define HATT_LAUNCH(DTV, OPTV)                                                                                                            \
   {                                                                                                                                       \
-    if (kg == 4)                                                                                                                          \
-      launch_kgroup<DTV, OPTV, 4>(stream, qk, vt, vt_nblk, out, TP, heads, items, max_items, bound);                                      \
-    else if (kg == 2)                                                                                                                     \
-      launch_kgroup<DTV, OPTV, 2>(stream, qk, vt, vt_nblk, out, TP, heads, items, max_items, bound);                                      \
+    if (kg == 4) {                                                                                                                        \
+      if (int rc_ = launch_kgroup<DTV, OPTV, 4>(stream, qk, vt, vt_nblk, out, TP, heads, items, max_items, bound)) return rc_;            \
+    } else if (kg == 2) {                                                                                                                 \
+      if (int rc_ = launch_kgroup<DTV, OPTV, 2>(stream, qk, vt, vt_nblk, out, TP, heads, items, max_items, bound)) return rc_;            \
+    }                                                                                                                                     \
     else if (ring)                                                                                                                        \
       hipLaunchKernelGGL((attention_h16_kernel<DTV, OPTV, true, 4>), dim3(max_items * heads), dim3(512), 0, stream, qk, vt, vt_nblk, out, TP, heads, items, bound, bq); \
     else if (g_rap_attn_h16_dma)                                                                                                          \
