@@ -384,18 +384,6 @@ int rap_layernorm_mod_h16(int32_t dtype, const float* x, uint16_t* out, int64_t 
                           int64_t mod_stride, const int32_t* token_row, void* stream);
 int rap_layernorm_affine_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* gain,
                              const float* shift, void* stream);
-/* Few-token calls (round 6, tuning key 21): the attention out-projection, its bias + residual add and the LayerNorm that follows it
- * (flow_model/layer.py:152-163 and the norm of the next branch, norm.py:74-76) in ONE kernel, as rap_sample / rap_dit_forward launch it for
- * calls of at most 4 096 token rows in the 16-bit modes.  A (rows, 512) in the operand type `dtype` (1 bf16 / 2 fp16); W_packed = the
- * (512, 512) weight (row n = output column n, row stride ldw) rearranged by rap_outproj_pack_h16 into MFMA-fragment order (512 * 512
- * elements: the kernel streams it with fully coalesced 1 KB loads); bias (512) fp32; h (rows, 512) is the residual stream -- fp32, or fp16 when h_f16 -- and is UPDATED IN
- * PLACE: h <- (A W^T + bias) + h (one saturating rounding when fp16); out (rows, 512) = LayerNorm of the stored h, eps 1e-5, times
- * (1 + mod[row][0:512]) plus mod[row][512:1024] with row = token_row[token] when mod != NULL (adaLN), else times gain plus shift (affine).
- * d must be 512. */
-int rap_outproj_pack_h16(const uint16_t* W, int32_t ldw, uint16_t* packed, void* stream);
-int rap_outproj_layernorm_h16(int32_t dtype, const uint16_t* A, const uint16_t* W_packed, const float* bias, void* h, int32_t h_f16,
-                              uint16_t* out, int64_t rows, int32_t d, const float* mod, int64_t mod_stride, const int32_t* token_row,
-                              const float* gain, const float* shift, void* stream);
 int rap_qknorm_h16(int32_t dtype, uint16_t* qk, int64_t TP, int32_t heads, const float* gamma_q, const float* gamma_k,
                    void* stream);
 
@@ -497,10 +485,6 @@ int rap_profile_collect_ex(float* h_ms_out, int64_t* h_count_out, int32_t n_clas
  *   key 19 few-token 16-bit / split-precision calls: the combine pass of every residual GEMM folded into the LayerNorm that follows it
  *          {1 (default), 0 = the round-5 launch sequence}.  Bit-identical in the 16-bit modes; in split precision the fused sequence
  *          also splits K of the out-projection (fp32-class agreement)
- *   key 21 few-token 16-bit calls (<= 4 096 token rows): attention out-projection + bias + residual + the following LayerNorm in one kernel
- *          (32 token rows x all 512 columns per block, the weight streamed through registers) instead of the split GEMM and the combine +
- *          LayerNorm pass {1 (default), 0 = never, 2 = every call of at most 8 192 token rows}.  Same function, the k-sum and the LayerNorm
- *          sums in another order: not bit-identical to the unfused sequence.  Needs key 19 = 1.
  *   key 20 16-bit attention of few-token calls (<= 4 096 token rows)
  *          {1 (default): the eight waves of a block are query waves x KEY GROUPS -- work items of 64 rows x 4 key groups up to 2 048 token
  *             rows, 128 rows x 2 key groups up to 4 096; the groups' partial (O, l, m) meet in LDS, nothing extra leaves the CU.  The keys of a

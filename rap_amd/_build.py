@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "librapflow.so")
 SOURCES = ["api.hip", "gemm_f32.hip", "attn_f32.hip", "norm.hip", "embed.hip", "adaln.hip", "sampler_kernels.hip",
-           "procrustes.hip", "gemm_h16.hip", "attn_h16.hip", "norm_h16.hip", "rigidity.hip", "transforms.hip", "overlap.hip", "spinnet.hip", "nn_metrics.hip", "fps.hip", "voxel.hip", "collate.hip", "outlier.hip", "voxel_sort.hip", "attn_x2.hip", "x2_pack.hip", "outproj_ln.hip"]
+           "procrustes.hip", "gemm_h16.hip", "attn_h16.hip", "norm_h16.hip", "rigidity.hip", "transforms.hip", "overlap.hip", "spinnet.hip", "nn_metrics.hip", "fps.hip", "voxel.hip", "collate.hip", "outlier.hip", "voxel_sort.hip", "attn_x2.hip", "x2_pack.hip"]
 HEADERS = ["common.h", "kernels.h", "kabsch.h", "half.h", os.path.join("..", "..", "include", "rapflow.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

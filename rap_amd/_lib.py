@@ -113,8 +113,6 @@ SIGNATURES = {
     "rap_gemm_h16_qkvnorm": (c_int32, [c_int32, _P, c_int32, _P, c_int32, _P, c_int32, c_int32, c_int32, _P, _P, c_float, _P, c_int32, _P]),
     "rap_attention_h16": (c_int32, [c_int32, _P, _P, c_int32, _P, c_int32, _P, c_int64, c_int32, _P, _P, c_size_t, _P]),
     "rap_layernorm_mod_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, c_int64, _P, _P]),
-    "rap_outproj_pack_h16": (c_int32, [_P, c_int32, _P, _P]),
-    "rap_outproj_layernorm_h16": (c_int32, [c_int32, _P, _P, _P, _P, c_int32, _P, c_int64, c_int32, _P, c_int64, _P, _P, _P, _P]),
     "rap_layernorm_affine_h16": (c_int32, [c_int32, _P, _P, c_int64, c_int32, _P, _P, _P]),
     "rap_qknorm_h16": (c_int32, [c_int32, _P, c_int64, c_int32, _P, _P, _P]),
     "rap_x2_pack": (c_int32, [_P, c_int64, c_int64, c_int32, c_float, _P, _P]),

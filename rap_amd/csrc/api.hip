@@ -93,7 +93,6 @@ struct LayerW {
 struct LayerWH {
   const u16* Wqkv[2];
   const u16* Wout[2];
-  const u16* WoutP[2] = {nullptr, nullptr};      // the same weights in MFMA-fragment order (outproj_ln.hip; 16-bit modes at d = 512 only)
   const u16* Wff1p;   // value/gate interleaved, as the fp32 packing
   const u16* Wff2;
   // split precision (RAP_DT_F32X2): the planes hold w * 2^e per tensor; s_* = 2^-e, the factor the epilogue applies to the accumulators
@@ -160,7 +159,6 @@ extern rap_tuning_t g_rap_attn_h16_dma;          // attn_h16.hip
 extern rap_tuning_t g_rap_gemm_f32_persistent;   // gemm_f32.hip
 extern rap_tuning_t g_rap_attn_x2_wpe;           // attn_x2.hip
 extern rap_tuning_t g_rap_attn_h16_small;        // attn_h16.hip, tuning key 20
-extern rap_tuning_t g_rap_outproj_ln;            // outproj_ln.hip, tuning key 21
 rap_tuning_t g_rap_attn_lpt = 1;               // tuning key 15: attention work lists longest-segment-first (1, default) or in segment order (0)
 // tuning key 17: split precision takes over from this many token rows (align_up(TP, 256)) per call; SMALLER calls of a model in compute
 // dtype 3 run the exact-fp32 kernels -- both are fp32-accurate, and below a few thousand tokens every kernel of a layer sits at the launch
@@ -198,7 +196,6 @@ extern "C" int rap_set_tuning(int32_t key, int32_t value) {
   if (key == 17 && value >= 0) { g_rap_x2_min_rows = value; return RAP_OK; }   // split precision from this many token rows per call (smaller calls: exact fp32)
   if (key == 18 && value >= 0) { g_rap_ring_blocks = value; return RAP_OK; }      // four-stage ring of the 128 x 128 16-bit GEMM up to this many blocks per launch (0 = never)
   if (key == 19 && (value == 0 || value == 1)) { g_rap_small_fused = value; return RAP_OK; }      // combine + LayerNorm fusion of few-token calls
-  if (key == 21 && (value == 0 || value == 1 || value == 2)) { g_rap_outproj_ln = value; return RAP_OK; }      // few-token 16-bit calls: out-projection + residual + LayerNorm in one kernel
   if (key == 20 && (value == 0 || value == 1 || value == 2 || value == 64 || value == 128 || value == 66 || value == 130)) { g_rap_attn_h16_small = value; return RAP_OK; }   // 16-bit attention of few-token calls: 64 / 128-row work items + four-stage ring
   if (key == 16 && (value == 2 || value == 4)) { g_rap_attn_x2_wpe = value; return RAP_OK; }   // split-precision attention: 1 / 2 blocks per CU
   return RAP_ERR_INVALID;
@@ -426,8 +423,7 @@ extern "C" int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* st
   if (!hw.blob) {
     hipStream_t stream = (hipStream_t)stream_;
     const size_t d = m->d, L = m->L;
-    const bool packed_out = d == 512;          // few-token calls stream the out-projection weight in fragment order (outproj_ln.hip)
-    const size_t per_layer = 2 * (3 * d * d + d * d) + 8 * d * d + 4 * d * d + (packed_out ? 2 * d * d : 0);
+    const size_t per_layer = 2 * (3 * d * d + d * d) + 8 * d * d + 4 * d * d;
     if (hipMalloc((void**)&hw.blob, per_layer * L * sizeof(u16)) != hipSuccess) { hw.blob = nullptr; return RAP_ERR_ALLOC; }
     u16* q = hw.blob;
     int rc = RAP_OK;
@@ -443,11 +439,6 @@ extern "C" int rap_model_set_compute_dtype(rap_model* m, int32_t dtype, void* st
       for (int a = 0; a < 2; ++a) {
         lh.Wqkv[a] = conv(lw.Wqkv[a], 3 * d * d);
         lh.Wout[a] = conv(lw.Wout[a], d * d);
-        if (packed_out) {
-          u16* dst = q; q += d * d;
-          if (rc == RAP_OK) rc = launch_outproj_pack_h16(stream, lh.Wout[a], (int)d, dst);
-          lh.WoutP[a] = dst;
-        }
       }
       lh.Wff1p = conv(lw.Wff1p, 8 * d * d);
       lh.Wff2 = conv(lw.Wff2, 4 * d * d);
@@ -786,16 +777,6 @@ static int forward_step(const rap_model* m, const Workspace& w, hipStream_t stre
                                     a == 0 ? w.max_items_part : w.max_items_batch, bound, prescale ? 1 : 0, w.attn_bq, w.attn_kg);
         }
         if (rc) return rc;
-        if (fused && lh.WoutP[a] && outproj_ln_wanted(dt, (long)TP, d, d)) {
-          // few-token calls: out-projection + bias + residual + the NEXT LayerNorm in one kernel (outproj_ln.hip; 32 token rows x all d
-          // columns per block, the weight streamed through registers) instead of the split GEMM and the combine + LayerNorm pass below
-          ProfScope ps(stream, 2);
-          rc = launch_outproj_ln_h16(stream, dt, w.atth, d, lh.WoutP[a], lw.bout[a], w.h16 ? (void*)w.h16 : (void*)w.h, hres_f16, w.xnh, TP, d, d,
-                                     a == 0 ? mod + (size_t)(j + 1) * 2 * d : nullptr, mod_stride, token_row, lw.ffn_g, lw.ffn_b);
-          if (rc) return rc;
-          xn_ready = true;
-          continue;
-        }
         GemmParamsH o{};
         o.A = w.atth; o.lda = d; o.W = lh.Wout[a]; o.ldw = d; o.ldc = d; o.M = TP; o.N = d; o.K = d;
         o.bias = lw.bout[a]; o.ldr = d;
@@ -1215,17 +1196,6 @@ extern "C" int rap_attention_h16(int32_t dtype, const uint16_t* qk, const uint16
   if ((rc = attn_ws_sanitize(stream, cu_seqlens, nseg, TP, ws, &cu_seqlens))) return rc;
   if ((rc = launch_build_attn_worklist(stream, cu_seqlens, nseg, (AttnWorkItem*)ws, max_items, bq))) return rc;
   return launch_attention_h16(stream, dtype, qk, vt, vt_nblk, out, (int)TP, heads, (const AttnWorkItem*)ws, max_items, logit_bound, 0, bq, kg);
-}
-extern "C" int rap_outproj_pack_h16(const uint16_t* W, int32_t ldw, uint16_t* packed, void* stream) {
-  if (!W || !packed || ldw < 512 || (ldw & 7)) return RAP_ERR_INVALID;
-  return launch_outproj_pack_h16((hipStream_t)stream, W, ldw, packed);
-}
-extern "C" int rap_outproj_layernorm_h16(int32_t dtype, const uint16_t* A, const uint16_t* W_packed, const float* bias, void* h, int32_t h_f16,
-                                         uint16_t* out, int64_t rows, int32_t d, const float* mod, int64_t mod_stride, const int32_t* token_row,
-                                         const float* gain, const float* shift, void* stream) {
-  if (!A || !W_packed || !h || !out || rows < 0 || rows > 0x7fffffffLL / 512 || (!mod && (!gain || !shift))) return RAP_ERR_INVALID;
-  return launch_outproj_ln_h16((hipStream_t)stream, dtype, A, d, W_packed, bias, h, h_f16 ? 1 : 0, out, (int)rows, d, d, mod, (long)mod_stride,
-                               token_row, gain, shift);
 }
 extern "C" int rap_layernorm_mod_h16(int32_t dtype, const float* x, uint16_t* out, int64_t TP, int32_t d, const float* mod,
                                      int64_t mod_stride, const int32_t* token_row, void* stream) {

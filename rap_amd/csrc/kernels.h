@@ -169,16 +169,6 @@ bool attention_h16_wants_prescaled_q(int dtype, bool bounded);
 int attention_h16_block_queries(int dtype, long rows = 0);      // work-list granularity of the 16-bit attention for a call of `rows` token rows
 bool attention_h16_forced();                                    // tuning key 20 holds one of its A/B values (a forced item size / key groups)
 int attention_h16_key_groups(int dtype, long rows = 0);         // key groups per block for the same call (1 unless tuning key 20 says so)
-// Few-token calls (round 6, outproj_ln.hip): attention out-projection (d = K = 512) + bias + residual + the LayerNorm that follows, one kernel.
-// h: the residual stream (fp32, or fp16 when h_f16), updated in place; out: the LayerNorm output (16-bit operand type); modulation as
-// launch_resid_combine_ln_h16 (mod != null: adaLN rows mod / mod + d per sample through token_row, else affine gain / shift)
-bool outproj_ln_wanted(int dtype, long rows, int d, int K);      // tuning key 21
-// W (512, ldw) 16-bit, row n = output column n  ->  packed (512 * 512): fragment (n-tile T of 32 rows, k-step S of 16) = 64 lanes x 16 bytes at
-// ((T * 32 + S) * 64 + lane) * 8 elements, lane = 32 hi + l31 holding W[32 T + l31][16 S + 8 hi .. +7]: one global_load_dwordx4 of a wave = 1 KB contiguous
-int launch_outproj_pack_h16(hipStream_t stream, const uint16_t* W, int ldw, uint16_t* packed);
-int launch_outproj_ln_h16(hipStream_t stream, int dtype, const uint16_t* A, int lda, const uint16_t* W_packed, const float* bias, void* h,
-                          int h_f16, uint16_t* out, int rows, int d, int K, const float* mod, long mod_stride, const int32_t* token_row,
-                          const float* gain, const float* shift);
 // per-head logit bounds of one attention branch after qk-norm: out[h] = 8 * max_j|gamma_q[h][j]| * max_j|gamma_k[h][j]|
 int launch_qk_logit_bound(hipStream_t stream, const float* gamma_q, const float* gamma_k, int heads, float* out);
 // LayerNorm with 16-bit output (fp32 statistics), same modulation forms as launch_layernorm_*

@@ -24,13 +24,11 @@ def arg(name, default):
     return default
 
 
-VARIANTS = {"r6": {18: 256, 19: 1, 7: 1, 20: 1, 21: 1}, "r5": {18: 0, 19: 0, 7: 0, 20: 0, 21: 0}, "ring-only": {18: 256, 19: 0, 7: 1, 20: 0}, "fused-only": {18: 0, 19: 1, 7: 1, 20: 0},
+VARIANTS = {"r6": {18: 256, 19: 1, 7: 1, 20: 1}, "r5": {18: 0, 19: 0, 7: 0, 20: 0}, "ring-only": {18: 256, 19: 0, 7: 1, 20: 0}, "fused-only": {18: 0, 19: 1, 7: 1, 20: 0},
             "no-attn-small": {18: 256, 19: 1, 7: 1, 20: 0}, "bq64": {18: 256, 19: 1, 7: 1, 20: 64}, "bq128": {18: 256, 19: 1, 7: 1, 20: 128}, "ring512": {18: 512, 19: 1, 7: 1, 20: 1}, "ring1024": {18: 1024, 19: 1, 7: 1, 20: 1}, "ring4096": {18: 4096, 19: 1, 7: 1, 20: 1},
             "unfused-qknorm": {18: 256, 19: 1, 7: 0, 20: 1},
             # 16-bit attention: no key groups (the first form of round 6) / forced 64 rows x 4 key groups / forced 128 rows x 2 key groups
-            "no-kgroups": {18: 256, 19: 1, 7: 1, 20: 2}, "kg4": {18: 256, 19: 1, 7: 1, 20: 66}, "kg2": {18: 256, 19: 1, 7: 1, 20: 130},
-            # out-projection + residual + LayerNorm in one kernel (key 21): off / forced up to 8 192 rows
-            "no-outproj-ln": {18: 256, 19: 1, 7: 1, 20: 1, 21: 0}, "outproj-ln-8k": {18: 256, 19: 1, 7: 1, 20: 1, 21: 2}}
+            "no-kgroups": {18: 256, 19: 1, 7: 1, 20: 2}, "kg4": {18: 256, 19: 1, 7: 1, 20: 66}, "kg2": {18: 256, 19: 1, 7: 1, 20: 130}}
 dev = torch.device("cuda:0")
 lib = _lib.load()
 cfg = dict(S.RAP_12)

@@ -75,7 +75,6 @@ def test_ring_and_fused_combine_layernorm_are_bit_identical_to_the_round5_launch
     outs = {}
     try:
         assert lib.rap_set_tuning(17, 0) == 0                      # split precision at every size (small calls default to exact fp32)
-        assert lib.rap_set_tuning(21, 0) == 0                      # (the fused out-projection + LayerNorm kernel re-associates the k-sum: its own tests below)
         # tuning keys 18 (GEMM ring), 19 (combine + LayerNorm), 20 (16-bit attention: 64 / 128-row work items + four-stage K / V^T ring)
         # (key 20 = 2: small work items + ring WITHOUT key groups -- the bit-identical form; the default, 1, adds key groups: tests below)
         for tag, ring, fused, attn in (("r6", 256, 1, 2), ("ring-only", 256, 0, 0), ("fused-only", 0, 1, 0), ("attn-only", 0, 0, 2), ("r5", 0, 0, 0)):
@@ -83,7 +82,6 @@ def test_ring_and_fused_combine_layernorm_are_bit_identical_to_the_round5_launch
             outs[tag], ctx = _sample(dev, cdt, rdt, parts)
     finally:
         assert lib.rap_set_tuning(18, 256) == 0 and lib.rap_set_tuning(19, 1) == 0 and lib.rap_set_tuning(20, 1) == 0 and lib.rap_set_tuning(17, 1024) == 0
-        assert lib.rap_set_tuning(21, 1) == 0
     for tag in ("r6", "ring-only", "fused-only", "attn-only"):
         for k, v in outs["r5"].items():
             assert not torch.isnan(v).any()
@@ -210,102 +208,3 @@ def test_key_group_attention_in_the_model_path(dev, cdt, rdt, geom):
         assert all(torch.isfinite(v).all() for v in outs[m].values())
         assert e[m] < 2e-2 and e[m] < 2.0 * e[2] + 1e-3, (m, e)
         assert d[m] < 1e-2, (m, d)
-
-
-# ---------------------------------------------------------------------------------------------
-# out-projection + bias + residual + LayerNorm in one kernel (outproj_ln.hip, tuning key 21)
-# ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("form", ["adaln", "affine"])
-@pytest.mark.parametrize("h_f16", [0, 1], ids=["fp32-stream", "fp16-stream"])
-@pytest.mark.parametrize("dt", [1, 2], ids=["bf16", "f16"])
-def test_outproj_layernorm_kernel_against_fp64(dev, dt, h_f16, form):
-    """rap_outproj_layernorm_h16 against fp64 on the ROUNDED operands: the new residual-stream value (A W^T + bias) + h -- fp32 accumulation of
-    512 exact products, ONE saturating rounding when the stream is fp16 (a row driven beyond 65 504 must saturate, not overflow) -- and the
-    LayerNorm of the STORED value (eps 1e-5, adaLN rows through token_row or affine gain / shift) at one rounding of the operand type.
-    Row counts that are and are not multiples of the 32-row block."""
-    import test_h16_gpu as T
-    lib = _lib.load()
-    for rows in (200, 2048):
-        g = torch.Generator().manual_seed(100 * dt + 10 * h_f16 + rows)
-        A = torch.randn(rows, 512, generator=g)
-        A[7] *= 40.0                                        # row 7: A W^T ~ N(0, 45^2) ...
-        A = T.to_h(A, dt)
-        W = T.to_h(torch.randn(512, 512, generator=g) * 0.05, dt)
-        bias = torch.randn(512, generator=g)
-        h0 = torch.randn(rows, 512, generator=g) * 2.0
-        if h_f16:
-            h0[7] = 65504.0                                 # ... on top of the largest finite fp16: a third of the row's columns pass 65 520 (would round to inf)
-        h0 = h0.half() if h_f16 else h0
-        nb = 3
-        mod = torch.randn(nb, 2048, generator=g) * 0.3      # adaLN rows: scale at [1024, 1536), shift at [1536, 2048) of a 2048-float row
-        token_row = torch.randint(0, nb, (rows,), generator=g, dtype=torch.int32)
-        gain, shift = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g) * 0.1
-        Ad, Wraw, bd, hd = A.to(dev), W.to(dev), bias.to(dev), h0.clone().to(dev)
-        Wd = torch.empty_like(Wraw)                         # the weight in MFMA-fragment order
-        _lib.check(lib.rap_outproj_pack_h16(_lib.ptr(Wraw), 512, _lib.ptr(Wd), T.stream(dev)), "rap_outproj_pack_h16")
-        out = torch.full((rows, 512), float("nan"), dtype=T.TORCH_DT[dt], device=dev)
-        modd, trd, gd, sd_ = mod.to(dev), token_row.to(dev), gain.to(dev), shift.to(dev)
-        if form == "adaln":
-            rc = lib.rap_outproj_layernorm_h16(dt, _lib.ptr(Ad), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(hd), h_f16, _lib.ptr(out), rows, 512,
-                                               _lib.ptr(modd[:, 1024:]), 2048, _lib.ptr(trd), None, None, T.stream(dev))
-        else:
-            rc = lib.rap_outproj_layernorm_h16(dt, _lib.ptr(Ad), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(hd), h_f16, _lib.ptr(out), rows, 512,
-                                               None, 0, None, _lib.ptr(gd), _lib.ptr(sd_), T.stream(dev))
-        _lib.check(rc, "rap_outproj_layernorm_h16")
-        torch.cuda.synchronize()
-        h_new, out = hd.cpu(), out.cpu()
-        v = A.double() @ W.double().t() + bias.double() + h0.double()
-        assert torch.isfinite(h_new.float()).all() and torch.isfinite(out.float()).all()
-        if h_f16:
-            want = v.clamp(-65504.0, 65504.0)
-            assert (v[7] > 65520.0).sum() > 100 and (h_new[7].float() == 65504.0).sum() >= (v[7] > 65520.0).sum()      # saturated, finite
-            err = ((h_new.double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
-            assert err < 2.0 ** -11 * 1.01 + 1e-5, err                     # one fp16 rounding (+ fp32 accumulation noise)
-        else:
-            err = ((h_new.double() - v).abs() / v.abs().clamp(min=1.0)).max().item()
-            assert err < 2e-6, err
-        # LayerNorm of the value the kernel STORED
-        x = h_new.double()
-        mean = x.mean(dim=1, keepdim=True)
-        var = ((x - mean) ** 2).mean(dim=1, keepdim=True)
-        xn = (x - mean) / torch.sqrt(var + 1e-5)
-        if form == "adaln":
-            ref = xn * (1.0 + mod[token_row.long(), 1024:1536].double()) + mod[token_row.long(), 1536:2048].double()
-        else:
-            ref = xn * gain.double() + shift.double()
-        keep = torch.ones(rows, dtype=torch.bool)
-        keep[7] = not h_f16            # (the saturated row: |x - mean| ~ 30 on values of 65 504 is beyond fp32 statistics -- only finiteness is asked of it)
-        e2 = ((out.double() - ref).abs() / ref.abs().clamp(min=1.0))[keep].max().item()
-        print(f"outproj+LN dt={dt} h_f16={h_f16} {form} rows={rows}: stream err {err:.2e}, LayerNorm err {e2:.2e}")
-        assert e2 < 1.01 * T.ULP[dt] + 1e-5, e2
-        # error behaviour: d != 512 is refused
-        assert lib.rap_outproj_layernorm_h16(dt, _lib.ptr(Ad), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(hd), h_f16, _lib.ptr(out.to(dev)), rows, 256,
-                                             None, 0, None, _lib.ptr(gd), _lib.ptr(sd_), T.stream(dev)) != 0
-
-
-OPL_CASES = [("bfloat16", "float16", "c0-geometry"), ("float16", "float32", "c0-geometry"), ("bfloat16", "float32", "ragged-2-samples"),
-             ("float16", "float16", "4000-tokens")]
-
-
-@pytest.mark.parametrize("cdt,rdt,geom", OPL_CASES, ids=[f"{g}-{c}-{r}-stream" for c, r, g in OPL_CASES])
-def test_fused_outprojection_layernorm_in_the_model_path(dev, cdt, rdt, geom):
-    """Whole sampling calls with tuning key 21 on (default) and off: the fused kernel replaces the split out-projection GEMM and the combine +
-    LayerNorm pass of both attention branches of every layer.  Same function with the k-sum in one chain: the two runs differ at the level of
-    16-bit roundings of the LayerNorm outputs, and the fused run is no further from the oracle than the unfused one."""
-    parts = GEOMS[geom]
-    lib = _lib.load()
-    outs = {}
-    try:
-        for mode in (0, 1):
-            assert lib.rap_set_tuning(21, mode) == 0
-            outs[mode], ctx = _sample(dev, cdt, rdt, parts)
-    finally:
-        assert lib.rap_set_tuning(21, 1) == 0
-    ref = _oracle(ctx, parts)
-    e = {m: float((outs[m]["end_point_trajectory"] - ref["end_point_trajectory"]).abs().max()) for m in outs}
-    dlt = float((outs[1]["end_point_trajectory"] - outs[0]["end_point_trajectory"]).abs().max())
-    print(f"{cdt}/{rdt} {geom}: end points vs the oracle {e}, fused vs unfused {dlt:.2e}")
-    assert all(torch.isfinite(v).all() for v in outs[1].values())
-    assert not torch.equal(outs[1]["end_point_trajectory"], outs[0]["end_point_trajectory"])      # (the switch reaches the launch)
-    assert e[1] < 2e-2 and e[1] < 2.0 * e[0] + 1e-3, e
-    assert dlt < 1e-2, dlt
